@@ -1,0 +1,617 @@
+"""Proof / witness formats of the reference, parsed into plain host-side records.
+
+This is the drop-in boundary on the *input* side: the reference's
+callers hand a verifier one of four files, and this module reads (and writes) all
+of them without touching the reference's code:
+
+  A  stark101 ``proof.json``   written by ``python -m fibsquare``
+        (stark101/scripts/fibsquare/prover.py:108,143-147,150-167, __main__.py:8-11)
+  B  stark101 ``proof.wit``    (stark101/scripts/generate_wit.py:13-30; read by
+        stark101/src/main.simf:13-16 as witness::P_MT_ROOT / P_EVALS / FRI_LAYERS /
+        FRI_LAST_LAYER)
+  C  stwo ``proof.json``       (schema consumed by stwo-verifier/scripts/generate_wit.py:106-245)
+  D  stwo ``proof.wit``        (stwo-verifier/scripts/generate_wit.py:218-243; read by
+        stwo-verifier/src/main.simf:10-15)
+
+A ``.wit`` file is a JSON object ``{NAME: {"value": <SimplicityHL literal>, "type": ...}}``;
+the literal grammar needed here is integers (decimal or 0x-hex), tuples ``( .. )``,
+arrays ``[ .. ]`` and ``list![ .. ]``.
+
+Hashes are kept as 32 raw bytes in SHA-256 output order (== the big-endian u256 the
+reference prints).  Field elements are raw ``u32`` words exactly as given -- the
+reference never range-checks them (SURVEY.md 7 "Unreduced / adversarial witness
+values"), so neither does the parser.
+"""
+from __future__ import annotations
+
+import json
+from dataclasses import dataclass, field
+from typing import Any, List, Sequence, Tuple
+
+import numpy as np
+
+MAX_LIST = 31  # SimplicityHL List<T, 32> holds strictly fewer than 32 elements
+
+
+class MalformedProof(ValueError):
+    """The input cannot be typed as the reference's witness (``simfony run`` exits 1 with a
+    type error before executing anything: simfony-cli/src/main.rs:77-81,187-190)."""
+
+
+# --------------------------------------------------------------------------- helpers
+def u256_to_bytes(v: int) -> bytes:
+    if not (0 <= v < 1 << 256):
+        raise MalformedProof("u256 out of range")
+    return int(v).to_bytes(32, "big")
+
+
+def bytes_to_u256(b: bytes) -> int:
+    return int.from_bytes(b, "big")
+
+
+def _u32(v: Any) -> int:
+    v = int(v)
+    if not (0 <= v < 1 << 32):
+        raise MalformedProof("u32 out of range: %r" % (v,))
+    return v
+
+
+def _path(nodes: Sequence[Any]) -> np.ndarray:
+    """List of u256 ints / 32-byte sequences -> uint8[len, 32] (leaf -> root order)."""
+    if len(nodes) > MAX_LIST:
+        raise MalformedProof("List<u256, 32> holds at most 31 elements")
+    out = np.zeros((len(nodes), 32), dtype=np.uint8)
+    for i, n in enumerate(nodes):
+        if isinstance(n, int):
+            out[i] = np.frombuffer(u256_to_bytes(n), dtype=np.uint8)
+        else:
+            b = bytes(n)
+            if len(b) != 32:
+                raise MalformedProof("expected 32 bytes")
+            out[i] = np.frombuffer(b, dtype=np.uint8)
+    return out
+
+
+# ----------------------------------------------------------- SimplicityHL literal parser
+def parse_literal(text: str) -> Any:
+    """Parse a SimplicityHL value literal into nested Python lists / ints."""
+    pos = 0
+    n = len(text)
+
+    def skip() -> None:
+        nonlocal pos
+        while pos < n and text[pos] in " \t\r\n":
+            pos += 1
+
+    def value() -> Any:
+        nonlocal pos
+        skip()
+        if pos >= n:
+            raise MalformedProof("unexpected end of literal")
+        ch = text[pos]
+        if text.startswith("list!", pos):
+            pos += 5
+            skip()
+            if pos >= n or text[pos] != "[":
+                raise MalformedProof("expected '[' after list!")
+            return seq("]")
+        if ch == "(":
+            return seq(")")
+        if ch == "[":
+            return seq("]")
+        start = pos
+        if text.startswith("0x", pos) or text.startswith("0X", pos):
+            pos += 2
+            while pos < n and text[pos] in "0123456789abcdefABCDEF_":
+                pos += 1
+            return int(text[start:pos].replace("_", ""), 16)
+        while pos < n and (text[pos].isdigit() or text[pos] == "_"):
+            pos += 1
+        if start == pos:
+            raise MalformedProof("unexpected character %r at %d" % (ch, pos))
+        return int(text[start:pos].replace("_", ""))
+
+    def seq(close: str) -> Any:
+        nonlocal pos
+        pos += 1  # opening bracket
+        items: List[Any] = []
+        commas = 0
+        while True:
+            skip()
+            if pos >= n:
+                raise MalformedProof("unterminated sequence")
+            if text[pos] == close:
+                pos += 1
+                # "(x)" is a parenthesised value, not a 1-tuple (generate_wit.py:8 wraps
+                # every FriLayer in a redundant pair of parentheses)
+                if close == ")" and len(items) == 1 and commas == 0:
+                    return items[0]
+                return items
+            items.append(value())
+            skip()
+            if pos < n and text[pos] == ",":
+                pos += 1
+                commas += 1
+
+    v = value()
+    skip()
+    if pos != n:
+        raise MalformedProof("trailing characters in literal")
+    return v
+
+
+# ------------------------------------------------------------------------- stark101
+@dataclass
+class Stark101Eval:
+    """``Eval = (u32, MerkleProof32)`` -- stark101/src/air.simf:24."""
+    ev: int
+    path: np.ndarray  # uint8[len, 32]
+
+
+@dataclass
+class Stark101Layer:
+    """``FriLayer`` -- stark101/src/fri.simf:30."""
+    root: bytes
+    beta: int
+    cpa: Stark101Eval
+    cpb: Stark101Eval
+
+
+@dataclass
+class Stark101Proof:
+    """``FibSquareProof`` -- stark101/src/verifier.simf:17."""
+    root: bytes
+    evals: List[Stark101Eval]
+    layers: List[Stark101Layer]
+    last: int
+
+    def copy(self) -> "Stark101Proof":
+        return Stark101Proof(
+            self.root,
+            [Stark101Eval(e.ev, e.path.copy()) for e in self.evals],
+            [Stark101Layer(l.root, l.beta, Stark101Eval(l.cpa.ev, l.cpa.path.copy()),
+                           Stark101Eval(l.cpb.ev, l.cpb.path.copy())) for l in self.layers],
+            self.last)
+
+
+def _s101_from_parts(root: Any, evals: Any, layers: Any, last: Any) -> Stark101Proof:
+    try:
+        if len(evals) != 3:
+            raise MalformedProof("P_EVALS must hold three evaluations")
+        if len(layers) > MAX_LIST:
+            raise MalformedProof("List<FriLayer, 32> holds at most 31 layers")
+        ev = [Stark101Eval(_u32(e[0]), _path(e[1])) for e in evals]
+        ls = []
+        for l in layers:
+            if len(l) != 6:
+                raise MalformedProof("FriLayer has six fields")
+            ls.append(Stark101Layer(u256_to_bytes(int(l[0])), _u32(l[1]),
+                                    Stark101Eval(_u32(l[2]), _path(l[3])),
+                                    Stark101Eval(_u32(l[4]), _path(l[5]))))
+        return Stark101Proof(u256_to_bytes(int(root)), ev, ls, _u32(last))
+    except (TypeError, IndexError, KeyError) as e:  # wrong nesting
+        raise MalformedProof(str(e)) from e
+
+
+def stark101_from_json(obj: Any) -> Stark101Proof:
+    """Format A: the prover's ``res`` dict / ``target/proof.json``."""
+    if isinstance(obj, (str, bytes)):
+        obj = json.loads(obj)
+    try:
+        return _s101_from_parts(obj["p_mt_root"], obj["evals"], obj["fri_layers"],
+                                obj["fri_last_layer"])
+    except KeyError as e:
+        raise MalformedProof("missing key %s" % e) from e
+
+
+def stark101_to_json(p: Stark101Proof) -> dict:
+    def pth(a: np.ndarray) -> List[int]:
+        return [bytes_to_u256(bytes(r)) for r in a]
+    return {
+        "p_mt_root": bytes_to_u256(p.root),
+        "evals": [[e.ev, pth(e.path)] for e in p.evals],
+        "fri_layers": [[bytes_to_u256(l.root), l.beta, l.cpa.ev, pth(l.cpa.path), l.cpb.ev,
+                        pth(l.cpb.path)] for l in p.layers],
+        "fri_last_layer": p.last,
+    }
+
+
+def stark101_from_wit(text: Any) -> Stark101Proof:
+    """Format B: ``proof.wit`` (stark101/scripts/generate_wit.py:13-30)."""
+    obj = json.loads(text) if isinstance(text, (str, bytes)) else text
+    try:
+        root = parse_literal(obj["P_MT_ROOT"]["value"])
+        evals = parse_literal(obj["P_EVALS"]["value"])
+        layers = parse_literal(obj["FRI_LAYERS"]["value"])
+        last = parse_literal(obj["FRI_LAST_LAYER"]["value"])
+    except KeyError as e:
+        raise MalformedProof("missing witness %s" % e) from e
+    return _s101_from_parts(root, evals, layers, last)
+
+
+def stark101_to_wit(p: Stark101Proof) -> str:
+    """Writer for format B, same text the reference's generate_wit.py prints."""
+    j = stark101_to_json(p)
+
+    def layer(l: List[Any]) -> str:
+        return "((%s, %s, %s, list!%s, %s, list!%s))" % (l[0], l[1], l[2], l[3], l[4], l[5])
+
+    p_evals = ", ".join("(%s, list!%s)" % (x[0], x[1]) for x in j["evals"])
+    fri_layers = ", ".join(layer(l) for l in j["fri_layers"])
+    res = {
+        "P_MT_ROOT": {"value": str(j["p_mt_root"]), "type": "u256"},
+        "P_EVALS": {"value": "(%s)" % p_evals,
+                    "type": "((u32, List<u256, 32>), (u32, List<u256, 32>), (u32, List<u256, 32>))"},
+        "FRI_LAYERS": {"value": "list![%s]" % fri_layers,
+                       "type": "List<((u256, u32, u32, List<u256, 32>, u32, List<u256, 32>), 32)"},
+        "FRI_LAST_LAYER": {"value": str(j["fri_last_layer"]), "type": "u32"},
+    }
+    return json.dumps(res, indent=4)
+
+
+# ----------------------------------------------------------------------------- stwo
+N_CP_PARTITIONS = 16  # evals/composition_poly.simf:12
+
+
+@dataclass(frozen=True)
+class StwoConfig:
+    """Runtime form of the compile-time macros in stwo-verifier/src/config.simf:10-51."""
+    n_cols: int = 4        # NUM_COLUMNS
+    trace_log: int = 9     # TRACE_LOG_SIZE
+    lde_log: int = 13      # LDE_LOG_SIZE
+    n_queries: int = 16    # NUM_FRI_QUERIES
+    n_layers: int = 8      # NUM_FRI_LAYERS (inner layers)
+    pow_bits: int = 5      # POW_TARGET_64 = 2^(64-pow_bits) - 1, strict '<'
+
+    @property
+    def pow_target(self) -> int:
+        return (1 << (64 - self.pow_bits)) - 1
+
+    @property
+    def log_blowup(self) -> int:
+        return self.lde_log - self.trace_log
+
+    def fri_path_len(self, layer: int) -> int:
+        """Merkle path length of FRI layer `layer` (0 = first): fri/layers.simf:40-48."""
+        return self.lde_log - 1 - layer
+
+    @property
+    def packed_bytes(self) -> int:
+        """Algorithmic bytes per proof."""
+        N, L, K, Q = self.n_cols, self.lde_log, self.n_layers, self.n_queries
+        return (96 + Q * (4 * N + 64 + 64 * L) + 16 * (N + 16) + 32 * (K + 1) + 16
+                + Q * sum(16 + 32 * (L - 1 - i) for i in range(K + 1)) + 8)
+
+    @property
+    def compressions(self) -> int:
+        """SHA-256 compression calls per proof of the reference algorithm."""
+        N, L, K, Q = self.n_cols, self.lde_log, self.n_layers, self.n_queries
+
+        def blk(n: int) -> int:
+            return (n + 9 + 63) // 64
+        return (Q * (blk(4 * N) + 2 + 4 * L) + Q * sum(4 + 2 * (L - 1 - i) for i in range(K + 1))
+                + 6 + (4 + K + (Q + 7) // 8) + blk(32 + 16 * (N + 16)) + 2 * (K + 1) + 2)
+
+
+TESTING_CONFIG = StwoConfig(4, 3, 4, 1, 2, 5)      # config.simf:16-33
+PRODUCTION_CONFIG = StwoConfig(4, 9, 13, 16, 8, 5)  # config.simf:34-52
+
+
+@dataclass
+class StwoProof:
+    """``StarkProof`` -- stwo-verifier/src/verifier.simf:22-29, arrays in query-major order."""
+    cfg: StwoConfig
+    roots: np.ndarray        # uint8[3, 32]          Commitments (const, trace, cp)
+    oods_trace: np.ndarray   # uint32[n_cols, 4]     OodsEvals.0
+    oods_cp: np.ndarray      # uint32[16, 4]         OodsEvals.1
+    trace_vals: np.ndarray   # uint32[Q, n_cols]
+    cp_vals: np.ndarray      # uint32[Q, 16]
+    trace_paths: List[np.ndarray]       # Q x uint8[len, 32]
+    cp_paths: List[np.ndarray]          # Q x uint8[len, 32]
+    fri_roots: np.ndarray    # uint8[K+1, 32]        first + inner commitments
+    last_layer: np.ndarray   # uint32[4]
+    fri_witness: np.ndarray  # uint32[K+1, Q, 4]
+    fri_paths: List[List[np.ndarray]]   # (K+1) x Q x uint8[len, 32]
+    pow_nonce: int
+
+    def copy(self) -> "StwoProof":
+        return StwoProof(self.cfg, self.roots.copy(), self.oods_trace.copy(), self.oods_cp.copy(),
+                         self.trace_vals.copy(), self.cp_vals.copy(),
+                         [p.copy() for p in self.trace_paths], [p.copy() for p in self.cp_paths],
+                         self.fri_roots.copy(), self.last_layer.copy(), self.fri_witness.copy(),
+                         [[p.copy() for p in l] for l in self.fri_paths], self.pow_nonce)
+
+
+def _qm31(node: Any) -> Tuple[int, int, int, int]:
+    x = node
+    while isinstance(x, list) and len(x) == 1 and isinstance(x[0], list):
+        x = x[0]
+    try:
+        (a, b), (c, d) = x
+    except (TypeError, ValueError) as e:
+        raise MalformedProof("bad QM31 literal") from e
+    return _u32(a), _u32(b), _u32(c), _u32(d)
+
+
+def _split(lst: Sequence[Any], n: int) -> List[Sequence[Any]]:
+    if n <= 0 or len(lst) % n:
+        raise MalformedProof("list length must be divisible by the number of queries")
+    k = len(lst) // n
+    return [lst[i * k:(i + 1) * k] for i in range(n)]
+
+
+def stwo_from_json(data: Any, trace_log: int | None = None) -> StwoProof:
+    """Format C.  The JSON carries pow_bits / log_blowup / n_queries; the LDE size is
+    implied by the Merkle path length (the reference hard-codes it: config.simf:21,39)."""
+    if isinstance(data, (str, bytes)):
+        data = json.loads(data)
+    try:
+        conf = data.get("config", {})
+        fri_conf = conf.get("fri_config", {})
+        Q = int(fri_conf.get("n_queries", 1))
+        roots = np.stack([np.frombuffer(bytes(c), dtype=np.uint8) for c in data["commitments"]])
+        if roots.shape != (3, 32):
+            raise MalformedProof("expected three 32-byte commitments")
+        sv = data["sampled_values"]
+        oods_trace = np.array([_qm31(c) for c in sv[1]], dtype=np.uint32).reshape(-1, 4)
+        oods_cp = np.array([_qm31(c) for c in sv[2]], dtype=np.uint32).reshape(-1, 4)
+        if oods_cp.shape[0] != N_CP_PARTITIONS:
+            raise MalformedProof("expected 16 composition-polynomial partitions")
+        N = oods_trace.shape[0]
+        dec = data["decommitments"]
+        trace_paths = [_path(c) for c in _split(dec[1]["hash_witness"], Q)]
+        cp_paths = [_path(c) for c in _split(dec[2]["hash_witness"], Q)]
+        qv = data["queried_values"]
+        trace_vals = np.array([[_u32(x) for x in c] for c in _split(qv[1], Q)], dtype=np.uint32)
+        cp_vals = np.array([[_u32(x) for x in c] for c in _split(qv[2], Q)], dtype=np.uint32)
+        if trace_vals.shape != (Q, N) or cp_vals.shape != (Q, N_CP_PARTITIONS):
+            raise MalformedProof("queried value count mismatch")
+        fri = data["fri_proof"]
+        layers = [fri["first_layer"]] + list(fri.get("inner_layers", []))
+        K = len(layers) - 1
+        if K > MAX_LIST:
+            raise MalformedProof("too many FRI layers")
+        fri_roots = np.stack([np.frombuffer(bytes(l["commitment"]), dtype=np.uint8) for l in layers])
+        fri_witness = np.zeros((K + 1, Q, 4), dtype=np.uint32)
+        fri_paths: List[List[np.ndarray]] = []
+        for i, l in enumerate(layers):
+            w = l["fri_witness"]
+            if len(w) != Q:
+                raise MalformedProof("one FRI witness per query expected")
+            fri_witness[i] = np.array([_qm31(x) for x in w], dtype=np.uint32)
+            fri_paths.append([_path(c) for c in _split(l["decommitment"]["hash_witness"], Q)])
+        coeffs = fri["last_layer_poly"]["coeffs"]
+        if len(coeffs) != 1:
+            raise MalformedProof("expected a degree-0 last layer")
+        last = np.array(_qm31(coeffs[0]), dtype=np.uint32)
+        lde_log = len(trace_paths[0]) if Q else 0
+        log_blowup = int(fri_conf.get("log_blowup_factor", 0))
+        tl = trace_log if trace_log is not None else lde_log - log_blowup
+        cfg = StwoConfig(N, tl, lde_log, Q, K, int(conf.get("pow_bits", 0)))
+        nonce = int(data.get("proof_of_work", 0))
+        if not (0 <= nonce < 1 << 64):
+            raise MalformedProof("u64 out of range")
+        return StwoProof(cfg, roots.copy(), oods_trace, oods_cp, trace_vals, cp_vals, trace_paths,
+                         cp_paths, fri_roots.copy(), last, fri_witness, fri_paths, nonce)
+    except (KeyError, IndexError, TypeError) as e:
+        raise MalformedProof(str(e)) from e
+
+
+def stwo_to_json(p: StwoProof) -> dict:
+    """Writer for format C (what an stwo-style prover would emit)."""
+    def q(v: Sequence[int]) -> List[List[int]]:
+        return [[int(v[0]), int(v[1])], [int(v[2]), int(v[3])]]
+
+    def hw(paths: List[np.ndarray]) -> List[List[int]]:
+        return [[int(b) for b in node] for pth in paths for node in pth]
+
+    def layer(i: int) -> dict:
+        return {"fri_witness": [q(w) for w in p.fri_witness[i]],
+                "decommitment": {"hash_witness": hw(p.fri_paths[i]), "column_witness": []},
+                "commitment": [int(b) for b in p.fri_roots[i]]}
+    c = p.cfg
+    return {
+        "config": {"pow_bits": c.pow_bits,
+                   "fri_config": {"log_blowup_factor": c.log_blowup,
+                                  "log_last_layer_degree_bound": 0, "n_queries": c.n_queries}},
+        "commitments": [[int(b) for b in r] for r in p.roots],
+        "sampled_values": [[], [[q(v)] for v in p.oods_trace], [[q(v)] for v in p.oods_cp]],
+        "decommitments": [{"hash_witness": [], "column_witness": []},
+                          {"hash_witness": hw(p.trace_paths), "column_witness": []},
+                          {"hash_witness": hw(p.cp_paths), "column_witness": []}],
+        "queried_values": [[], [int(x) for x in p.trace_vals.reshape(-1)],
+                           [int(x) for x in p.cp_vals.reshape(-1)]],
+        "proof_of_work": int(p.pow_nonce),
+        "fri_proof": {"first_layer": layer(0),
+                      "inner_layers": [layer(i) for i in range(1, c.n_layers + 1)],
+                      "last_layer_poly": {"coeffs": [q(p.last_layer)], "log_size": 0}},
+    }
+
+
+def stwo_from_wit(text: Any, trace_log: int, pow_bits: int = 5) -> StwoProof:
+    """Format D (stwo-verifier/scripts/generate_wit.py:218-243).  A ``.wit`` carries no
+    config, so TRACE_LOG_SIZE and the PoW target come from the caller, as they come from
+    config.simf for the reference."""
+    obj = json.loads(text) if isinstance(text, (str, bytes)) else text
+    try:
+        com = parse_literal(obj["COMMITMENTS"]["value"])
+        dec = parse_literal(obj["DECOMMITMENTS"]["value"])
+        oods = parse_literal(obj["OODS_EVALS"]["value"])
+        fric = parse_literal(obj["FRI_COMMITMENTS"]["value"])
+        frid = parse_literal(obj["FRI_DECOMMITMENTS"]["value"])
+        nonce = parse_literal(obj["POW_NONCE"]["value"])
+    except KeyError as e:
+        raise MalformedProof("missing witness %s" % e) from e
+    try:
+        roots = np.stack([np.frombuffer(u256_to_bytes(c), dtype=np.uint8) for c in com])
+        Q = len(dec)
+        oods_trace = np.array([_qm31(c[0]) for c in oods[0]], dtype=np.uint32).reshape(-1, 4)
+        oods_cp = np.array([_qm31(c) for c in oods[1]], dtype=np.uint32).reshape(-1, 4)
+        N = oods_trace.shape[0]
+        trace_vals = np.array([[_u32(c[0]) for c in d[0][0]] for d in dec], dtype=np.uint32)
+        cp_vals = np.array([[_u32(x) for x in d[1][0]] for d in dec], dtype=np.uint32)
+        trace_paths = [_path(d[0][1]) for d in dec]
+        cp_paths = [_path(d[1][1]) for d in dec]
+        layers_d = [frid[0]] + list(frid[1])
+        K = len(layers_d) - 1
+        fri_roots = np.stack([np.frombuffer(u256_to_bytes(c), dtype=np.uint8)
+                              for c in [fric[0]] + list(fric[1])])
+        last = np.array(_qm31(fric[2]), dtype=np.uint32)
+        fri_witness = np.array([[_qm31(x[0]) for x in l] for l in layers_d], dtype=np.uint32)
+        fri_paths = [[_path(x[1]) for x in l] for l in layers_d]
+        if (roots.shape != (3, 32) or trace_vals.shape != (Q, N)
+                or cp_vals.shape != (Q, N_CP_PARTITIONS) or fri_roots.shape != (K + 1, 32)
+                or fri_witness.shape != (K + 1, Q, 4) or oods_cp.shape[0] != N_CP_PARTITIONS):
+            raise MalformedProof("witness shape mismatch")
+        lde_log = len(trace_paths[0]) if Q else 0
+        cfg = StwoConfig(N, trace_log, lde_log, Q, K, pow_bits)
+        return StwoProof(cfg, roots.copy(), oods_trace, oods_cp, trace_vals, cp_vals, trace_paths,
+                         cp_paths, fri_roots.copy(), last, fri_witness, fri_paths, int(nonce))
+    except (IndexError, TypeError, ValueError) as e:
+        if isinstance(e, MalformedProof):
+            raise
+        raise MalformedProof(str(e)) from e
+
+
+def stwo_to_wit(p: StwoProof) -> str:
+    """Writer for format D, same layout as the reference's generate_wit.py."""
+    def hx(b: Any) -> str:
+        return "0x" + bytes(b).hex()
+
+    def q(v: Sequence[int]) -> str:
+        return "((%d, %d), (%d, %d))" % (int(v[0]), int(v[1]), int(v[2]), int(v[3]))
+
+    def lst(pth: np.ndarray) -> str:
+        return "list![" + ", ".join(hx(n) for n in pth) + "]"
+    c = p.cfg
+    Q, K, N = c.n_queries, c.n_layers, c.n_cols
+    M31, MP = "u32", "List<u256, 32>"
+    CM31 = "(%s, %s)" % (M31, M31)
+    QM31 = "(%s, %s)" % (CM31, CM31)
+    dec_t = "(([[%s; 1]; %d], %s), ([%s; 16], %s))" % (M31, N, MP, M31, MP)
+    fqd = "(%s, %s)" % (QM31, MP)
+    fld = "[%s; %d]" % (fqd, Q)
+    dec_items = []
+    for i in range(Q):
+        tv = "[" + ", ".join("[%d]" % int(x) for x in p.trace_vals[i]) + "]"
+        cv = "[" + ", ".join(str(int(x)) for x in p.cp_vals[i]) + "]"
+        dec_items.append("((%s, %s), (%s, %s))" % (tv, lst(p.trace_paths[i]), cv, lst(p.cp_paths[i])))
+
+    def fl(i: int) -> str:
+        return "[" + ", ".join("(%s, %s)" % (q(p.fri_witness[i, j]), lst(p.fri_paths[i][j]))
+                               for j in range(Q)) + "]"
+    wit = {
+        "COMMITMENTS": {"value": "(%s, %s, %s)" % tuple(hx(r) for r in p.roots),
+                        "type": "(u256, u256, u256)"},
+        "DECOMMITMENTS": {"value": "[" + ", ".join(dec_items) + "]",
+                          "type": "[%s; %d]" % (dec_t, Q)},
+        "OODS_EVALS": {"value": "(%s, %s)" % (
+            "[" + ", ".join("[" + q(v) + "]" for v in p.oods_trace) + "]",
+            "[" + ", ".join(q(v) for v in p.oods_cp) + "]"),
+            "type": "([[%s; 1]; %d], [%s; 16])" % (QM31, N, QM31)},
+        "FRI_COMMITMENTS": {"value": "(%s, [%s], %s)" % (
+            hx(p.fri_roots[0]), ", ".join(hx(r) for r in p.fri_roots[1:]), q(p.last_layer)),
+            "type": "(u256, [u256; %d], %s)" % (K, QM31)},
+        "FRI_DECOMMITMENTS": {"value": "(%s, [%s])" % (
+            fl(0), ", ".join(fl(i) for i in range(1, K + 1))),
+            "type": "(%s, [%s; %d])" % (fld, fld, K)},
+        "POW_NONCE": {"value": str(int(p.pow_nonce)), "type": "u64"},
+    }
+    return json.dumps(wit, indent=4)
+
+
+# ------------------------------------------------------------- seeded corruption (tests / bench)
+def stark101_fields(p: Stark101Proof) -> List[Tuple[str, Any]]:
+    """Every mutable location of a stark101 proof, for bit-flip negative tests."""
+    locs: List[Tuple[str, Any]] = [("root", None), ("last", None)]
+    for k in range(3):
+        locs.append(("eval_ev", k))
+        locs += [("eval_path", (k, i)) for i in range(len(p.evals[k].path))]
+    for li, l in enumerate(p.layers):
+        locs += [("layer_root", li), ("layer_beta", li), ("cpa_ev", li), ("cpb_ev", li)]
+        locs += [("cpa_path", (li, i)) for i in range(len(l.cpa.path))]
+        locs += [("cpb_path", (li, i)) for i in range(len(l.cpb.path))]
+    return locs
+
+
+def _flip_bytes(b: bytes, bit: int) -> bytes:
+    a = bytearray(b)
+    a[(bit // 8) % len(a)] ^= 1 << (bit % 8)
+    return bytes(a)
+
+
+def stark101_corrupt(p: Stark101Proof, rng: np.random.Generator) -> Tuple[Stark101Proof, str]:
+    """Flip one seeded bit somewhere in the proof.  Returns (new proof, description)."""
+    q = p.copy()
+    locs = stark101_fields(q)
+    kind, arg = locs[int(rng.integers(len(locs)))]
+    bit = int(rng.integers(256))
+    if kind == "root":
+        q.root = _flip_bytes(q.root, bit)
+    elif kind == "last":
+        q.last ^= 1 << (bit % 32)
+    elif kind == "eval_ev":
+        q.evals[arg].ev ^= 1 << (bit % 32)
+    elif kind == "eval_path":
+        k, i = arg
+        q.evals[k].path[i, (bit // 8) % 32] ^= 1 << (bit % 8)
+    elif kind == "layer_root":
+        q.layers[arg].root = _flip_bytes(q.layers[arg].root, bit)
+    elif kind == "layer_beta":
+        q.layers[arg].beta ^= 1 << (bit % 32)
+    elif kind == "cpa_ev":
+        q.layers[arg].cpa.ev ^= 1 << (bit % 32)
+    elif kind == "cpb_ev":
+        q.layers[arg].cpb.ev ^= 1 << (bit % 32)
+    elif kind == "cpa_path":
+        li, i = arg
+        q.layers[li].cpa.path[i, (bit // 8) % 32] ^= 1 << (bit % 8)
+    elif kind == "cpb_path":
+        li, i = arg
+        q.layers[li].cpb.path[i, (bit // 8) % 32] ^= 1 << (bit % 8)
+    return q, "%s%s bit %d" % (kind, "" if arg is None else str(arg), bit)
+
+
+def stwo_corrupt(p: StwoProof, rng: np.random.Generator) -> Tuple[StwoProof, str]:
+    """Flip one seeded bit in one seeded section of an stwo proof."""
+    q = p.copy()
+    Q, K = p.cfg.n_queries, p.cfg.n_layers
+    sections = ["roots", "oods_trace", "oods_cp", "trace_vals", "cp_vals", "trace_path", "cp_path",
+                "fri_roots", "last_layer", "fri_witness", "fri_path", "pow_nonce"]
+    s = sections[int(rng.integers(len(sections)))]
+    bit = int(rng.integers(1 << 30))
+
+    def flip_u8(a: np.ndarray) -> None:
+        flat = a.reshape(-1)
+        flat[(bit // 8) % flat.size] ^= np.uint8(1 << (bit % 8))
+
+    def flip_u32(a: np.ndarray) -> None:
+        flat = a.reshape(-1)
+        flat[(bit // 32) % flat.size] ^= np.uint32(1 << (bit % 32))
+    if s == "roots":
+        flip_u8(q.roots)
+    elif s == "oods_trace":
+        flip_u32(q.oods_trace)
+    elif s == "oods_cp":
+        flip_u32(q.oods_cp)
+    elif s == "trace_vals":
+        flip_u32(q.trace_vals)
+    elif s == "cp_vals":
+        flip_u32(q.cp_vals)
+    elif s == "trace_path":
+        flip_u8(q.trace_paths[int(rng.integers(Q))])
+    elif s == "cp_path":
+        flip_u8(q.cp_paths[int(rng.integers(Q))])
+    elif s == "fri_roots":
+        flip_u8(q.fri_roots)
+    elif s == "last_layer":
+        flip_u32(q.last_layer)
+    elif s == "fri_witness":
+        flip_u32(q.fri_witness)
+    elif s == "fri_path":
+        cand = [(l, j) for l in range(K + 1) for j in range(Q) if q.fri_paths[l][j].size]
+        l, j = cand[int(rng.integers(len(cand)))]
+        flip_u8(q.fri_paths[l][j])
+    elif s == "pow_nonce":
+        q.pow_nonce ^= 1 << (bit % 64)
+    return q, "%s bit %d" % (s, bit)
