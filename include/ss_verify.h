@@ -1,0 +1,169 @@
+/*
+ * ss_verify.h -- C ABI of libss_verify.so, the MI355X (gfx950) batch STARK verifier.
+ *
+ * What this replaces.  The reference has no plugin/FFI seam for its verifier: the
+ * boundary is "one process per proof", `simfony run main.simf --witness proof.wit`
+ *   - stark101/Makefile:8-9, stwo-verifier/Makefile:17-18        (the call)
+ *   - simfony-cli/src/main.rs:163-209 `handle_run`               (compile + satisfy + run)
+ *   - simfony-cli/src/main.rs:205 `run_program(..)`              (the verifier executes here)
+ *   - simfony-cli/src/main.rs:254-257                            (exit 0 = ACCEPT, 1 = REJECT)
+ * whose body is `verify_proof` (stark101/src/verifier.simf:24-42,
+ * stwo-verifier/src/verifier.simf:32-58).  The entry points below are what a cgo / JNI /
+ * ctypes / Rust-FFI binding for "verify these N witnesses" would bind instead
+ * (INTEGRATION.md shows the binding).  Plain pointers and sizes only.
+ *
+ * No CPU fallback exists in this library: every verify entry point runs HIP kernels and
+ * returns SS_ERR_NO_DEVICE / SS_ERR_HIP if it cannot.
+ *
+ * ---------------------------------------------------------------------------------------
+ * Data conventions
+ *   word      little-endian uint32_t.
+ *   hash      8 words; word j is the big-endian integer of digest bytes 4j..4j+3, i.e.
+ *             the SHA-256 state word (the u256 the reference prints, most significant
+ *             word first).
+ *   QM31      4 words (a, b, c, d) of a + bi + (c + di)j  (fields/qm31.simf:15).
+ *   record    one proof in natural order (layouts below); what a caller produces.
+ *   batch     N records re-tiled for the GPU by ss_*_pack (SoA over proofs / queries,
+ *             Merkle paths in 64-chain tiles [level][half][lane][4 words] so that a
+ *             wavefront reads one sibling level as two contiguous 1 KiB bursts).  A batch
+ *             is a pure permutation (+ zero padding) of its records: no hashing, no
+ *             arithmetic.  Its size is ss_*_batch_words().
+ *   status    one uint32_t per proof: 0 = ACCEPT, otherwise the code of the FIRST assert
+ *             that fails in the reference's evaluation order (codes below).  The
+ *             reference only exposes accept/reject; the code is extra information.
+ */
+#ifndef SS_VERIFY_H
+#define SS_VERIFY_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SS_VERSION 0x00010000
+
+/* return codes (all < 0 are errors; verdicts live in the status array) */
+#define SS_OK 0
+#define SS_ERR_ARG (-1)       /* null pointer, bad size, unsupported config */
+#define SS_ERR_HIP (-2)       /* a HIP call failed; see ss_last_error() */
+#define SS_ERR_NO_DEVICE (-3) /* no usable gfx950 device */
+#define SS_ERR_WORKSPACE (-4) /* workspace too small */
+
+int ss_version(void);
+const char *ss_last_error(void); /* thread-local text of the last error */
+int ss_device_count(void);       /* number of visible HIP devices, <0 on error */
+
+/* ======================================================================== stark101
+ * Record (ss_s101_record_words(max_layers, max_path) words, zero padded):
+ *   root[8]  n_layers  last
+ *   3 x { ev, len, path[max_path][8] }                        (air.simf:24-27)
+ *   max_layers x { root[8], beta,
+ *                  cpa_ev, cpa_len, cpa_path[max_path][8],
+ *                  cpb_ev, cpb_len, cpb_path[max_path][8] }   (fri.simf:30)
+ * paths are leaf -> root, as the prover emits them (prover.py:144-146,162-164).
+ * Status codes: (stage << 8) | sub
+ *   1 beta mismatch (fri.simf:43) sub=layer | 2 trace Merkle (air.simf:41) sub=k |
+ *   3 composition division abort (field.simf:46) sub=0..2 |
+ *   4 FRI layer, sub = 4*layer + {0 chain fri.simf:77, 1 cpa Merkle :79, 2 cpb Merkle :80,
+ *     3 fold division :58-60} | 5 last value (fri.simf:90)                                  */
+typedef struct ss_s101_shape {
+    uint32_t max_layers; /* <= 31 */
+    uint32_t max_path;   /* <= 31 */
+} ss_s101_shape;
+
+size_t ss_s101_record_words(const ss_s101_shape *shape);
+size_t ss_s101_batch_words(const ss_s101_shape *shape, size_t n);
+size_t ss_s101_workspace_bytes(const ss_s101_shape *shape, size_t n);
+/* records[i] -> proof i (pointers may repeat).  batch_host receives ss_s101_batch_words words. */
+int ss_s101_pack(const ss_s101_shape *shape, size_t n, const uint32_t *const *records,
+                 uint32_t *batch_host);
+
+/* ============================================================================ stwo
+ * Runtime form of the compile-time macros of stwo-verifier/src/config.simf:10-51.       */
+typedef struct ss_stwo_cfg {
+    uint32_t n_cols;     /* NUM_COLUMNS      (1..1024)                     */
+    uint32_t trace_log;  /* TRACE_LOG_SIZE                                 */
+    uint32_t lde_log;    /* LDE_LOG_SIZE     (<= 31)                       */
+    uint32_t n_queries;  /* NUM_FRI_QUERIES  (1..64)                       */
+    uint32_t n_layers;   /* NUM_FRI_LAYERS, inner layers (<= 30, < lde_log) */
+    uint32_t mode;       /* SS_MODE_*                                      */
+    uint64_t pow_target; /* POW_TARGET_64: digest value must be < target   */
+} ss_stwo_cfg;
+
+/* SS_MODE_LITERAL follows the .simf text (single DEEP batch fri/answers.simf:97-130,
+ * `log_size_ex == 0` fri/verify.simf:127, `folded_query == 0` fri/layers.simf:75).
+ * SS_MODE_FIXTURE is what the reference's own proofs (tests/data/proof*.json) satisfy:
+ * trace columns sampled at P and the 16 composition columns at 2P as two DEEP batches
+ * (docs/batching_samples.md:62-70), and neither of those two asserts.   */
+#define SS_MODE_LITERAL 0u
+#define SS_MODE_FIXTURE 1u
+
+/* Record (ss_stwo_record_words words):
+ *   roots[3][8]  oods_trace[n_cols][4]  oods_cp[16][4]  fri_roots[1+n_layers][8]
+ *   last_layer[4]  pow_nonce_hi  pow_nonce_lo
+ *   n_queries x { trace_vals[n_cols], cp_vals[16], trace_path[lde_log][8], cp_path[lde_log][8] }
+ *   (1+n_layers) x n_queries x { witness[4], path[lde_log-1-layer][8] }
+ * A Merkle path whose length differs from the shape above cannot verify in the reference
+ * (`path == 1`, merkle.simf:42): the caller reports it in shape_status (code of that
+ * assert, or 0) and stores zeros; the verdict is min(first device failure, shape_status).
+ * Status codes: (stage << 24) | (layer << 16) | (query << 4) | sub
+ *   1 channel draw exhausted | 2 OODS (sub 1 point inverse, 2 vanishing inverse, 3 CP mismatch
+ *   deep/oods.simf:58) | 4 proof of work (pow.simf:33) | 5 decommit (sub 0 trace path, 1 trace
+ *   root, 2 cp path, 3 cp root) | 6 DEEP denominator abort (sub = batch) | 7 FRI layer (sub 0
+ *   path, 1 root, 2 fold inverse) | 8 log_size_ex != 0 [LITERAL] | 9 last layer (sub 0
+ *   folded_query != 0 [LITERAL], 1 value mismatch fri/layers.simf:76)                       */
+size_t ss_stwo_record_words(const ss_stwo_cfg *cfg);
+size_t ss_stwo_batch_words(const ss_stwo_cfg *cfg, size_t n);
+size_t ss_stwo_workspace_bytes(const ss_stwo_cfg *cfg, size_t n);
+int ss_stwo_pack(const ss_stwo_cfg *cfg, size_t n, const uint32_t *const *records,
+                 uint32_t *batch_host);
+
+/* ======================================================================= execution
+ * One context per process and GPU (one process per GPU is the intended deployment).   */
+typedef struct ss_ctx ss_ctx;
+int ss_ctx_create(int device, ss_ctx **out);
+void ss_ctx_destroy(ss_ctx *ctx);
+
+/* Device-resident entry points: every pointer is device memory on ctx's GPU, `stream` is a
+ * hipStream_t (NULL = default stream).  Asynchronous; status_dev is valid once the stream
+ * has drained.  shape_status_dev may be NULL.  accept_count_dev (may be NULL) receives the
+ * number of accepted proofs (one uint32_t) -- the value a multi-GPU caller all-reduces.
+ * No allocation and no synchronisation happen inside, so the call is hipGraph-capturable.  */
+int ss_s101_verify_batch_dev(ss_ctx *ctx, const ss_s101_shape *shape, size_t n,
+                             const uint32_t *batch_dev, void *workspace_dev,
+                             size_t workspace_bytes, uint32_t *status_dev,
+                             uint32_t *accept_count_dev, void *stream);
+int ss_stwo_verify_batch_dev(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n,
+                             const uint32_t *batch_dev, const uint32_t *shape_status_dev,
+                             void *workspace_dev, size_t workspace_bytes, uint32_t *status_dev,
+                             uint32_t *accept_count_dev, void *stream);
+
+/* Host-buffer convenience: pack + H2D + verify + D2H, synchronous.  Allocates scratch
+ * device memory for the call.  PCIe-inclusive; not what bench.py times.                 */
+int ss_s101_verify_records(ss_ctx *ctx, const ss_s101_shape *shape, size_t n,
+                           const uint32_t *const *records, uint32_t *status_host);
+int ss_stwo_verify_records(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n,
+                           const uint32_t *const *records, const uint32_t *shape_status_host,
+                           uint32_t *status_host);
+
+/* Timing of the last *_verify_batch_dev call on this context, measured with HIP events
+ * recorded on the caller's stream around each kernel (enable with ss_ctx_set_timing(ctx, 1);
+ * off by default because event recording is not graph-capturable).  Names are static
+ * strings; returns the number of kernels written (<= cap).                              */
+int ss_ctx_set_timing(ss_ctx *ctx, int enabled);
+int ss_ctx_last_timing(ss_ctx *ctx, int cap, const char **names, float *ms);
+
+/* Device self-test of the primitives (tests only): runs `op` over `n` inputs.
+ *   op 0  sha256 of 64-byte messages: in 16 words/item, out 8 words/item
+ *   op 1  m31: in (a, b) -> out (add, sub, mul, inv(a) or 0xffffffff when a == 0)
+ *   op 2  qm31: in (a[4], b[4]) -> out (mul[4], inv(a)[4] or all-ones on abort)
+ *   op 3  circle point of index: in idx -> out (x, y)
+ *   op 4  stark101 field: in (a, b) -> out (add, sub, mul, div(a,b) or 0xffffffff on abort) */
+int ss_selftest(ss_ctx *ctx, int op, size_t n, const uint32_t *in_host, uint32_t *out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SS_VERIFY_H */

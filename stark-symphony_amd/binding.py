@@ -1,0 +1,95 @@
+"""ctypes binding of libss_verify.so (include/ss_verify.h).
+
+The library is the product: there is no Python or CPU implementation of the verifier in
+this package.  If the shared object is missing the import fails loudly; if no MI355X is
+visible, creating a context fails loudly (`SsError`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libss_verify.so")
+
+SS_OK, SS_ERR_ARG, SS_ERR_HIP, SS_ERR_NO_DEVICE, SS_ERR_WORKSPACE = 0, -1, -2, -3, -4
+MODE_LITERAL, MODE_FIXTURE = 0, 1
+
+
+class SsError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("libss_verify error %d: %s" % (code, msg))
+        self.code = code
+
+
+class StwoCfg(C.Structure):
+    """ss_stwo_cfg"""
+    _fields_ = [("n_cols", C.c_uint32), ("trace_log", C.c_uint32), ("lde_log", C.c_uint32),
+                ("n_queries", C.c_uint32), ("n_layers", C.c_uint32), ("mode", C.c_uint32),
+                ("pow_target", C.c_uint64)]
+
+
+class S101Shape(C.Structure):
+    """ss_s101_shape"""
+    _fields_ = [("max_layers", C.c_uint32), ("max_path", C.c_uint32)]
+
+
+EXPORTS = [
+    "ss_version", "ss_last_error", "ss_device_count",
+    "ss_s101_record_words", "ss_s101_batch_words", "ss_s101_workspace_bytes", "ss_s101_pack",
+    "ss_stwo_record_words", "ss_stwo_batch_words", "ss_stwo_workspace_bytes", "ss_stwo_pack",
+    "ss_ctx_create", "ss_ctx_destroy", "ss_s101_verify_batch_dev", "ss_stwo_verify_batch_dev",
+    "ss_s101_verify_records", "ss_stwo_verify_records", "ss_ctx_set_timing", "ss_ctx_last_timing",
+    "ss_selftest",
+]
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the HIP library.  Raises ImportError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, sz, u32p = C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)
+    pp = C.POINTER(C.c_void_p)
+
+    def sig(name, res, *args):
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = list(args)
+    sig("ss_version", C.c_int)
+    sig("ss_last_error", C.c_char_p)
+    sig("ss_device_count", C.c_int)
+    sp = C.POINTER(S101Shape)
+    sig("ss_s101_record_words", sz, sp)
+    sig("ss_s101_batch_words", sz, sp, sz)
+    sig("ss_s101_workspace_bytes", sz, sp, sz)
+    sig("ss_s101_pack", C.c_int, sp, sz, pp, vp)
+    cp = C.POINTER(StwoCfg)
+    sig("ss_stwo_record_words", sz, cp)
+    sig("ss_stwo_batch_words", sz, cp, sz)
+    sig("ss_stwo_workspace_bytes", sz, cp, sz)
+    sig("ss_stwo_pack", C.c_int, cp, sz, pp, vp)
+    sig("ss_ctx_create", C.c_int, C.c_int, pp)
+    sig("ss_ctx_destroy", None, vp)
+    sig("ss_s101_verify_batch_dev", C.c_int, vp, sp, sz, vp, vp, sz, vp, vp, vp)
+    sig("ss_stwo_verify_batch_dev", C.c_int, vp, cp, sz, vp, vp, vp, sz, vp, vp, vp)
+    sig("ss_s101_verify_records", C.c_int, vp, sp, sz, pp, vp)
+    sig("ss_stwo_verify_records", C.c_int, vp, cp, sz, pp, vp, vp)
+    sig("ss_ctx_set_timing", C.c_int, vp, C.c_int)
+    sig("ss_ctx_last_timing", C.c_int, vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float))
+    sig("ss_selftest", C.c_int, vp, C.c_int, sz, vp, vp)
+    _lib = L
+    return L
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        raise SsError(rc, lib().ss_last_error().decode("utf-8", "replace"))
+    return rc

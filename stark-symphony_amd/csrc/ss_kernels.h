@@ -1,0 +1,18 @@
+// Kernel entry points shared between the translation units of libss_verify.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ss_layout.h"
+
+namespace ss {
+
+__global__ void stwo_transcript_kernel(StwoLayout lay, const uint32_t *batch, uint32_t *ws, uint32_t *status);
+__global__ void stwo_query_kernel(StwoLayout lay, const uint32_t *batch, uint32_t *ws, uint32_t *status);
+__global__ void stwo_merkle_kernel(StwoLayout lay, const uint32_t *batch, const uint32_t *ws, uint32_t *status);
+__global__ void stwo_finalize_kernel(uint32_t n, uint32_t *status, const uint32_t *shape_status,
+                                     uint32_t *accept_count);
+
+__global__ void s101_transcript_kernel(S101Layout lay, const uint32_t *batch, uint32_t *ws, uint32_t *status);
+__global__ void s101_merkle_kernel(S101Layout lay, const uint32_t *batch, const uint32_t *ws, uint32_t *status);
+
+}  // namespace ss

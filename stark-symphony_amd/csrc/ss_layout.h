@@ -1,0 +1,159 @@
+// Batch layouts shared by the host packers and the kernels (see include/ss_verify.h for the
+// record formats and DESIGN.md "data layout in HBM").
+//
+// Everything is an array of little-endian u32 words in ONE buffer.
+//   per-proof "head" words      head[w][proof]              (SoA, proofs padded to 64)
+//   per-instance values         vals[column][instance]      (instance = proof * Q + query)
+//   Merkle paths, per chain type: 64-chain tiles
+//          tile[g][level][half][lane][4 words],   g = instance / 64, lane = instance % 64
+//     so a wavefront fetches one sibling level of its 64 chains as two contiguous 1 KiB reads.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#ifndef SS_HD
+#ifdef __HIPCC__
+#define SS_HD __host__ __device__
+#else
+#define SS_HD
+#endif
+#endif
+
+namespace ss {
+
+constexpr uint32_t kMaxList = 31;
+constexpr uint32_t kMaxQueries = 64;
+constexpr uint32_t kCp = 16;  // NUM_CP_PARTITIONS, evals/composition_poly.simf:12
+
+SS_HD inline uint64_t round_up64(uint64_t v) { return (v + 63) & ~(uint64_t)63; }
+
+// word offset of word `w` (0..7) of the sibling at `level` of chain `inst` in a tiled section
+SS_HD inline uint64_t tile_word(uint64_t base, uint32_t tile_len, uint64_t inst, uint32_t level,
+                                uint32_t w)
+{
+    return base + (((inst >> 6) * tile_len + level) * 2 + (w >> 2)) * 256 + (inst & 63) * 4 + (w & 3);
+}
+
+// ------------------------------------------------------------------------------ stwo
+struct StwoLayout {
+    uint32_t N, TL, L, Q, K, mode;
+    uint64_t pow_target;
+    uint32_t n, np;    // proofs, padded to 64
+    uint32_t ni, nip;  // instances (n * Q), padded to 64
+    // head word indices
+    uint32_t h_roots, h_oods_trace, h_oods_cp, h_fri_roots, h_last, h_nonce, head_words;
+    // section word offsets inside the batch buffer
+    uint64_t off_head, off_trace_vals, off_cp_vals, off_fri_wit, off_trace_path, off_cp_path;
+    uint64_t off_fri_path[kMaxList + 1];
+    uint64_t total_words;
+    // workspace word offsets (u32 words)
+    uint32_t c_queries, c_p, c_p2, c_b, c_a1, c_c1, c_a2, c_c2, c_m1, c_fold, ctx_words;
+    uint64_t ws_ctx, ws_leaf, ws_total_words;
+};
+
+SS_HD inline bool stwo_cfg_ok(uint32_t N, uint32_t TL, uint32_t L, uint32_t Q, uint32_t K, uint32_t mode)
+{
+    return N >= 1 && N <= 1024 && L >= 2 && L <= 31 && TL >= 1 && TL <= L && Q >= 1 &&
+           Q <= kMaxQueries && K + 1 < L && K <= 30 && mode <= 1;
+}
+
+SS_HD inline StwoLayout stwo_layout(uint32_t N, uint32_t TL, uint32_t L, uint32_t Q, uint32_t K,
+                                    uint32_t mode, uint64_t pow_target, uint64_t n)
+{
+    StwoLayout y{};
+    y.N = N; y.TL = TL; y.L = L; y.Q = Q; y.K = K; y.mode = mode; y.pow_target = pow_target;
+    y.n = (uint32_t)n;
+    y.np = (uint32_t)round_up64(n);
+    y.ni = (uint32_t)(n * Q);
+    y.nip = (uint32_t)round_up64(n * Q);
+    y.h_roots = 0;
+    y.h_oods_trace = 24;
+    y.h_oods_cp = y.h_oods_trace + 4 * N;
+    y.h_fri_roots = y.h_oods_cp + 4 * kCp;
+    y.h_last = y.h_fri_roots + 8 * (K + 1);
+    y.h_nonce = y.h_last + 4;
+    y.head_words = y.h_nonce + 2;
+    uint64_t o = 0;
+    y.off_head = o;        o += (uint64_t)y.head_words * y.np;
+    y.off_trace_vals = o;  o += (uint64_t)N * y.nip;
+    y.off_cp_vals = o;     o += (uint64_t)kCp * y.nip;
+    y.off_fri_wit = o;     o += (uint64_t)(K + 1) * 4 * y.nip;
+    y.off_trace_path = o;  o += (uint64_t)L * 8 * y.nip;
+    y.off_cp_path = o;     o += (uint64_t)L * 8 * y.nip;
+    for (uint32_t l = 0; l <= K; l++) {
+        y.off_fri_path[l] = o;
+        o += (uint64_t)(L - 1 - l) * 8 * y.nip;
+    }
+    y.total_words = o;
+    // per-proof context written by the transcript kernel
+    uint32_t c = 0;
+    y.c_queries = c; c += Q;
+    y.c_p = c;       c += 8;            // OODS point P  (x.a..x.d, y.a..y.d)
+    y.c_p2 = c;      c += 8;            // 2P
+    y.c_b = c;       c += 4 * (N + kCp);
+    y.c_a1 = c;      c += 4;
+    y.c_c1 = c;      c += 4;
+    y.c_a2 = c;      c += 4;
+    y.c_c2 = c;      c += 4;
+    y.c_m1 = c;      c += 4;
+    y.c_fold = c;    c += 4 * (K + 1);
+    y.ctx_words = c;
+    uint64_t w = 0;
+    y.ws_ctx = w;   w += (uint64_t)y.ctx_words * y.np;
+    y.ws_leaf = w;  w += (uint64_t)(K + 1) * 8 * y.nip;
+    y.ws_total_words = w;
+    return y;
+}
+
+SS_HD inline uint64_t stwo_record_words(uint32_t N, uint32_t L, uint32_t Q, uint32_t K)
+{
+    uint64_t w = 24 + 4 * (uint64_t)N + 64 + 8 * (uint64_t)(K + 1) + 4 + 2;
+    w += (uint64_t)Q * (N + kCp + 16 * (uint64_t)L);
+    for (uint32_t l = 0; l <= K; l++) w += (uint64_t)Q * (4 + 8 * (uint64_t)(L - 1 - l));
+    return w;
+}
+
+// -------------------------------------------------------------------------- stark101
+// chain types: 0..2 trace evals; 3 + 2*i cpa of layer i; 4 + 2*i cpb of layer i.
+// Every type owns PM levels per tile (a chain reads only its own `len` levels, so the
+// zero padding of shorter chains costs capacity, never bandwidth).
+struct S101Layout {
+    uint32_t ML, PM;  // max layers, max path length of the records
+    uint32_t n, np;
+    uint32_t n_types;
+    uint32_t h_root, h_nlayers, h_last, h_layer, head_words;  // layer: root[8], beta
+    uint64_t off_head, off_leaf, off_len, off_path;            // off_path + type * path_stride
+    uint64_t path_stride;
+    uint64_t total_words;
+    uint64_t ws_total_words;  // idx per proof
+};
+
+SS_HD inline bool s101_shape_ok(uint32_t ML, uint32_t PM) { return ML <= kMaxList && PM <= kMaxList; }
+
+SS_HD inline uint64_t s101_record_words(uint32_t ML, uint32_t PM)
+{
+    return 10 + 3 * (2 + 8 * (uint64_t)PM) + (uint64_t)ML * (9 + 2 * (2 + 8 * (uint64_t)PM));
+}
+
+SS_HD inline S101Layout s101_layout(uint32_t ML, uint32_t PM, uint64_t n)
+{
+    S101Layout y{};
+    y.ML = ML; y.PM = PM;
+    y.n = (uint32_t)n;
+    y.np = (uint32_t)round_up64(n);
+    y.n_types = 3 + 2 * ML;
+    y.h_root = 0; y.h_nlayers = 8; y.h_last = 9; y.h_layer = 10;
+    y.head_words = 10 + 9 * ML;
+    uint64_t o = 0;
+    y.off_head = o;  o += (uint64_t)y.head_words * y.np;
+    y.off_leaf = o;  o += (uint64_t)y.n_types * y.np;  // leaf value (ev) per chain
+    y.off_len = o;   o += (uint64_t)y.n_types * y.np;  // path length per chain
+    y.off_path = o;
+    y.path_stride = (uint64_t)PM * 8 * y.np;
+    o += y.path_stride * y.n_types;
+    y.total_words = o;
+    y.ws_total_words = y.np;
+    return y;
+}
+
+}  // namespace ss

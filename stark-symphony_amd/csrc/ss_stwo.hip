@@ -1,0 +1,543 @@
+// stwo circle-STARK batch verifier kernels for gfx950.
+//
+// Reference path: `verify_proof`, stwo-verifier/src/verifier.simf:32-58 and everything it
+// calls.  The seven stages of docs/verifier_flow.md:3-36 are regrouped by their parallelism:
+//
+//   stwo_transcript_kernel   one lane per PROOF.   Stages I-IV + query generation: the
+//        Fiat-Shamir chain is ~(3K+25) dependent SHA-256 compressions, so lanes (not
+//        wavefronts) are the unit; it also hoists everything of stage VI that does not
+//        depend on the query (DEEP line coefficients, fri/answers.simf:44-64).
+//   stwo_query_kernel        one lane per QUERY.   Stage VI (DEEP quotient at the query
+//        point) and the fold chain of stage VII (fri/folding.simf:15-41); emits the leaf
+//        pair of every FRI layer for the Merkle kernel.
+//   stwo_merkle_kernel       one lane per Merkle CHAIN, one wavefront per 64 chains of the
+//        same kind: the trace / composition decommitments of stage V (evals/verify.simf:47-69)
+//        and the per-layer FRI decommitments (fri/layers.simf:40-48).  >90 % of the work.
+//   stwo_finalize_kernel     one lane per proof: first-failure code -> status, accept count.
+//
+// A failed assert never stops a lane: each check contributes its code through atomicMin, and
+// because the codes are ordered like the reference's evaluation order the minimum IS the
+// first failing assert (every check is a pure function of the proof).
+#include <hip/hip_runtime.h>
+
+#include "ss_fields.h"
+#include "ss_layout.h"
+#include "ss_sha256.h"
+
+namespace ss {
+
+__device__ __forceinline__ uint32_t stwo_code(uint32_t stage, uint32_t layer, uint32_t query, uint32_t sub)
+{
+    return (stage << 24) | (layer << 16) | (query << 4) | sub;
+}
+
+struct Dig { uint32_t v[8]; };
+struct W16 { uint32_t v[16]; };
+
+// Out-of-line compression for the sequential transcript (keeps its code footprint small).
+__device__ __noinline__ Dig compress_call(Dig st, W16 w)
+{
+    sha256_compress(st.v, w.v);
+    return st;
+}
+__device__ __noinline__ Dig compress_pad64_call(Dig st)
+{
+    sha256_compress_pad64(st.v);
+    return st;
+}
+__device__ __forceinline__ Dig dig_iv()
+{
+    Dig d;
+    sha_iv(d.v);
+    return d;
+}
+
+// channel_mix_u256 (channel.simf:154-161): digest <- H(digest || in)
+__device__ inline void channel_mix(Dig &dig, uint32_t &ctr, const Dig &in)
+{
+    W16 w;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { w.v[i] = dig.v[i]; w.v[8 + i] = in.v[i]; }
+    dig = compress_pad64_call(compress_call(dig_iv(), w));
+    ctr = 0;
+}
+
+// H(digest || m[0..n)) for n <= 5 words: one block (draws, mix_u64, mix_line_poly)
+template <int NW>
+__device__ inline Dig hash_digest_words(const Dig &dig, const uint32_t (&m)[NW])
+{
+    static_assert(NW <= 5, "single block");
+    W16 w;
+#pragma unroll
+    for (int i = 0; i < 16; i++) w.v[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) w.v[i] = dig.v[i];
+#pragma unroll
+    for (int i = 0; i < NW; i++) w.v[8 + i] = m[i];
+    w.v[8 + NW] = 0x80000000u;
+    w.v[15] = 32u * (8 + NW);
+    return compress_call(dig_iv(), w);
+}
+
+// channel_draw_words (channel.simf:36-65)
+__device__ inline Dig channel_draw_words(const Dig &dig, uint32_t &ctr)
+{
+    uint32_t m[1] = {ctr};
+    Dig out = hash_digest_words<1>(dig, m);
+    ctr = ctr + 1;
+    return out;
+}
+
+// channel_draw_qm31 (channel.simf:115-140): retry while any of the first four words >= 2^32 - 2;
+// the for_while counter is a u8, so at most 256 attempts.
+__device__ inline bool channel_draw_qm31(const Dig &dig, uint32_t &ctr, QM31 &out)
+{
+    for (int it = 0; it < 256; it++) {
+        Dig w = channel_draw_words(dig, ctr);
+        if (w.v[0] < 4294967294u && w.v[1] < 4294967294u && w.v[2] < 4294967294u &&
+            w.v[3] < 4294967294u) {
+            out = {m31_red(w.v[0]), m31_red(w.v[1]), m31_red(w.v[2]), m31_red(w.v[3])};
+            return true;
+        }
+    }
+    out = qm31_zero();
+    return false;
+}
+
+// deep_quotient_interpolant_coefficients (deep/quotients.simf:25-36)
+__device__ inline void interpolant_coefficients(const QM31Point &sp, QM31 value, QM31 alpha_i,
+                                                QM31 &a, QM31 &b, QM31 &c)
+{
+    CM31 im_v = q_im(value), im_py = q_im(sp.y);
+    QM31 a0 = q_make(CM31{0, 0}, cm31_neg(cm31_add(im_v, im_v)));
+    QM31 b0 = q_make(CM31{0, 0}, cm31_neg(cm31_add(im_py, im_py)));
+    QM31 a_py = qm31_mul(a0, sp.y);
+    QM31 b_val = qm31_mul(b0, value);
+    QM31 c0 = qm31_sub(b_val, a_py);
+    a = qm31_mul(alpha_i, a0);
+    b = qm31_mul(alpha_i, b0);
+    c = qm31_mul(alpha_i, c0);
+}
+
+// ========================================================================== transcript
+__global__ void __launch_bounds__(64)
+stwo_transcript_kernel(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,
+                       uint32_t *__restrict__ status)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= lay.n) return;
+    const uint32_t *head = batch + lay.off_head;
+    const uint32_t np = lay.np;
+    auto H = [&](uint32_t w) { return head[(size_t)w * np + p]; };
+    auto HQ = [&](uint32_t w) { return QM31{H(w), H(w + 1), H(w + 2), H(w + 3)}; };
+    uint32_t *ctx = ws + lay.ws_ctx;
+    auto CW = [&](uint32_t w, uint32_t v) { ctx[(size_t)w * np + p] = v; };
+    auto CQ = [&](uint32_t w, QM31 q) { CW(w, q.a); CW(w + 1, q.b); CW(w + 2, q.c); CW(w + 3, q.d); };
+    uint32_t fail = 0xffffffffu;
+    auto FAIL = [&](uint32_t code) { fail = code < fail ? code : fail; };
+    uint32_t draw_ord = 0;
+
+    Dig dig;
+#pragma unroll
+    for (int i = 0; i < 8; i++) dig.v[i] = 0;
+    uint32_t ctr = 0;  // channel_init, channel.simf:31
+
+    // ---- stage I: evals_commit (evals/commit.simf:20-35)
+    QM31 cp_alpha, deep_alpha;
+    {
+        Dig r;
+        for (int i = 0; i < 8; i++) r.v[i] = H(lay.h_roots + i);
+        channel_mix(dig, ctr, r);
+        for (int i = 0; i < 8; i++) r.v[i] = H(lay.h_roots + 8 + i);
+        channel_mix(dig, ctr, r);
+        if (!channel_draw_qm31(dig, ctr, cp_alpha)) FAIL(stwo_code(1, 0, 0, draw_ord));
+        draw_ord++;
+        for (int i = 0; i < 8; i++) r.v[i] = H(lay.h_roots + 16 + i);
+        channel_mix(dig, ctr, r);
+    }
+
+    // ---- stage II: oods (deep/oods.simf:44-64)
+    QM31Point P;
+    {
+        // channel_draw_qm31_point (channel.simf:143-151)
+        QM31 t, inv;
+        if (!channel_draw_qm31(dig, ctr, t)) FAIL(stwo_code(1, 0, 0, draw_ord));
+        draw_ord++;
+        QM31 t_sq = qm31_mul(t, t);
+        if (!qm31_inv(qm31_add(qm31_one(), t_sq), inv)) FAIL(stwo_code(2, 0, 0, 1));
+        P.x = qm31_mul(qm31_sub(qm31_one(), t_sq), inv);
+        P.y = qm31_mul(qm31_add(t, t), inv);
+
+        // channel_mix_oods_evals (deep/oods.simf:23-39): H(digest || 4(N+16) words)
+        {
+            const uint32_t total = 8 + 4 * (lay.N + kCp);  // message words
+            const uint32_t nblk = (total + 2) / 16 + 1;      // + 0x80 word + 64-bit length
+            Dig st = dig_iv();
+            for (uint32_t b = 0; b < nblk; b++) {
+                W16 w;
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const uint32_t i = b * 16 + j;
+                    uint32_t v = 0;
+                    if (i < 8) v = 0;  // patched below (static indexing of the digest)
+                    else if (i < total) v = H(lay.h_oods_trace + (i - 8));
+                    else if (i == total) v = 0x80000000u;
+                    else if (i == nblk * 16 - 1) v = 32u * total;
+                    w.v[j] = v;
+                }
+                if (b == 0) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) w.v[j] = dig.v[j];
+                }
+                st = compress_call(st, w);
+            }
+            dig = st;
+            ctr = 0;
+        }
+
+        // eval_composition_poly (constraints/wide_fibonacci.simf:24-62)
+        QM31 acc = qm31_zero(), a = qm31_zero(), b = qm31_zero();
+        uint32_t skip = 0;
+        for (uint32_t k = 0; k < lay.N; k++) {
+            QM31 c = HQ(lay.h_oods_trace + 4 * k);
+            if (skip == 2) {
+                QM31 constraint = qm31_sub(c, qm31_add(qm31_mul(b, b), qm31_mul(a, a)));
+                acc = qm31_add(qm31_mul(acc, cp_alpha), constraint);
+            } else {
+                skip++;
+            }
+            a = b;
+            b = c;
+        }
+        // vanishing_poly_eval (evals/composition_poly.simf:27-35,66-71): u8 loop counter
+        QM31 van = P.x;
+        {
+            const uint32_t n_iter = (lay.TL - 1) & 0xff;
+            for (uint32_t counter = 0; counter < 256; counter++) {
+                if (counter == n_iter) break;
+                van = qm31_dbl_x(van);
+            }
+        }
+        QM31 van_inv;
+        if (!qm31_inv(van, van_inv)) FAIL(stwo_code(2, 0, 0, 2));
+        QM31 cp_eval = qm31_mul(acc, van_inv);
+        // composition_poly_eval_from_decomposed (evals/composition_poly.simf:38-59)
+        QM31 part[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {  // j = a, b, c, d ; index = 4 * coord + j
+            QM31 c0 = HQ(lay.h_oods_cp + 4 * (0 + j)), c1 = HQ(lay.h_oods_cp + 4 * (4 + j));
+            QM31 c2 = HQ(lay.h_oods_cp + 4 * (8 + j)), c3 = HQ(lay.h_oods_cp + 4 * (12 + j));
+            QM31 r = qm31_add(c0, qm31_mul(c1, QM31{0, 1, 0, 0}));
+            r = qm31_add(r, qm31_mul(c2, QM31{0, 0, 1, 0}));
+            r = qm31_add(r, qm31_mul(c3, QM31{0, 0, 0, 1}));
+            part[j] = r;
+        }
+        QM31 sampled = qm31_add(part[0], qm31_mul(part[1], P.y));
+        sampled = qm31_add(sampled, qm31_mul(part[2], P.x));
+        sampled = qm31_add(sampled, qm31_mul(part[3], qm31_mul(P.x, P.y)));
+        if (!qm31_eq(cp_eval, sampled)) FAIL(stwo_code(2, 0, 0, 3));
+
+        if (!channel_draw_qm31(dig, ctr, deep_alpha)) FAIL(stwo_code(1, 0, 0, draw_ord));
+        draw_ord++;
+    }
+
+    // ---- stage III: fri_commit (fri/commit.simf:70-85)
+    for (uint32_t l = 0; l <= lay.K; l++) {
+        Dig r;
+        for (int i = 0; i < 8; i++) r.v[i] = H(lay.h_fri_roots + 8 * l + i);
+        channel_mix(dig, ctr, r);
+        QM31 fa;
+        if (!channel_draw_qm31(dig, ctr, fa)) FAIL(stwo_code(1, 0, 0, draw_ord));
+        draw_ord++;
+        CQ(lay.c_fold + 4 * l, fa);
+    }
+    {
+        uint32_t m[4] = {H(lay.h_last), H(lay.h_last + 1), H(lay.h_last + 2), H(lay.h_last + 3)};
+        dig = hash_digest_words<4>(dig, m);  // channel_mix_line_poly, fri/commit.simf:48-57
+        ctr = 0;
+    }
+
+    // ---- stage IV: check_proof_of_work (pow.simf:22-36)
+    {
+        uint32_t m[2] = {H(lay.h_nonce), H(lay.h_nonce + 1)};
+        dig = hash_digest_words<2>(dig, m);  // channel_mix_u64
+        ctr = 0;
+        // last 8 digest bytes, read little-endian: (bswap(h) << 32) | bswap(g)
+        uint64_t value = ((uint64_t)__builtin_bswap32(dig.v[7]) << 32) | __builtin_bswap32(dig.v[6]);
+        if (!(value < lay.pow_target)) FAIL(stwo_code(4, 0, 0, 0));
+    }
+
+    // ---- stage V (first half): fri_generate_queries (fri/queries.simf:29-43)
+    {
+        const uint32_t mask = shl32(lay.L, 1) - 1;
+        for (uint32_t base = 0; base < lay.Q; base += 8) {
+            Dig w = channel_draw_words(dig, ctr);
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (base + j < lay.Q) CW(lay.c_queries + base + j, w.v[j] & mask);
+        }
+    }
+
+    // ---- stage VI, query-independent part (fri/answers.simf:44-64,97-130)
+    {
+        QM31Point P2 = qm31_point_add(P, P);
+        CQ(lay.c_p, P.x);  CQ(lay.c_p + 4, P.y);
+        CQ(lay.c_p2, P2.x); CQ(lay.c_p2 + 4, P2.y);
+        QM31 A = qm31_zero(), C = qm31_zero(), alpha_i = deep_alpha;
+        for (uint32_t k = 0; k < lay.N; k++) {
+            QM31 a, b, c;
+            interpolant_coefficients(P, HQ(lay.h_oods_trace + 4 * k), alpha_i, a, b, c);
+            CQ(lay.c_b + 4 * k, b);
+            A = qm31_add(A, a);
+            C = qm31_add(C, c);
+            alpha_i = qm31_mul(alpha_i, deep_alpha);
+        }
+        if (lay.mode == 1) {  // FIXTURE: second batch at 2P, alpha restarts
+            CQ(lay.c_a1, A); CQ(lay.c_c1, C);
+            A = qm31_zero(); C = qm31_zero(); alpha_i = deep_alpha;
+            QM31 alpha_pow = qm31_one();
+            for (uint32_t k = 0; k < kCp; k++) {
+                QM31 a, b, c;
+                interpolant_coefficients(P2, HQ(lay.h_oods_cp + 4 * k), alpha_i, a, b, c);
+                CQ(lay.c_b + 4 * (lay.N + k), b);
+                A = qm31_add(A, a);
+                C = qm31_add(C, c);
+                alpha_i = qm31_mul(alpha_i, deep_alpha);
+                alpha_pow = qm31_mul(alpha_pow, deep_alpha);
+            }
+            CQ(lay.c_a2, A); CQ(lay.c_c2, C);
+            CQ(lay.c_m1, alpha_pow);
+        } else {  // LITERAL: one batch over all N + 16 columns at P
+            for (uint32_t k = 0; k < kCp; k++) {
+                QM31 a, b, c;
+                interpolant_coefficients(P, HQ(lay.h_oods_cp + 4 * k), alpha_i, a, b, c);
+                CQ(lay.c_b + 4 * (lay.N + k), b);
+                A = qm31_add(A, a);
+                C = qm31_add(C, c);
+                alpha_i = qm31_mul(alpha_i, deep_alpha);
+            }
+            CQ(lay.c_a1, A); CQ(lay.c_c1, C);
+            CQ(lay.c_a2, qm31_zero()); CQ(lay.c_c2, qm31_zero());
+            CQ(lay.c_m1, alpha_i);  // alpha^(N+17), fri/answers.simf:126
+        }
+    }
+    if (fail != 0xffffffffu) atomicMin(&status[p], fail);
+}
+
+// =============================================================================== query
+__device__ inline bool denominator_inverse(const uint32_t *ctx, uint32_t np, uint32_t p, uint32_t cw,
+                                           M31Point q, CM31 &out)
+{
+    // deep_quotient_denominator_inverse (deep/quotients.simf:15-22)
+    auto G = [&](uint32_t w) { return ctx[(size_t)(cw + w) * np + p]; };
+    CM31 prx = {G(0), G(1)}, pix = {G(2), G(3)}, pry = {G(4), G(5)}, piy = {G(6), G(7)};
+    CM31 dx = cm31_sub_m31(prx, q.x), dy = cm31_sub_m31(pry, q.y);
+    CM31 d = cm31_sub(cm31_mul(dx, piy), cm31_mul(dy, pix));
+    return cm31_inv(d, out);
+}
+
+__global__ void __launch_bounds__(64)
+stwo_query_kernel(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,
+                  uint32_t *__restrict__ status)
+{
+    const uint32_t inst = blockIdx.x * blockDim.x + threadIdx.x;
+    if (inst >= lay.ni) return;
+    const uint32_t p = inst / lay.Q, q = inst - p * lay.Q;
+    const uint32_t np = lay.np, nip = lay.nip;
+    const uint32_t *ctx = ws + lay.ws_ctx;
+    auto CG = [&](uint32_t w) { return ctx[(size_t)w * np + p]; };
+    auto CGQ = [&](uint32_t w) { return QM31{CG(w), CG(w + 1), CG(w + 2), CG(w + 3)}; };
+    uint32_t fail = 0xffffffffu;
+    auto FAIL = [&](uint32_t code) { fail = code < fail ? code : fail; };
+
+    const uint32_t query = CG(lay.c_queries + q);
+    const uint32_t L = lay.L;
+
+    // ---- stage VI: fri_answer at the query point (fri/answers.simf:97-130)
+    QM31 eval;
+    {
+        M31Point dp = circle_point(circle_position_to_index(L, bit_reverse_position(query, L)));
+        CM31 di1, di2 = {0, 0};
+        if (!denominator_inverse(ctx, np, p, lay.c_p, dp, di1)) FAIL(stwo_code(6, 0, q, 0));
+        if (lay.mode == 1 && !denominator_inverse(ctx, np, p, lay.c_p2, dp, di2)) FAIL(stwo_code(6, 0, q, 1));
+        const uint32_t *tv = batch + lay.off_trace_vals, *cv = batch + lay.off_cp_vals;
+        QM31 s = qm31_zero();
+        for (uint32_t k = 0; k < lay.N; k++)
+            s = qm31_add(s, qm31_mul_m31(CGQ(lay.c_b + 4 * k), tv[(size_t)k * nip + inst]));
+        QM31 s2 = qm31_zero();
+        for (uint32_t k = 0; k < kCp; k++)
+            s2 = qm31_add(s2, qm31_mul_m31(CGQ(lay.c_b + 4 * (lay.N + k)), cv[(size_t)k * nip + inst]));
+        if (lay.mode == 1) {
+            QM31 n1 = qm31_sub(s, qm31_add(qm31_mul_m31(CGQ(lay.c_a1), dp.y), CGQ(lay.c_c1)));
+            QM31 n2 = qm31_sub(s2, qm31_add(qm31_mul_m31(CGQ(lay.c_a2), dp.y), CGQ(lay.c_c2)));
+            QM31 b1 = qm31_mul_cm31(n1, di1), b2 = qm31_mul_cm31(n2, di2);
+            eval = qm31_add(qm31_mul(b1, CGQ(lay.c_m1)), b2);
+        } else {
+            QM31 nn = qm31_sub(qm31_add(s, s2), qm31_add(qm31_mul_m31(CGQ(lay.c_a1), dp.y), CGQ(lay.c_c1)));
+            eval = qm31_mul(qm31_mul_cm31(nn, di1), CGQ(lay.c_m1));
+        }
+    }
+
+    // ---- stage VII: fold chain (fri/layers.simf:48-70, fri/folding.simf:15-41)
+    uint32_t *leaf = ws + lay.ws_leaf;
+    const uint32_t *wit = batch + lay.off_fri_wit;
+    uint32_t cur = query;
+    for (uint32_t l = 0; l <= lay.K; l++) {
+        const uint32_t logl = L - l;
+        QM31 w = {wit[((size_t)l * 4 + 0) * nip + inst], wit[((size_t)l * 4 + 1) * nip + inst],
+                  wit[((size_t)l * 4 + 2) * nip + inst], wit[((size_t)l * 4 + 3) * nip + inst]};
+        const bool odd = cur & 1;  // adjacent_leaves (fri/layers.simf:29-37)
+        const uint32_t position = cur & ~1u;
+        QM31 e0 = odd ? w : eval, e1 = odd ? eval : w;
+        uint32_t *lf = leaf + (size_t)l * 8 * nip + inst;
+        lf[0] = e0.a; lf[(size_t)nip] = e0.b; lf[(size_t)2 * nip] = e0.c; lf[(size_t)3 * nip] = e0.d;
+        lf[(size_t)4 * nip] = e1.a; lf[(size_t)5 * nip] = e1.b; lf[(size_t)6 * nip] = e1.c;
+        lf[(size_t)7 * nip] = e1.d;
+        uint32_t coord;
+        if (l == 0) {
+            coord = circle_point(circle_position_to_index(logl, bit_reverse_position(position, logl))).y;
+        } else {
+            coord = circle_point(line_position_to_index(logl, bit_reverse_position(position, logl))).x;
+        }
+        uint32_t cinv;
+        if (!m31_inv(coord, cinv)) FAIL(stwo_code(7, l, q, 2));
+        QM31 f0 = qm31_add(e0, e1);
+        QM31 f1 = qm31_mul_m31(qm31_sub(e0, e1), cinv);
+        eval = qm31_add(f0, qm31_mul(CGQ(lay.c_fold + 4 * l), f1));
+        cur = position >> 1;
+    }
+
+    // ---- last layer (fri/verify.simf:124-128, fri/layers.simf:73-78)
+    if (lay.mode == 0) {
+        if (((L - (lay.K + 1)) & 0xff) != 0) FAIL(stwo_code(8, 0, 0, 0));
+        if (cur != 0) FAIL(stwo_code(9, 0, q, 0));
+    }
+    {
+        const uint32_t *head = batch + lay.off_head;
+        QM31 last = {head[(size_t)(lay.h_last + 0) * np + p], head[(size_t)(lay.h_last + 1) * np + p],
+                     head[(size_t)(lay.h_last + 2) * np + p], head[(size_t)(lay.h_last + 3) * np + p]};
+        if (!qm31_eq(eval, last)) FAIL(stwo_code(9, 0, q, 1));
+    }
+    if (fail != 0xffffffffu) atomicMin(&status[p], fail);
+}
+
+// ============================================================================== merkle
+// One wavefront = 64 chains of one kind.  Tile order: trace, cp, FRI layer 0..K (longest
+// chains first, so the tail of the grid is made of the shortest ones).
+__global__ void __launch_bounds__(256)
+stwo_merkle_kernel(StwoLayout lay, const uint32_t *__restrict__ batch, const uint32_t *__restrict__ ws,
+                   uint32_t *__restrict__ status)
+{
+    const uint32_t tiles_per_type = lay.nip >> 6;
+    const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t type = tile / tiles_per_type;  // wave-uniform
+    if (type >= lay.K + 3) return;
+    const uint32_t g = tile - type * tiles_per_type;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t inst = g * 64 + lane;
+    const bool live = inst < lay.ni;
+    const uint32_t p = live ? inst / lay.Q : 0, q = live ? inst - p * lay.Q : 0;
+    const uint32_t np = lay.np, nip = lay.nip;
+    const uint32_t *ctx = ws + lay.ws_ctx;
+    const uint32_t *head = batch + lay.off_head;
+    const uint32_t query = ctx[(size_t)(lay.c_queries + q) * np + p];
+
+    uint32_t node[8];
+    uint32_t auth, len, root_w, code_base;
+    const uint32_t *path;
+    if (type < 2) {
+        // verify_trace_evals / verify_cp_evals (evals/verify.simf:47-69)
+        const uint32_t ncol = type == 0 ? lay.N : kCp;
+        const uint32_t *vals = batch + (type == 0 ? lay.off_trace_vals : lay.off_cp_vals) + inst;
+        // hash_node_m31_trace / hash_node_m31_cp (hasher.simf:85-97): SHA-256 of ncol BE words
+        const uint32_t nblk = (ncol + 2) / 16 + 1;
+        sha_iv(node);
+        for (uint32_t b = 0; b < nblk; b++) {
+            uint32_t w[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const uint32_t i = b * 16 + j;
+                uint32_t v = 0;
+                if (i < ncol) v = vals[(size_t)i * nip];
+                else if (i == ncol) v = 0x80000000u;
+                else if (i == nblk * 16 - 1) v = 32u * ncol;
+                w[j] = v;
+            }
+            sha256_compress(node, w);
+        }
+        auth = query + shl32(lay.L, 1);
+        len = lay.L;
+        path = batch + (type == 0 ? lay.off_trace_path : lay.off_cp_path);
+        root_w = lay.h_roots + 8 * (type + 1);
+        code_base = stwo_code(5, 0, q, 2 * type);
+    } else {
+        // verify_decommitment (fri/layers.simf:40-48)
+        const uint32_t l = type - 2;
+        const uint32_t *lf = ws + lay.ws_leaf + (size_t)l * 8 * nip + inst;
+        uint32_t e0[4], e1[4], l0[8], l1[8];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { e0[j] = lf[(size_t)j * nip]; e1[j] = lf[(size_t)(4 + j) * nip]; }
+        sha256_words<4>(e0, l0);  // hash_node_qm31 (hasher.simf:100-104)
+        sha256_words<4>(e1, l1);
+        sha256_pair(l0, l1, node);
+        const uint32_t logl = lay.L - l;
+        const uint32_t position = (query >> l) & ~1u;
+        auth = (position + shl32(logl, 1)) >> 1;
+        len = logl - 1;
+        path = batch + lay.off_fri_path[l];
+        root_w = lay.h_fri_roots + 8 * l;
+        code_base = stwo_code(7, l, q, 0);
+    }
+
+    // merkle_verify_32 (merkle.simf:22-44): fold the siblings leaf -> root
+    const uint4 *tp = reinterpret_cast<const uint4 *>(path) + ((size_t)g * len * 2) * 64 + lane;
+    uint4 s0 = make_uint4(0, 0, 0, 0), s1 = s0;
+    if (len) { s0 = tp[0]; s1 = tp[64]; }
+    for (uint32_t lvl = 0; lvl < len; lvl++) {
+        uint4 n0 = s0, n1 = s1;
+        if (lvl + 1 < len) {  // prefetch the next level while this one is hashed
+            n0 = tp[(size_t)(lvl + 1) * 128];
+            n1 = tp[(size_t)(lvl + 1) * 128 + 64];
+        }
+        const uint32_t sib[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const bool right = auth & 1;  // node is the right child: H(sibling || node)
+        uint32_t w[16];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            w[j] = right ? sib[j] : node[j];
+            w[8 + j] = right ? node[j] : sib[j];
+        }
+        sha_iv(node);
+        sha256_compress(node, w);
+        sha256_compress_pad64(node);
+        auth >>= 1;
+        s0 = n0; s1 = n1;
+    }
+    if (!live) return;
+    uint32_t fail = 0xffffffffu;
+    bool same = true;
+#pragma unroll
+    for (int j = 0; j < 8; j++) same &= node[j] == head[(size_t)(root_w + j) * np + p];
+    if (!same) fail = code_base + 1;   // assert!(eq_256(computed_root, root))  merkle.simf:43
+    if (auth != 1) fail = code_base;   // assert!(eq_32(path, 1))              merkle.simf:42
+    if (fail != 0xffffffffu) atomicMin(&status[p], fail);
+}
+
+// ============================================================================ finalize
+__global__ void stwo_finalize_kernel(uint32_t n, uint32_t *__restrict__ status,
+                                     const uint32_t *__restrict__ shape_status,
+                                     uint32_t *__restrict__ accept_count)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    uint32_t s = status[p];
+    if (shape_status) {
+        uint32_t h = shape_status[p];
+        if (h != 0 && h < s) s = h;
+    }
+    s = s == 0xffffffffu ? 0u : s;
+    status[p] = s;
+    if (accept_count && s == 0) atomicAdd(accept_count, 1u);
+}
+
+}  // namespace ss

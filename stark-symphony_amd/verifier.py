@@ -1,0 +1,299 @@
+"""Host side of the batch verifier: records, device batches, verify().
+
+Mirrors the reference's caller-side contract: a proof file goes in, ACCEPT /
+REJECT comes out (`simfony run` exit status, simfony-cli/src/main.rs:205-206,254-257) -- for
+N proofs at once.  All verification work happens in libss_verify.so's HIP kernels; this
+module only re-orders bytes (records -> batch, via ss_*_pack) and moves them with PyTorch,
+which is used for device memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import binding as B
+from .formats import Stark101Proof, StwoConfig, StwoProof
+
+MODE_LITERAL, MODE_FIXTURE = B.MODE_LITERAL, B.MODE_FIXTURE
+
+
+# ----------------------------------------------------------------------------- records
+def _hash_words(b) -> np.ndarray:
+    """32*k bytes -> big-endian u32 words (SHA-256 state words)."""
+    return np.frombuffer(bytes(b), dtype=">u4").astype(np.uint32)
+
+
+def _fixed_path(path: np.ndarray, n: int) -> np.ndarray:
+    """uint8[len, 32] -> uint32[n * 8], truncated / zero padded to n levels."""
+    out = np.zeros(n * 8, dtype=np.uint32)
+    k = min(len(path), n)
+    if k:
+        out[:k * 8] = np.ascontiguousarray(path[:k]).view(">u4").astype(np.uint32).reshape(-1)
+    return out
+
+
+def stwo_code(stage: int, layer: int, query: int, sub: int) -> int:
+    return (stage << 24) | (layer << 16) | (query << 4) | sub
+
+
+def stwo_record(p: StwoProof) -> Tuple[np.ndarray, int]:
+    """Proof -> (record, shape_status); layout in include/ss_verify.h.  shape_status is the
+    code of the first `path == 1` assert (merkle.simf:42) that a wrong-length Merkle path
+    trips, or 0."""
+    c = p.cfg
+    N, L, Q, K = c.n_cols, c.lde_log, c.n_queries, c.n_layers
+    shape = 0
+
+    def note(code: int) -> None:
+        nonlocal shape
+        if shape == 0 or code < shape:
+            shape = code
+    parts: List[np.ndarray] = [
+        _hash_words(p.roots.tobytes()), p.oods_trace.astype(np.uint32).reshape(-1),
+        p.oods_cp.astype(np.uint32).reshape(-1), _hash_words(p.fri_roots.tobytes()),
+        p.last_layer.astype(np.uint32).reshape(-1),
+        np.array([p.pow_nonce >> 32, p.pow_nonce & 0xFFFFFFFF], dtype=np.uint32)]
+    for q in range(Q):
+        if len(p.trace_paths[q]) != L:
+            note(stwo_code(5, 0, q, 0))
+        if len(p.cp_paths[q]) != L:
+            note(stwo_code(5, 0, q, 2))
+        parts += [p.trace_vals[q].astype(np.uint32), p.cp_vals[q].astype(np.uint32),
+                  _fixed_path(p.trace_paths[q], L), _fixed_path(p.cp_paths[q], L)]
+    for l in range(K + 1):
+        n = L - 1 - l
+        for q in range(Q):
+            if len(p.fri_paths[l][q]) != n:
+                note(stwo_code(7, l, q, 0))
+            parts += [p.fri_witness[l, q].astype(np.uint32), _fixed_path(p.fri_paths[l][q], n)]
+    rec = np.ascontiguousarray(np.concatenate(parts), dtype=np.uint32)
+    return rec, shape
+
+
+def s101_shape_of(proofs: Sequence[Stark101Proof]) -> Tuple[int, int]:
+    ml = max([len(p.layers) for p in proofs] + [0])
+    pm = 0
+    for p in proofs:
+        pm = max([pm] + [len(e.path) for e in p.evals]
+                 + [len(x.path) for l in p.layers for x in (l.cpa, l.cpb)])
+    return ml, pm
+
+
+def s101_record(p: Stark101Proof, max_layers: int, max_path: int) -> np.ndarray:
+    def chain(e) -> List[np.ndarray]:
+        return [np.array([e.ev, len(e.path)], dtype=np.uint32), _fixed_path(e.path, max_path)]
+    parts: List[np.ndarray] = [_hash_words(p.root),
+                               np.array([len(p.layers), p.last], dtype=np.uint32)]
+    for e in p.evals:
+        parts += chain(e)
+    for i in range(max_layers):
+        if i < len(p.layers):
+            l = p.layers[i]
+            parts += [_hash_words(l.root), np.array([l.beta], dtype=np.uint32)]
+            parts += chain(l.cpa) + chain(l.cpb)
+        else:
+            parts.append(np.zeros(9 + 2 * (2 + 8 * max_path), dtype=np.uint32))
+    return np.ascontiguousarray(np.concatenate(parts), dtype=np.uint32)
+
+
+def _ptr_array(records: Sequence[np.ndarray]):
+    arr = (C.c_void_p * len(records))()
+    for i, r in enumerate(records):
+        arr[i] = r.ctypes.data
+    return arr
+
+
+def stwo_cfg_struct(cfg: StwoConfig, mode: int) -> B.StwoCfg:
+    return B.StwoCfg(cfg.n_cols, cfg.trace_log, cfg.lde_log, cfg.n_queries, cfg.n_layers, mode,
+                     cfg.pow_target)
+
+
+def pack_stwo(cfg: StwoConfig, mode: int, records: Sequence[np.ndarray]) -> np.ndarray:
+    """records (one per proof; entries may repeat) -> host batch buffer (uint32)."""
+    L = B.lib()
+    cs = stwo_cfg_struct(cfg, mode)
+    want = L.ss_stwo_record_words(C.byref(cs))
+    if want == 0:
+        raise B.SsError(B.SS_ERR_ARG, "unsupported stwo config %r" % (cfg,))
+    for r in records:
+        if r.dtype != np.uint32 or r.size != want or not r.flags["C_CONTIGUOUS"]:
+            raise ValueError("record must be %d contiguous uint32 words" % want)
+    out = np.empty(L.ss_stwo_batch_words(C.byref(cs), len(records)), dtype=np.uint32)
+    B.check(L.ss_stwo_pack(C.byref(cs), len(records), _ptr_array(records), out.ctypes.data))
+    return out
+
+
+def pack_s101(max_layers: int, max_path: int, records: Sequence[np.ndarray]) -> np.ndarray:
+    L = B.lib()
+    sh = B.S101Shape(max_layers, max_path)
+    want = L.ss_s101_record_words(C.byref(sh))
+    for r in records:
+        if r.dtype != np.uint32 or r.size != want or not r.flags["C_CONTIGUOUS"]:
+            raise ValueError("record must be %d contiguous uint32 words" % want)
+    out = np.empty(L.ss_s101_batch_words(C.byref(sh), len(records)), dtype=np.uint32)
+    B.check(L.ss_s101_pack(C.byref(sh), len(records), _ptr_array(records), out.ctypes.data))
+    return out
+
+
+# ---------------------------------------------------------------------- device batches
+def _torch():
+    import torch
+    return torch
+
+
+def _to_dev(a: np.ndarray, device):
+    torch = _torch()
+    return torch.from_numpy(a.view(np.int32)).to(device, non_blocking=False)
+
+
+class _DeviceBatch:
+    """A batch resident in HBM plus its workspace / status buffers."""
+
+    def __init__(self, ver: "Verifier", n: int, batch_host: np.ndarray, ws_bytes: int,
+                 shape_status: Optional[np.ndarray]):
+        torch = _torch()
+        self.ver, self.n = ver, n
+        self.batch = _to_dev(batch_host, ver.device)
+        self.ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.int32, device=ver.device)
+        self.status_dev = torch.empty(n, dtype=torch.int32, device=ver.device)
+        self.accept_dev = torch.zeros(1, dtype=torch.int32, device=ver.device)
+        self.shape_dev = None
+        if shape_status is not None and np.any(shape_status):
+            self.shape_dev = _to_dev(np.ascontiguousarray(shape_status, dtype=np.uint32), ver.device)
+        self.batch_bytes = batch_host.nbytes
+
+    def _stream(self, stream) -> int:
+        torch = _torch()
+        s = stream if stream is not None else torch.cuda.current_stream(self.ver.device)
+        return int(s.cuda_stream)
+
+    def status(self) -> np.ndarray:
+        """Synchronises, returns the per-proof status words (0 = ACCEPT)."""
+        return self.status_dev.cpu().numpy().view(np.uint32).copy()
+
+    def accepted(self) -> int:
+        return int(self.accept_dev.item())
+
+
+class StwoDeviceBatch(_DeviceBatch):
+    def __init__(self, ver: "Verifier", cfg: StwoConfig, mode: int, records: Sequence[np.ndarray],
+                 shape_status: Optional[np.ndarray] = None):
+        L = B.lib()
+        self.cfg, self.mode = cfg, mode
+        self.cs = stwo_cfg_struct(cfg, mode)
+        host = pack_stwo(cfg, mode, records)
+        super().__init__(ver, len(records), host, L.ss_stwo_workspace_bytes(C.byref(self.cs), len(records)),
+                         shape_status)
+
+    def run(self, stream=None) -> None:
+        """Asynchronous: enqueue the verification of the whole batch on `stream`."""
+        B.check(B.lib().ss_stwo_verify_batch_dev(
+            self.ver.ctx, C.byref(self.cs), self.n, self.batch.data_ptr(),
+            self.shape_dev.data_ptr() if self.shape_dev is not None else None,
+            self.ws.data_ptr(), self.ws.numel() * 4, self.status_dev.data_ptr(),
+            self.accept_dev.data_ptr(), self._stream(stream)))
+
+
+class S101DeviceBatch(_DeviceBatch):
+    def __init__(self, ver: "Verifier", max_layers: int, max_path: int, records: Sequence[np.ndarray]):
+        L = B.lib()
+        self.sh = B.S101Shape(max_layers, max_path)
+        host = pack_s101(max_layers, max_path, records)
+        super().__init__(ver, len(records), host, L.ss_s101_workspace_bytes(C.byref(self.sh), len(records)),
+                         None)
+
+    def run(self, stream=None) -> None:
+        B.check(B.lib().ss_s101_verify_batch_dev(
+            self.ver.ctx, C.byref(self.sh), self.n, self.batch.data_ptr(), self.ws.data_ptr(),
+            self.ws.numel() * 4, self.status_dev.data_ptr(), self.accept_dev.data_ptr(),
+            self._stream(stream)))
+
+
+class Verifier:
+    """One context on one MI355X.  Raises SsError if the GPU or the library is unusable."""
+
+    def __init__(self, device: int = 0):
+        torch = _torch()
+        self.index = device
+        self.device = torch.device("cuda", device)
+        ctx = C.c_void_p()
+        B.check(B.lib().ss_ctx_create(device, C.byref(ctx)))
+        self.ctx = ctx
+        torch.cuda.set_device(self.device)
+
+    def close(self) -> None:
+        if self.ctx:
+            B.lib().ss_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- timing -----------------------------------------------------------------------
+    def set_timing(self, on: bool) -> None:
+        B.check(B.lib().ss_ctx_set_timing(self.ctx, 1 if on else 0))
+
+    def last_timing(self) -> List[Tuple[str, float]]:
+        names = (C.c_char_p * 8)()
+        ms = (C.c_float * 8)()
+        k = B.check(B.lib().ss_ctx_last_timing(self.ctx, 8, names, ms))
+        return [(names[i].decode(), float(ms[i])) for i in range(k)]
+
+    # -- stark101 ---------------------------------------------------------------------
+    def stark101_batch(self, proofs: Sequence[Stark101Proof], replicate: int = 1) -> S101DeviceBatch:
+        ml, pm = s101_shape_of(proofs)
+        recs = [s101_record(p, ml, pm) for p in proofs]
+        return S101DeviceBatch(self, ml, pm, recs * replicate)
+
+    def verify_stark101(self, proofs: Sequence[Stark101Proof]) -> np.ndarray:
+        b = self.stark101_batch(proofs)
+        b.run()
+        return b.status()
+
+    # -- stwo -------------------------------------------------------------------------
+    def stwo_batch(self, proofs: Sequence[StwoProof], mode: int = MODE_FIXTURE,
+                   replicate: int = 1) -> StwoDeviceBatch:
+        cfg = proofs[0].cfg
+        if any(p.cfg != cfg for p in proofs):
+            raise ValueError("all proofs of a batch must share one StwoConfig")
+        recs, shapes = zip(*[stwo_record(p) for p in proofs])
+        return StwoDeviceBatch(self, cfg, mode, list(recs) * replicate,
+                               np.array(list(shapes) * replicate, dtype=np.uint32))
+
+    def verify_stwo(self, proofs: Sequence[StwoProof], mode: int = MODE_FIXTURE) -> np.ndarray:
+        b = self.stwo_batch(proofs, mode)
+        b.run()
+        return b.status()
+
+    # -- primitives self-test (tests only) ------------------------------------------------
+    def selftest(self, op: int, inputs: np.ndarray) -> np.ndarray:
+        in_w, out_w = [16, 2, 8, 1, 2][op], [8, 4, 8, 2, 4][op]
+        inputs = np.ascontiguousarray(inputs, dtype=np.uint32).reshape(-1, in_w)
+        out = np.empty((inputs.shape[0], out_w), dtype=np.uint32)
+        B.check(B.lib().ss_selftest(self.ctx, op, inputs.shape[0], inputs.ctypes.data, out.ctypes.data))
+        return out
+
+
+_default: Optional[Verifier] = None
+
+
+def default_verifier() -> Verifier:
+    global _default
+    if _default is None:
+        _default = Verifier(0)
+    return _default
+
+
+def verify_stark101(proof: Stark101Proof) -> bool:
+    """Drop-in for `simfony run stark101/main.simf --witness proof.wit`: True = ACCEPT."""
+    return int(default_verifier().verify_stark101([proof])[0]) == 0
+
+
+def verify_stwo(proof: StwoProof, mode: int = MODE_FIXTURE) -> bool:
+    """Drop-in for `simfony run stwo-verifier/main.simf --witness proof.wit`."""
+    return int(default_verifier().verify_stwo([proof], mode)[0]) == 0

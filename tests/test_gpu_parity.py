@@ -1,0 +1,223 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit for bit.
+
+Every status word must equal the oracle's -- not only accept/reject but the code of the first
+failing assert.  Run on the GPU box with `pytest -m gpu`.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from stark_symphony_amd import formats, verifier
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+SEED = 0x5EED2025
+
+
+@pytest.fixture(scope="module")
+def ver():
+    return verifier.Verifier(0)
+
+
+# ------------------------------------------------------------------------- primitives
+def _mixed_u32(rng, n):
+    """Canonical, unreduced and edge-case words."""
+    v = rng.integers(0, 1 << 32, size=n, dtype=np.uint64).astype(np.uint32)
+    edges = np.array([0, 1, 2, 2147483646, 2147483647, 2147483648, 2147483649, 3221225472,
+                      3221225473, 3221225474, 4294967294, 4294967295], dtype=np.uint32)
+    v[:len(edges)] = edges
+    return v
+
+
+def test_sha256_pair(ver):
+    rng = np.random.default_rng(SEED)
+    msgs = rng.integers(0, 1 << 32, size=(257, 16), dtype=np.uint64).astype(np.uint32)
+    msgs[0] = 0
+    got = ver.selftest(0, msgs)
+    for m, g in zip(msgs, got):
+        want = np.frombuffer(O.sha256(m.astype(">u4").tobytes()), dtype=">u4")
+        assert np.array_equal(g, want)
+
+
+def test_m31_ops(ver):
+    rng = np.random.default_rng(SEED + 1)
+    a, b = _mixed_u32(rng, 4096), np.roll(_mixed_u32(rng, 4096), 7)
+    got = ver.selftest(1, np.stack([a, b], 1))
+    L = O.lib()
+    for x, y, g in zip(a.tolist(), b.tolist(), got.tolist()):
+        out = C.c_uint32()
+        inv = out.value if L.so_m31_inv(x, C.byref(out)) == 0 else 0xFFFFFFFF
+        assert g == [L.so_m31_add(x, y), L.so_m31_sub(x, y), L.so_m31_mul(x, y), inv]
+
+
+def test_qm31_ops(ver):
+    rng = np.random.default_rng(SEED + 2)
+    v = _mixed_u32(rng, 8 * 1024).reshape(-1, 8)
+    v[3, :4] = 0  # inverse of zero aborts
+    got = ver.selftest(2, v)
+    L = O.lib()
+    for row, g in zip(v.tolist(), got.tolist()):
+        a, b = O.qm(row[:4]), O.qm(row[4:])
+        inv = O.QM31()
+        ok = L.so_qm31_inv(a, C.byref(inv)) == 0
+        want = list(L.so_qm31_mul(a, b).t()) + (list(inv.t()) if ok else [0xFFFFFFFF] * 4)
+        assert g == want
+
+
+def test_circle_point(ver):
+    rng = np.random.default_rng(SEED + 3)
+    idx = _mixed_u32(rng, 2048)
+    idx[20:40] = np.arange(20)
+    idx[40] = 1389
+    got = ver.selftest(3, idx)
+    L = O.lib()
+    for i, g in zip(idx.tolist(), got.tolist()):
+        assert tuple(g) == L.so_circle_point_index_to_m31_point(i).t()
+
+
+def test_stark101_field(ver):
+    rng = np.random.default_rng(SEED + 4)
+    a, b = _mixed_u32(rng, 4096), np.roll(_mixed_u32(rng, 4096), 5)
+    got = ver.selftest(4, np.stack([a, b], 1))
+    L = O.lib()
+    for x, y, g in zip(a.tolist(), b.tolist(), got.tolist()):
+        out = C.c_uint32()
+        d = out.value if L.so_s101_div_mod(x, y, C.byref(out)) == 0 else 0xFFFFFFFF
+        assert g == [L.so_s101_add_mod(x, y), L.so_s101_sub_mod(x, y), L.so_s101_mul_mod(x, y), d]
+
+
+# ---------------------------------------------------------------------------- stark101
+def test_stark101_accept(ver, s101_proof):
+    assert ver.verify_stark101([s101_proof]).tolist() == [0]
+    assert verifier.verify_stark101(s101_proof) is True
+
+
+def test_stark101_corruptions(ver, s101_proof):
+    rng = np.random.default_rng(SEED)
+    batch, notes = [s101_proof], ["valid"]
+    for _ in range(299):
+        p, why = formats.stark101_corrupt(s101_proof, rng)
+        batch.append(p)
+        notes.append(why)
+    got = ver.verify_stark101(batch)
+    want = O.s101_verify_batch(batch)
+    bad = [(i, notes[i], hex(got[i]), hex(want[i])) for i in range(len(batch)) if got[i] != want[i]]
+    assert not bad, bad[:5]
+    assert want[0] == 0 and (want[1:] != 0).all()
+    assert len(set(want.tolist())) > 5  # the corruptions exercise several stages
+
+
+def test_stark101_ragged_shapes(ver, s101_proof):
+    """Shorter / longer layer lists and Merkle paths (List<_, 32> is data-dependent)."""
+    batch = [s101_proof]
+    p = s101_proof.copy(); p.layers = p.layers[:7]; batch.append(p)
+    p = s101_proof.copy(); p.layers = p.layers[:0]; batch.append(p)
+    p = s101_proof.copy(); p.evals[1].path = p.evals[1].path[:9]; batch.append(p)
+    p = s101_proof.copy()
+    p.layers[3].cpb.path = np.concatenate([p.layers[3].cpb.path, p.layers[3].cpb.path[:2]])
+    batch.append(p)
+    p = s101_proof.copy(); p.layers[0].cpa.path = p.layers[0].cpa.path[:0]; batch.append(p)
+    p = s101_proof.copy(); p.layers = p.layers + p.layers[-3:]; batch.append(p)
+    got = ver.verify_stark101(batch)
+    want = O.s101_verify_batch(batch)
+    assert got.tolist() == want.tolist() and want[0] == 0
+
+
+def test_stark101_unreduced_words(ver, s101_proof):
+    """Field words >= p are legal u32 witnesses; wrap-around semantics must match."""
+    P = 3221225473
+    batch = []
+    for mut in range(6):
+        p = s101_proof.copy()
+        if mut == 0: p.last = 0xFFFFFFFF
+        if mut == 1: p.evals[0].ev = 0xFFFFFFFF
+        if mut == 2: p.layers[2].cpb.ev = P
+        if mut == 3: p.layers[0].beta = 0xFFFFFFFE
+        if mut == 4: p.evals[2].ev = 0
+        if mut == 5: p.layers[9].cpa.ev = P + 5
+        batch.append(p)
+    got = ver.verify_stark101(batch)
+    assert got.tolist() == O.s101_verify_batch(batch).tolist()
+
+
+def test_stark101_batch_4096(ver, s101_proof):
+    """BASELINE config 2: 4096 proofs, every fourth one corrupted."""
+    rng = np.random.default_rng(SEED + 9)
+    distinct = [s101_proof] + [formats.stark101_corrupt(s101_proof, rng)[0] for _ in range(15)]
+    idx = [0 if i % 4 else 1 + (i // 4) % 15 for i in range(4096)]
+    batch = [distinct[i] for i in idx]
+    got = ver.verify_stark101(batch)
+    want_d = O.s101_verify_batch(distinct)
+    assert got.tolist() == [int(want_d[i]) for i in idx]
+
+
+# -------------------------------------------------------------------------------- stwo
+@pytest.mark.parametrize("which", ["small", "prod"])
+def test_stwo_fixtures(ver, stwo_small, stwo_prod, which):
+    p = stwo_small if which == "small" else stwo_prod
+    assert ver.verify_stwo([p], verifier.MODE_FIXTURE).tolist() == [0]
+    lit = ver.verify_stwo([p], verifier.MODE_LITERAL).tolist()
+    assert lit == [O.stwo_verify(p, O.MODE_LITERAL)] and lit[0] == (7 << 24) | 1
+
+
+@pytest.mark.parametrize("mode", [verifier.MODE_FIXTURE, verifier.MODE_LITERAL])
+def test_stwo_corruptions(ver, stwo_small, stwo_prod, mode):
+    for base, n in ((stwo_small, 200), (stwo_prod, 120)):
+        rng = np.random.default_rng(SEED + mode)
+        batch, notes = [base], ["valid"]
+        for _ in range(n - 1):
+            p, why = formats.stwo_corrupt(base, rng)
+            batch.append(p)
+            notes.append(why)
+        got = ver.verify_stwo(batch, mode)
+        want = O.stwo_verify_batch(batch, mode)
+        bad = [(i, notes[i], hex(got[i]), hex(want[i])) for i in range(n) if got[i] != want[i]]
+        assert not bad, bad[:5]
+        if mode == verifier.MODE_FIXTURE:
+            assert want[0] == 0 and len(set(want.tolist())) > 4
+
+
+def test_stwo_wrong_path_lengths(ver, stwo_prod):
+    batch = [stwo_prod]
+    p = stwo_prod.copy(); p.trace_paths[3] = p.trace_paths[3][:-1]; batch.append(p)
+    p = stwo_prod.copy()
+    p.cp_paths[0] = np.concatenate([p.cp_paths[0], p.cp_paths[0][:1]])
+    batch.append(p)
+    p = stwo_prod.copy(); p.fri_paths[4][7] = p.fri_paths[4][7][:2]; batch.append(p)
+    p = stwo_prod.copy(); p.fri_paths[0][0] = p.fri_paths[0][0][:0]; p.pow_nonce += 1; batch.append(p)
+    got = ver.verify_stwo(batch)
+    want = O.stwo_verify_batch(batch)
+    assert got.tolist() == want.tolist()
+
+
+def test_stwo_unreduced_words(ver, stwo_prod):
+    P = 2147483647
+    batch = []
+    for mut in range(8):
+        p = stwo_prod.copy()
+        if mut == 0: p.fri_witness[0, 0, 1] += P
+        if mut == 1: p.fri_witness[3, 5, :] = 0xFFFFFFFF
+        if mut == 2: p.oods_trace[1, 2] += P
+        if mut == 3: p.oods_cp[5, 0] = 0xFFFFFFFF
+        if mut == 4: p.last_layer[0] += P
+        if mut == 5: p.trace_vals[2, 1] += P
+        if mut == 6: p.cp_vals[7, 9] = 0xFFFFFFFE
+        if mut == 7: p.oods_trace[0, 0] = 0x80000001
+        batch.append(p)
+    for mode in (verifier.MODE_FIXTURE, verifier.MODE_LITERAL):
+        got = ver.verify_stwo(batch, mode)
+        assert got.tolist() == O.stwo_verify_batch(batch, mode).tolist()
+
+
+def test_stwo_batch_replicated(ver, stwo_prod):
+    """A 1000-proof batch (not a multiple of 64) mixing a valid proof and corruptions."""
+    rng = np.random.default_rng(SEED + 5)
+    distinct = [stwo_prod] + [formats.stwo_corrupt(stwo_prod, rng)[0] for _ in range(9)]
+    idx = [0 if i % 3 else 1 + (i // 3) % 9 for i in range(1000)]
+    got = ver.verify_stwo([distinct[i] for i in idx])
+    want_d = O.stwo_verify_batch(distinct)
+    assert got.tolist() == [int(want_d[i]) for i in idx]
+    b = ver.stwo_batch([distinct[i] for i in idx])
+    b.run()
+    assert b.accepted() == sum(1 for i in idx if want_d[i] == 0)

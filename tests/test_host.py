@@ -1,0 +1,215 @@
+"""CPU-only tests of the host layer: formats, records, the C ABI's exports and the packers
+(no compute calls -- those need an MI355X and live in test_gpu_parity.py)."""
+import ctypes as C
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import stark_symphony_amd as ss
+from stark_symphony_amd import binding, formats, verifier
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = binding.lib()
+    hdr = open(os.path.join(ROOT, "include", "ss_verify.h")).read()
+    declared = set(re.findall(r"\b(ss_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"ss_ctx"}
+    assert declared == set(binding.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ss_version() == 0x00010000
+
+
+def test_no_device_is_a_loud_error():
+    """Without a GPU the context cannot be created; nothing falls back to the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = binding.lib()
+    ctx = C.c_void_p()
+    rc = lib.ss_ctx_create(0, C.byref(ctx))
+    assert rc == binding.SS_ERR_NO_DEVICE and lib.ss_last_error()
+    with pytest.raises(binding.SsError):
+        binding.check(rc)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "stark-symphony_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("the oracle", "").replace("CPU oracle", ""), f
+
+
+def test_stark101_formats_roundtrip(s101_proof):
+    j = ss.stark101_to_json(s101_proof)
+    assert j == json.load(open(os.path.join(ROOT, "tests", "golden", "stark101_proof.json")))
+    again = ss.stark101_from_wit(ss.stark101_to_wit(s101_proof))
+    assert ss.stark101_to_json(again) == j
+    assert [len(l.cpa.path) for l in s101_proof.layers] == list(range(13, 3, -1))
+
+
+def test_stwo_formats_roundtrip(stwo_small, stwo_prod):
+    for p, name in ((stwo_small, "stwo_proof_test.json"), (stwo_prod, "stwo_proof.json")):
+        assert ss.stwo_to_json(p) == json.load(open(os.path.join(ROOT, "tests", "golden", name)))
+        again = ss.stwo_from_wit(ss.stwo_to_wit(p), p.cfg.trace_log, p.cfg.pow_bits)
+        assert ss.stwo_to_json(again) == ss.stwo_to_json(p)
+    assert stwo_small.cfg == ss.TESTING_CONFIG and stwo_prod.cfg == ss.PRODUCTION_CONFIG
+
+
+def test_work_formulas_match_baseline_md():
+    c = ss.StwoConfig
+    assert (ss.PRODUCTION_CONFIG.packed_bytes, ss.PRODUCTION_CONFIG.compressions) == (54488, 3806)
+    assert (c(4, 16, 20, 32, 15, 5).packed_bytes, c(4, 16, 20, 32, 15, 5).compressions) == (241080, 16549)
+    assert (c(4, 20, 24, 16, 19, 5).packed_bytes, c(4, 20, 24, 16, 19, 5).compressions) == (170296, 11583)
+    assert (c(256, 14, 18, 16, 13, 5).packed_bytes, c(256, 14, 18, 16, 13, 5).compressions) == (119608, 7180)
+
+
+def test_malformed_inputs_raise():
+    with pytest.raises(ss.MalformedProof):
+        ss.stark101_from_json({"p_mt_root": 1})
+    with pytest.raises(ss.MalformedProof):
+        ss.stark101_from_json({"p_mt_root": 1 << 256, "evals": [[1, []]] * 3, "fri_layers": [],
+                               "fri_last_layer": 0})
+    with pytest.raises(ss.MalformedProof):
+        ss.stark101_from_json({"p_mt_root": 1, "evals": [[1, [0] * 32]] * 3, "fri_layers": [],
+                               "fri_last_layer": 0})
+    with pytest.raises(ss.MalformedProof):
+        formats.parse_literal("(1, 2")
+    assert formats.parse_literal("((1, list![0x10, 2]), [3], (4))") == [[1, [16, 2]], [3], 4]
+
+
+def test_literal_matches_reference_generator_text(stwo_prod, s101_proof):
+    """The .wit text we write is what stark101/scripts/generate_wit.py and
+    stwo-verifier/scripts/generate_wit.py print (only checked where /root/reference exists)."""
+    ref = os.environ.get("SS_REFERENCE", "/root/reference")
+    if not os.path.isdir(ref):
+        pytest.skip("reference not mounted")
+    g = os.path.join(ROOT, "tests", "golden")
+    out = subprocess.run(["python3", os.path.join(ref, "stwo-verifier/scripts/generate_wit.py"),
+                          os.path.join(g, "stwo_proof.json")], capture_output=True, text=True, check=True)
+    assert json.loads(out.stdout) == json.loads(ss.stwo_to_wit(stwo_prod))
+    out = subprocess.run(["python3", os.path.join(ref, "stark101/scripts/generate_wit.py"),
+                          os.path.join(g, "stark101_proof.json")], capture_output=True, text=True, check=True)
+    assert json.loads(out.stdout) == json.loads(ss.stark101_to_wit(s101_proof))
+
+
+# --------------------------------------------------------------------------- packers
+def _tile_word(base, tile_len, inst, level, w):
+    return base + (((inst >> 6) * tile_len + level) * 2 + (w >> 2)) * 256 + (inst & 63) * 4 + (w & 3)
+
+
+def test_stwo_record_and_pack_layout(stwo_prod):
+    cfg = stwo_prod.cfg
+    rec, shape = verifier.stwo_record(stwo_prod)
+    assert shape == 0
+    lib = binding.lib()
+    cs = verifier.stwo_cfg_struct(cfg, verifier.MODE_FIXTURE)
+    assert rec.size == lib.ss_stwo_record_words(C.byref(cs))
+    assert rec.size * 4 == cfg.packed_bytes  # the record is exactly the algorithmic bytes
+    n = 70
+    other = rec.copy()
+    other[::7] ^= 0xA5A5A5A5
+    recs = [rec if i % 2 == 0 else other for i in range(n)]
+    batch = verifier.pack_stwo(cfg, verifier.MODE_FIXTURE, recs)
+    N, L, Q, K = cfg.n_cols, cfg.lde_log, cfg.n_queries, cfg.n_layers
+    npad, nip = 128, ((n * Q + 63) // 64) * 64
+    head_words = 24 + 4 * N + 64 + 8 * (K + 1) + 4 + 2
+    assert batch.size == lib.ss_stwo_batch_words(C.byref(cs), n)
+    # every word of every record sits where the documented layout says; nothing else is set
+    expect = np.zeros_like(batch)
+    off_head = 0
+    off_tv = off_head + head_words * npad
+    off_cv = off_tv + N * nip
+    off_wit = off_cv + 16 * nip
+    off_tp = off_wit + (K + 1) * 4 * nip
+    off_cp = off_tp + L * 8 * nip
+    off_fp = [off_cp + L * 8 * nip]
+    for l in range(K + 1):
+        off_fp.append(off_fp[-1] + (L - 1 - l) * 8 * nip)
+    assert off_fp[-1] == batch.size
+    for p, r in enumerate(recs):
+        pos = 0
+        for w in range(head_words):
+            expect[off_head + w * npad + p] = r[pos]; pos += 1
+        for q in range(Q):
+            inst = p * Q + q
+            for k in range(N):
+                expect[off_tv + k * nip + inst] = r[pos]; pos += 1
+            for k in range(16):
+                expect[off_cv + k * nip + inst] = r[pos]; pos += 1
+            for base in (off_tp, off_cp):
+                for lv in range(L):
+                    for w in range(8):
+                        expect[_tile_word(base, L, inst, lv, w)] = r[pos]; pos += 1
+        for l in range(K + 1):
+            ln = L - 1 - l
+            for q in range(Q):
+                inst = p * Q + q
+                for w in range(4):
+                    expect[off_wit + (l * 4 + w) * nip + inst] = r[pos]; pos += 1
+                for lv in range(ln):
+                    for w in range(8):
+                        expect[_tile_word(off_fp[l], ln, inst, lv, w)] = r[pos]; pos += 1
+        assert pos == r.size
+    assert np.array_equal(batch, expect)
+
+
+def test_stwo_record_reports_wrong_path_lengths(stwo_prod):
+    p = stwo_prod.copy()
+    p.fri_paths[2][5] = p.fri_paths[2][5][:-1]
+    p.cp_paths[9] = p.cp_paths[9][:3]
+    rec, shape = verifier.stwo_record(p)
+    assert shape == verifier.stwo_code(5, 0, 9, 2)
+    assert rec.size * 4 == p.cfg.packed_bytes
+
+
+def test_s101_record_and_pack(s101_proof):
+    ml, pm = verifier.s101_shape_of([s101_proof])
+    assert (ml, pm) == (10, 13)
+    rec = verifier.s101_record(s101_proof, ml, pm)
+    lib = binding.lib()
+    sh = binding.S101Shape(ml, pm)
+    assert rec.size == lib.ss_s101_record_words(C.byref(sh))
+    batch = verifier.pack_s101(ml, pm, [rec] * 65)
+    assert batch.size == lib.ss_s101_batch_words(C.byref(sh), 65)
+    npad = 128
+    head_words = 10 + 9 * ml
+    root = np.frombuffer(s101_proof.root, dtype=">u4")
+    assert [batch[w * npad + 64] for w in range(8)] == root.tolist()
+    assert batch[8 * npad + 3] == 10 and batch[9 * npad + 3] == s101_proof.last
+    off_leaf = head_words * npad
+    off_len = off_leaf + 23 * npad
+    off_path = off_len + 23 * npad
+    assert batch[off_leaf + 0 * npad + 1] == s101_proof.evals[0].ev
+    assert batch[off_leaf + (3 + 2 * 4) * npad + 1] == s101_proof.layers[4].cpa.ev
+    assert [batch[off_len + t * npad + 7] for t in range(23)] == \
+        [13, 13, 13] + [13 - i for i in range(10) for _ in range(2)]
+    node = np.frombuffer(s101_proof.layers[2].cpb.path[5].tobytes(), dtype=">u4")
+    base = off_path + (4 + 2 * 2) * (pm * 8 * npad)
+    assert [batch[_tile_word(base, pm, 64, 5, w)] for w in range(8)] == node.tolist()
+
+
+def test_pack_rejects_bad_arguments(stwo_prod):
+    lib = binding.lib()
+    cs = binding.StwoCfg(0, 9, 13, 16, 8, 1, 1)
+    assert lib.ss_stwo_record_words(C.byref(cs)) == 0
+    cs = binding.StwoCfg(4, 9, 13, 16, 12, 1, 1)  # more layers than the domain allows
+    assert lib.ss_stwo_batch_words(C.byref(cs), 4) == 0
+    with pytest.raises(ValueError):
+        verifier.pack_stwo(stwo_prod.cfg, 1, [np.zeros(5, dtype=np.uint32)])
+
+
+def test_corruption_helpers_are_seeded(s101_proof, stwo_prod):
+    a = [formats.stark101_corrupt(s101_proof, np.random.default_rng(7))[1] for _ in range(2)]
+    assert a[0] == a[1]
+    q1, _ = formats.stwo_corrupt(stwo_prod, np.random.default_rng(11))
+    q2, _ = formats.stwo_corrupt(stwo_prod, np.random.default_rng(11))
+    assert ss.stwo_to_json(q1) == ss.stwo_to_json(q2) != ss.stwo_to_json(stwo_prod)
