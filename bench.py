@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Benchmark of the batch STARK verifier hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (for N > 1 launched by torch.distributed.run; RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* come from the environment).  A "step" verifies one batch of
+`--proofs-per-gpu` stwo circle-STARK proofs that is already resident in HBM, then all-reduces
+the accept count over RCCL (the only exchange of the path).  Weak scaling: every rank owns
+its own batch, total work grows with N.  Rank 0 prints ONE JSON line.
+
+Workloads (`--workload`):
+  stwo_2p20      2^20-row wide-Fibonacci trace, blowup 2^4 (LDE 2^24), 16 queries, 19 inner FRI
+                 layers, SHA-256 -- BASELINE.json configs[3], the configuration the metric is
+                 quoted on.  Proofs: tests/golden/stwo_trace20.npz (made by tools/stwo_prover.py).
+  stwo_fixture   the reference's own proof (tests/golden/stwo_proof.json: trace 2^9, LDE 2^13,
+                 16 queries) replicated -- used when the 2^20 fixture is absent.
+  stark101       BASELINE.json configs[1]: the stark101 proof x 4096.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E spec peak
+# integer VALU peak: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz lane-ops/s (same issue rate as the
+# 157.3 TFLOP/s fp32 vector peak counted as 1 op, MI355X_MICROARCH.md chip table)
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9
+
+
+def load_workload(name: str):
+    """-> (workload name, family, list of distinct proofs, note)"""
+    import stark_symphony_amd as ss
+    from stark_symphony_amd import formats
+    big = os.path.join(GOLDEN, "stwo_trace20.npz")
+    if name == "auto":
+        name = "stwo_2p20" if os.path.exists(big) else "stwo_fixture"
+    if name == "stwo_2p20":
+        from stark_symphony_amd import records
+        proofs = records.load_stwo_npz(big)
+        return name, "stwo", proofs, "wide-Fibonacci 2^20 x 4, LDE 2^24, Q=16, K=19, SHA-256"
+    if name == "stwo_fixture":
+        p = ss.stwo_from_json(json.load(open(os.path.join(GOLDEN, "stwo_proof.json"))))
+        return name, "stwo", [p], "reference proof.json (trace 2^9, LDE 2^13, Q=16, K=8) replicated"
+    if name == "stark101":
+        p = ss.stark101_from_json(json.load(open(os.path.join(GOLDEN, "stark101_proof.json"))))
+        return name, "stark101", [p], "reference stark101 proof replicated (only one valid proof exists)"
+    raise SystemExit("unknown workload %r" % name)
+
+
+def cpu_baseline(family, proofs, seconds: float):
+    """Oracle (CPU restatement of the reference path) on this box's host cores; bounded sample."""
+    from oracle import oracle as O
+    threads = O.num_procs()
+    if family == "stwo":
+        chunk = max(threads * 4, 32)
+        batch = O.StwoBatch([proofs[i % len(proofs)] for i in range(chunk)])
+        run = lambda: batch.verify(O.MODE_FIXTURE, threads)  # noqa: E731
+    else:
+        chunk = max(threads * 64, 512)
+        arr = O.s101_array([proofs[i % len(proofs)] for i in range(chunk)])
+        run = lambda: O.s101_verify_batch(arr, threads)  # noqa: E731
+    st = run()
+    assert (st == 0).all(), "oracle rejects the benchmark proofs"
+    done, t0 = 0, time.perf_counter()
+    while True:
+        run()
+        done += chunk
+        dt = time.perf_counter() - t0
+        if dt >= seconds:
+            break
+    return {"value": done / dt, "unit": "proofs/s", "cores": threads, "kind": "port",
+            "sample": "%d proofs of the same workload in %.1f s, C oracle (restatement of the "
+                      "SimplicityHL verifier; `simfony run` is not buildable here), OpenMP over proofs"
+                      % (done, dt)}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="auto")
+    ap.add_argument("--proofs-per-gpu", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from stark_symphony_amd import verifier
+    wname, family, proofs, note = load_workload(args.workload)
+    ver = verifier.Verifier(local)
+
+    if family == "stwo":
+        cfg = proofs[0].cfg
+        per_gpu = args.proofs_per_gpu or (8192 if cfg.lde_log >= 20 else 32768)
+        reps = (per_gpu + len(proofs) - 1) // len(proofs)
+        batch = ver.stwo_batch(proofs, verifier.MODE_FIXTURE, replicate=reps)
+        bytes_per_proof, compr_per_proof = cfg.packed_bytes, cfg.compressions
+        dominant = "stwo_merkle"
+    else:
+        per_gpu = args.proofs_per_gpu or 4096
+        batch = ver.stark101_batch(proofs, replicate=per_gpu)
+        bytes_per_proof, compr_per_proof = 7176, 480
+        dominant = "s101_merkle"
+    n_local = batch.n
+
+    acc = torch.zeros(1, dtype=torch.int32, device=ver.device)
+
+    def step() -> None:
+        batch.run()
+        if world > 1:  # the path's only exchange: accept-count reduce over xGMI
+            acc.copy_(batch.accept_dev)
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    assert batch.accepted() == n_local, "benchmark proofs must all be ACCEPT (%d of %d)" % (
+        batch.accepted(), n_local)
+    ver.set_timing(True)
+    ver.collect_timing()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    timing = ver.collect_timing()
+    ver.set_timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ver.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        total_accept = int(acc.item())
+    else:
+        total_accept = batch.accepted()
+    assert total_accept == n_local * world, "accept-reduce mismatch"
+
+    if rank == 0:
+        total = n_local * world * args.steps
+        value = total / elapsed
+        k_ms, k_n = timing.get(dominant, (0.0, 0))
+        k_avg_s = (k_ms / max(k_n, 1)) * 1e-3
+        launch_bytes = bytes_per_proof * n_local
+        achieved = launch_bytes / k_avg_s / 1e9 if k_avg_s else 0.0
+        compr_s = compr_per_proof * n_local / k_avg_s if k_avg_s else 0.0
+        out = {
+            "metric": "proofs verified/sec (batch), stwo 2^20-domain circle-STARK"
+                      if family == "stwo" else "proofs verified/sec (batch), stark101",
+            "value": value, "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": wname, "note": note, "proofs_per_gpu": n_local,
+                       "distinct_proofs": len(proofs), "bytes_per_proof": bytes_per_proof,
+                       "sha256_compressions_per_proof": compr_per_proof, "hash": "sha256",
+                       "mode": "fixture_correct", "parallelism": "proofs sharded over %d GPU(s)" % world},
+            "hbm_gb_s": value * bytes_per_proof / 1e9,
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None,
+                         "kernel_avg_ms": k_avg_s * 1e3, "kernel_launches": k_n,
+                         "algorithmic_bytes_per_launch": launch_bytes,
+                         "note": "integer-ALU bound by construction (2 SHA-256 compressions per "
+                                 "32-byte sibling); see alu_roofline"},
+            "alu_roofline": {"sha256_compressions_per_s": compr_s,
+                             "valu_peak_lane_ops_per_s": VALU_PEAK_LANE_OPS},
+            "kernels_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in timing.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(family, proofs, args.cpu_seconds)
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

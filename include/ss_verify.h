@@ -148,12 +148,14 @@ int ss_stwo_verify_records(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n,
                            const uint32_t *const *records, const uint32_t *shape_status_host,
                            uint32_t *status_host);
 
-/* Timing of the last *_verify_batch_dev call on this context, measured with HIP events
- * recorded on the caller's stream around each kernel (enable with ss_ctx_set_timing(ctx, 1);
- * off by default because event recording is not graph-capturable).  Names are static
- * strings; returns the number of kernels written (<= cap).                              */
+/* Kernel timing.  With timing enabled every *_verify_batch_dev call records a HIP event pair
+ * around each kernel ON THE CALLER'S STREAM (no synchronisation; not graph-capturable, so off
+ * by default).  ss_ctx_collect_timing waits for the recorded events, sums them per kernel
+ * name (static strings) and clears the list: names[i], total_ms[i], launches[i] for i <
+ * return value (<= cap).                                                                  */
 int ss_ctx_set_timing(ss_ctx *ctx, int enabled);
-int ss_ctx_last_timing(ss_ctx *ctx, int cap, const char **names, float *ms);
+int ss_ctx_collect_timing(ss_ctx *ctx, int cap, const char **names, float *total_ms,
+                          uint32_t *launches);
 
 /* Device self-test of the primitives (tests only): runs `op` over `n` inputs.
  *   op 0  sha256 of 64-byte messages: in 16 words/item, out 8 words/item

@@ -39,7 +39,7 @@ EXPORTS = [
     "ss_s101_record_words", "ss_s101_batch_words", "ss_s101_workspace_bytes", "ss_s101_pack",
     "ss_stwo_record_words", "ss_stwo_batch_words", "ss_stwo_workspace_bytes", "ss_stwo_pack",
     "ss_ctx_create", "ss_ctx_destroy", "ss_s101_verify_batch_dev", "ss_stwo_verify_batch_dev",
-    "ss_s101_verify_records", "ss_stwo_verify_records", "ss_ctx_set_timing", "ss_ctx_last_timing",
+    "ss_s101_verify_records", "ss_stwo_verify_records", "ss_ctx_set_timing", "ss_ctx_collect_timing",
     "ss_selftest",
 ]
 
@@ -83,7 +83,7 @@ def lib() -> C.CDLL:
     sig("ss_s101_verify_records", C.c_int, vp, sp, sz, pp, vp)
     sig("ss_stwo_verify_records", C.c_int, vp, cp, sz, pp, vp, vp)
     sig("ss_ctx_set_timing", C.c_int, vp, C.c_int)
-    sig("ss_ctx_last_timing", C.c_int, vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float))
+    sig("ss_ctx_collect_timing", C.c_int, vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float))
     sig("ss_selftest", C.c_int, vp, C.c_int, sz, vp, vp)
     _lib = L
     return L

@@ -50,15 +50,19 @@ extern "C" int ss_device_count(void)
 }
 
 // ----------------------------------------------------------------------------- context
+struct TimedSpan {
+    const char *name;
+    hipEvent_t start, stop;
+};
+
 struct ss_ctx {
     int device;
     int timing;
-    static constexpr int kMaxK = 8;
-    hipEvent_t ev[kMaxK + 1];
-    bool ev_made;
-    const char *names[kMaxK];
-    int n_timed;
+    std::vector<TimedSpan> spans;   // recorded since the last collect
+    std::vector<hipEvent_t> pool;   // recycled events
 };
+
+static constexpr size_t kMaxSpans = 1 << 16;
 
 extern "C" int ss_ctx_create(int device, ss_ctx **out)
 {
@@ -75,8 +79,6 @@ extern "C" int ss_ctx_create(int device, ss_ctx **out)
     ss_ctx *c = new ss_ctx();
     c->device = device;
     c->timing = 0;
-    c->ev_made = false;
-    c->n_timed = 0;
     *out = c;
     return SS_OK;
 }
@@ -84,51 +86,69 @@ extern "C" int ss_ctx_create(int device, ss_ctx **out)
 extern "C" void ss_ctx_destroy(ss_ctx *ctx)
 {
     if (!ctx) return;
-    if (ctx->ev_made)
-        for (auto &e : ctx->ev) (void)hipEventDestroy(e);
+    for (auto &sp : ctx->spans) { (void)hipEventDestroy(sp.start); (void)hipEventDestroy(sp.stop); }
+    for (auto &e : ctx->pool) (void)hipEventDestroy(e);
     delete ctx;
 }
 
 extern "C" int ss_ctx_set_timing(ss_ctx *ctx, int enabled)
 {
     if (!ctx) return set_err(SS_ERR_ARG, "ctx is null");
-    if (enabled && !ctx->ev_made) {
-        HIP_TRY(hipSetDevice(ctx->device));
-        for (auto &e : ctx->ev) HIP_TRY(hipEventCreate(&e));
-        ctx->ev_made = true;
-    }
     ctx->timing = enabled;
-    ctx->n_timed = 0;
     return SS_OK;
 }
 
-extern "C" int ss_ctx_last_timing(ss_ctx *ctx, int cap, const char **names, float *ms)
+static hipEvent_t take_event(ss_ctx *c)
 {
-    if (!ctx || !names || !ms) return set_err(SS_ERR_ARG, "null argument");
-    if (!ctx->timing || ctx->n_timed == 0) return 0;
-    HIP_TRY(hipEventSynchronize(ctx->ev[ctx->n_timed]));
-    int k = std::min(cap, ctx->n_timed);
-    for (int i = 0; i < k; i++) {
-        names[i] = ctx->names[i];
-        HIP_TRY(hipEventElapsedTime(&ms[i], ctx->ev[i], ctx->ev[i + 1]));
+    if (!c->pool.empty()) { hipEvent_t e = c->pool.back(); c->pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+extern "C" int ss_ctx_collect_timing(ss_ctx *ctx, int cap, const char **names, float *total_ms,
+                                     uint32_t *launches)
+{
+    if (!ctx || !names || !total_ms || !launches) return set_err(SS_ERR_ARG, "null argument");
+    int k = 0;
+    for (auto &sp : ctx->spans) {
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(sp.stop));
+        HIP_TRY(hipEventElapsedTime(&ms, sp.start, sp.stop));
+        int j = 0;
+        while (j < k && names[j] != sp.name) j++;
+        if (j == k) {
+            if (k == cap) continue;
+            names[k] = sp.name; total_ms[k] = 0.f; launches[k] = 0; k++;
+        }
+        total_ms[j] += ms;
+        launches[j] += 1;
+        ctx->pool.push_back(sp.start);
+        ctx->pool.push_back(sp.stop);
     }
+    ctx->spans.clear();
     return k;
 }
 
+// Records one (start, stop) event pair around each kernel launch on the launch stream.
 struct Timer {
     ss_ctx *c;
     hipStream_t s;
-    int i = 0;
-    Timer(ss_ctx *c_, hipStream_t s_) : c(c_), s(s_)
+    hipEvent_t cur = nullptr;
+    Timer(ss_ctx *c_, hipStream_t s_) : c(c_), s(s_) {}
+    void begin()
     {
-        if (c->timing) { c->n_timed = 0; (void)hipEventRecord(c->ev[0], s); }
+        if (!c->timing || c->spans.size() >= kMaxSpans) return;
+        cur = take_event(c);
+        (void)hipEventRecord(cur, s);
     }
-    void mark(const char *name)
+    void end(const char *name)
     {
-        if (!c->timing || i >= ss_ctx::kMaxK) return;
-        c->names[i] = name;
-        (void)hipEventRecord(c->ev[i + 1], s);
-        c->n_timed = ++i;
+        if (!cur) return;
+        hipEvent_t stop = take_event(c);
+        (void)hipEventRecord(stop, s);
+        c->spans.push_back({name, cur, stop});
+        cur = nullptr;
     }
 };
 
@@ -223,16 +243,20 @@ extern "C" int ss_stwo_verify_batch_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_
     HIP_TRY(hipMemsetAsync(status, 0xff, n * 4, s));
     if (accept_count) HIP_TRY(hipMemsetAsync(accept_count, 0, 4, s));
     Timer t(ctx, s);
+    t.begin();
     hipLaunchKernelGGL(stwo_transcript_kernel, dim3((y.n + 63) / 64), dim3(64), 0, s, y, batch, ws, status);
-    t.mark("stwo_transcript");
+    t.end("stwo_transcript");
+    t.begin();
     hipLaunchKernelGGL(stwo_query_kernel, dim3((y.ni + 63) / 64), dim3(64), 0, s, y, batch, ws, status);
-    t.mark("stwo_query");
+    t.end("stwo_query");
     const uint32_t tiles = (y.K + 3) * (y.nip >> 6);
+    t.begin();
     hipLaunchKernelGGL(stwo_merkle_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, y, batch, ws, status);
-    t.mark("stwo_merkle");
+    t.end("stwo_merkle");
+    t.begin();
     hipLaunchKernelGGL(stwo_finalize_kernel, dim3((y.n + 255) / 256), dim3(256), 0, s, y.n, status,
                        shape_status, accept_count);
-    t.mark("stwo_finalize");
+    t.end("stwo_finalize");
     HIP_TRY(hipGetLastError());
     return SS_OK;
 }
@@ -301,14 +325,17 @@ extern "C" int ss_s101_verify_batch_dev(ss_ctx *ctx, const ss_s101_shape *sh, si
     HIP_TRY(hipMemsetAsync(status, 0xff, n * 4, s));
     if (accept_count) HIP_TRY(hipMemsetAsync(accept_count, 0, 4, s));
     Timer t(ctx, s);
+    t.begin();
     hipLaunchKernelGGL(s101_transcript_kernel, dim3((y.n + 63) / 64), dim3(64), 0, s, y, batch, ws, status);
-    t.mark("s101_transcript");
+    t.end("s101_transcript");
     const uint32_t tiles = y.n_types * (y.np >> 6);
+    t.begin();
     hipLaunchKernelGGL(s101_merkle_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, y, batch, ws, status);
-    t.mark("s101_merkle");
+    t.end("s101_merkle");
+    t.begin();
     hipLaunchKernelGGL(stwo_finalize_kernel, dim3((y.n + 255) / 256), dim3(256), 0, s, y.n, status,
                        (const uint32_t *)nullptr, accept_count);
-    t.mark("s101_finalize");
+    t.end("s101_finalize");
     HIP_TRY(hipGetLastError());
     return SS_OK;
 }

@@ -238,11 +238,13 @@ class Verifier:
     def set_timing(self, on: bool) -> None:
         B.check(B.lib().ss_ctx_set_timing(self.ctx, 1 if on else 0))
 
-    def last_timing(self) -> List[Tuple[str, float]]:
-        names = (C.c_char_p * 8)()
-        ms = (C.c_float * 8)()
-        k = B.check(B.lib().ss_ctx_last_timing(self.ctx, 8, names, ms))
-        return [(names[i].decode(), float(ms[i])) for i in range(k)]
+    def collect_timing(self) -> dict:
+        """{kernel name: (total_ms, launches)} since the last collect (waits for the events)."""
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        cnt = (C.c_uint32 * 16)()
+        k = B.check(B.lib().ss_ctx_collect_timing(self.ctx, 16, names, ms, cnt))
+        return {names[i].decode(): (float(ms[i]), int(cnt[i])) for i in range(k)}
 
     # -- stark101 ---------------------------------------------------------------------
     def stark101_batch(self, proofs: Sequence[Stark101Proof], replicate: int = 1) -> S101DeviceBatch:
