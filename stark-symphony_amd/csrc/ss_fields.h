@@ -103,7 +103,10 @@ __device__ __forceinline__ QM31 qm31_mul_cm31(QM31 x, CM31 y)
 __device__ inline QM31 qm31_mul(QM31 x, QM31 y)
 {
     CM31 ar = q_re(x), ai = q_im(x), br = q_re(y), bi = q_im(y);
-    CM31 re = cm31_add(cm31_mul(ar, br), cm31_mul(cm31_mul(ai, bi), CM31{2, 1}));
+    // (x + yi)(2 + i) = (2x - y) + (x + 2y)i; the product ai*bi is canonical, so adds suffice
+    CM31 t = cm31_mul(ai, bi);
+    CM31 tr = {m31_sub(m31_add(t.a, t.a), t.b), m31_add(t.a, m31_add(t.b, t.b))};
+    CM31 re = cm31_add(cm31_mul(ar, br), tr);
     CM31 im = cm31_add(cm31_mul(ar, bi), cm31_mul(ai, br));
     return q_make(re, im);
 }

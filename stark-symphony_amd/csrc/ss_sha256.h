@@ -61,13 +61,21 @@ __host__ __device__ constexpr Sha256K make_pad_wk(uint32_t bits)
 constexpr Sha256K kPad64WK = make_pad_wk(512);
 
 __device__ __forceinline__ uint32_t rotr32(uint32_t x, int n) { return __builtin_rotateright32(x, n); }
-// v_bfi_b32 forms: bfi(x, y, z) = z ^ (x & (y ^ z))
+// gfx950 has v_bitop3_b32: any 3-input bitwise function in one VALU op, selected by an 8-bit
+// truth table (table = f(0xF0, 0xCC, 0xAA)).  xor3, Ch and Maj are one instruction each.
+#ifndef SS_NO_BITOP3
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+__device__ __forceinline__ uint32_t sha_ch(uint32_t e, uint32_t f, uint32_t g) { return __builtin_amdgcn_bitop3_b32(e, f, g, 0xCA); }
+__device__ __forceinline__ uint32_t sha_maj(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8); }
+#else
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return a ^ b ^ c; }
 __device__ __forceinline__ uint32_t sha_ch(uint32_t e, uint32_t f, uint32_t g) { return g ^ (e & (f ^ g)); }
 __device__ __forceinline__ uint32_t sha_maj(uint32_t a, uint32_t b, uint32_t c) { return b ^ ((a ^ b) & (c ^ b)); }
-__device__ __forceinline__ uint32_t sha_S0(uint32_t a) { return rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22); }
-__device__ __forceinline__ uint32_t sha_S1(uint32_t e) { return rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25); }
-__device__ __forceinline__ uint32_t sha_s0(uint32_t x) { return rotr32(x, 7) ^ rotr32(x, 18) ^ (x >> 3); }
-__device__ __forceinline__ uint32_t sha_s1(uint32_t x) { return rotr32(x, 17) ^ rotr32(x, 19) ^ (x >> 10); }
+#endif
+__device__ __forceinline__ uint32_t sha_S0(uint32_t a) { return xor3(rotr32(a, 2), rotr32(a, 13), rotr32(a, 22)); }
+__device__ __forceinline__ uint32_t sha_S1(uint32_t e) { return xor3(rotr32(e, 6), rotr32(e, 11), rotr32(e, 25)); }
+__device__ __forceinline__ uint32_t sha_s0(uint32_t x) { return xor3(rotr32(x, 7), rotr32(x, 18), x >> 3); }
+__device__ __forceinline__ uint32_t sha_s1(uint32_t x) { return xor3(rotr32(x, 17), rotr32(x, 19), x >> 10); }
 
 __device__ __forceinline__ void sha_iv(uint32_t (&h)[8])
 {

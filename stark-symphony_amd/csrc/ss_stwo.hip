@@ -325,23 +325,29 @@ stwo_transcript_kernel(StwoLayout lay, const uint32_t *__restrict__ batch, uint3
 }
 
 // =============================================================================== query
-__device__ inline bool denominator_inverse(const uint32_t *ctx, uint32_t np, uint32_t p, uint32_t cw,
-                                           M31Point q, CM31 &out)
-{
-    // deep_quotient_denominator_inverse (deep/quotients.simf:15-22)
-    auto G = [&](uint32_t w) { return ctx[(size_t)(cw + w) * np + p]; };
-    CM31 prx = {G(0), G(1)}, pix = {G(2), G(3)}, pry = {G(4), G(5)}, piy = {G(6), G(7)};
-    CM31 dx = cm31_sub_m31(prx, q.x), dy = cm31_sub_m31(pry, q.y);
-    CM31 d = cm31_sub(cm31_mul(dx, piy), cm31_mul(dy, pix));
-    return cm31_inv(d, out);
-}
+// Coordinates the fold chain divides by (fri/folding.simf:15-41), without a point
+// multiplication per layer.  With position_l = (query >> l) & ~1 the reference computes
+//   layer 0:  y of circle_domain(L).at(bitrev(position_0, L))                       = y0
+//   layer l:  x of line_domain(L - l).at(bitrev(position_l, L - l))
+// and on the canonic cosets (groups/circle_domain.simf:17-25, line_domain.simf:18-31) these are
+//   x_1 = s_1 x0,   x_l = s_l pi^(l-1)(x0),   pi(x) = 2x^2 - 1,   s_l = -1 iff bit l of query
+// where (x0, y0) is the domain point of position_0: halving the position keeps the doubled
+// point (line offset/step double with it), and clearing the position's low bit moves the
+// circle index by 2^30, i.e. negates the point.  The point of the query itself is (x0, +-y0).
+// All values are canonical field elements, so this re-association is exact.  The K+1 fold
+// inverses and the (one or two) DEEP denominator norms share ONE m31 inversion (Montgomery's
+// trick); a raw zero still reports the reference's abort code for exactly that inverse.
+constexpr int kInvSlots = kMaxList + 4;
 
 __global__ void __launch_bounds__(64)
 stwo_query_kernel(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,
                   uint32_t *__restrict__ status)
 {
+    __shared__ uint32_t sh_u[kInvSlots][64];
+    __shared__ uint32_t sh_p[kInvSlots][64];
     const uint32_t inst = blockIdx.x * blockDim.x + threadIdx.x;
     if (inst >= lay.ni) return;
+    const uint32_t lane = threadIdx.x;
     const uint32_t p = inst / lay.Q, q = inst - p * lay.Q;
     const uint32_t np = lay.np, nip = lay.nip;
     const uint32_t *ctx = ws + lay.ws_ctx;
@@ -351,15 +357,56 @@ stwo_query_kernel(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *
     auto FAIL = [&](uint32_t code) { fail = code < fail ? code : fail; };
 
     const uint32_t query = CG(lay.c_queries + q);
-    const uint32_t L = lay.L;
+    const uint32_t L = lay.L, K = lay.K;
+    const bool two = lay.mode == 1;
 
-    // ---- stage VI: fri_answer at the query point (fri/answers.simf:97-130)
+    // domain point of the even member of the query's leaf pair, and of the query itself
+    const uint32_t pos0 = query & ~1u;
+    const M31Point p0 = circle_point(circle_position_to_index(L, bit_reverse_position(pos0, L)));
+    const M31Point dp = {p0.x, (query & 1) ? m31_sub(0, p0.y) : p0.y};
+
+    // deep_quotient_denominator_inverse (deep/quotients.simf:15-22): d = dx * piy - dy * pix
+    auto denominator = [&](uint32_t cw) {
+        CM31 prx = {CG(cw + 0), CG(cw + 1)}, pix = {CG(cw + 2), CG(cw + 3)};
+        CM31 pry = {CG(cw + 4), CG(cw + 5)}, piy = {CG(cw + 6), CG(cw + 7)};
+        CM31 dx = cm31_sub_m31(prx, dp.x), dy = cm31_sub_m31(pry, dp.y);
+        return cm31_sub(cm31_mul(dx, piy), cm31_mul(dy, pix));
+    };
+    const CM31 d1 = denominator(lay.c_p);
+    const CM31 d2 = two ? denominator(lay.c_p2) : CM31{1, 0};
+
+    // ---- one inversion for: y0, pi^(l-1)(x0) (l = 1..K), |d1|^2, |d2|^2
+    const uint32_t n_inv = K + 3;
+    {
+        uint32_t t = p0.x, run = 1;
+        for (uint32_t i = 0; i < n_inv; i++) {
+            uint32_t u;
+            if (i == 0) u = p0.y;
+            else if (i <= K) { u = t; t = m31_dbl_x(t); }
+            else if (i == K + 1) u = m31_add(m31_sqr(d1.a), m31_sqr(d1.b));
+            else u = m31_add(m31_sqr(d2.a), m31_sqr(d2.b));
+            if (u == 0) {  // m31_inv aborts on a zero word (fields/m31.simf:118-122)
+                FAIL(i <= K ? stwo_code(7, i, q, 2) : stwo_code(6, 0, q, i - K - 1));
+                u = 1;
+            }
+            run = m31_mul(run, u);
+            sh_u[i][lane] = u;
+            sh_p[i][lane] = run;
+        }
+        uint32_t r;
+        m31_inv(run, r);
+        for (uint32_t i = n_inv; i-- > 0;) {
+            const uint32_t before = i ? sh_p[i - 1][lane] : 1u;
+            sh_p[i][lane] = m31_mul(r, before);  // = 1 / u_i
+            r = m31_mul(r, sh_u[i][lane]);
+        }
+    }
+
+    // ---- stage VI: fri_answer at the query point (fri/answers.simf:97-130, SURVEY 0.1 D1)
     QM31 eval;
     {
-        M31Point dp = circle_point(circle_position_to_index(L, bit_reverse_position(query, L)));
-        CM31 di1, di2 = {0, 0};
-        if (!denominator_inverse(ctx, np, p, lay.c_p, dp, di1)) FAIL(stwo_code(6, 0, q, 0));
-        if (lay.mode == 1 && !denominator_inverse(ctx, np, p, lay.c_p2, dp, di2)) FAIL(stwo_code(6, 0, q, 1));
+        const CM31 di1 = cm31_mul_m31(CM31{d1.a, m31_neg(d1.b)}, sh_p[K + 1][lane]);
+        const CM31 di2 = cm31_mul_m31(CM31{d2.a, m31_neg(d2.b)}, sh_p[K + 2][lane]);
         const uint32_t *tv = batch + lay.off_trace_vals, *cv = batch + lay.off_cp_vals;
         QM31 s = qm31_zero();
         for (uint32_t k = 0; k < lay.N; k++)
@@ -367,7 +414,7 @@ stwo_query_kernel(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *
         QM31 s2 = qm31_zero();
         for (uint32_t k = 0; k < kCp; k++)
             s2 = qm31_add(s2, qm31_mul_m31(CGQ(lay.c_b + 4 * (lay.N + k)), cv[(size_t)k * nip + inst]));
-        if (lay.mode == 1) {
+        if (two) {
             QM31 n1 = qm31_sub(s, qm31_add(qm31_mul_m31(CGQ(lay.c_a1), dp.y), CGQ(lay.c_c1)));
             QM31 n2 = qm31_sub(s2, qm31_add(qm31_mul_m31(CGQ(lay.c_a2), dp.y), CGQ(lay.c_c2)));
             QM31 b1 = qm31_mul_cm31(n1, di1), b2 = qm31_mul_cm31(n2, di2);
@@ -382,8 +429,7 @@ stwo_query_kernel(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *
     uint32_t *leaf = ws + lay.ws_leaf;
     const uint32_t *wit = batch + lay.off_fri_wit;
     uint32_t cur = query;
-    for (uint32_t l = 0; l <= lay.K; l++) {
-        const uint32_t logl = L - l;
+    for (uint32_t l = 0; l <= K; l++) {
         QM31 w = {wit[((size_t)l * 4 + 0) * nip + inst], wit[((size_t)l * 4 + 1) * nip + inst],
                   wit[((size_t)l * 4 + 2) * nip + inst], wit[((size_t)l * 4 + 3) * nip + inst]};
         const bool odd = cur & 1;  // adjacent_leaves (fri/layers.simf:29-37)
@@ -393,14 +439,8 @@ stwo_query_kernel(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *
         lf[0] = e0.a; lf[(size_t)nip] = e0.b; lf[(size_t)2 * nip] = e0.c; lf[(size_t)3 * nip] = e0.d;
         lf[(size_t)4 * nip] = e1.a; lf[(size_t)5 * nip] = e1.b; lf[(size_t)6 * nip] = e1.c;
         lf[(size_t)7 * nip] = e1.d;
-        uint32_t coord;
-        if (l == 0) {
-            coord = circle_point(circle_position_to_index(logl, bit_reverse_position(position, logl))).y;
-        } else {
-            coord = circle_point(line_position_to_index(logl, bit_reverse_position(position, logl))).x;
-        }
-        uint32_t cinv;
-        if (!m31_inv(coord, cinv)) FAIL(stwo_code(7, l, q, 2));
+        uint32_t cinv = sh_p[l][lane];
+        if (l > 0 && ((query >> l) & 1)) cinv = m31_sub(0, cinv);
         QM31 f0 = qm31_add(e0, e1);
         QM31 f1 = qm31_mul_m31(qm31_sub(e0, e1), cinv);
         eval = qm31_add(f0, qm31_mul(CGQ(lay.c_fold + 4 * l), f1));
@@ -409,7 +449,7 @@ stwo_query_kernel(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *
 
     // ---- last layer (fri/verify.simf:124-128, fri/layers.simf:73-78)
     if (lay.mode == 0) {
-        if (((L - (lay.K + 1)) & 0xff) != 0) FAIL(stwo_code(8, 0, 0, 0));
+        if (((L - (K + 1)) & 0xff) != 0) FAIL(stwo_code(8, 0, 0, 0));
         if (cur != 0) FAIL(stwo_code(9, 0, q, 0));
     }
     {

@@ -1,0 +1,63 @@
+"""Multi-GPU driver: proofs are independent, so a batch shards by proof index.
+
+One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI on the GPU box,
+"gloo" in CPU tests).  Rank r verifies the contiguous slice [lo, hi) of the batch on its own
+GPU; the only exchange of the path is the final accept-reduce: one
+all-reduce(SUM) of {accepted, total} -- 8 bytes, latency bound -- and, when the caller wants
+every verdict everywhere, one all-gather of the status words.  No data-path collective.
+
+The reference has nothing to compare with here: it verifies one proof per process
+(simfony-cli/src/main.rs:163-209).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced partition of n items: the first n % world ranks get one extra."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def verify_sharded(proofs: Sequence, verify_local: Callable[[Sequence], np.ndarray],
+                   group=None, gather_status: bool = False, device=None):
+    """Verify `proofs` (the same list on every rank) with each rank doing its own slice.
+
+    verify_local(slice) -> uint32 status per proof (0 = ACCEPT); on the GPU box this is
+    `Verifier(local_rank).verify_stwo` / `.verify_stark101`.
+    Returns (local_status, accepted_total, n_total[, all_status])."""
+    import torch
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    lo, hi = shard_range(len(proofs), rank, world)
+    local = np.asarray(verify_local(proofs[lo:hi]) if hi > lo else np.zeros(0, np.uint32),
+                       dtype=np.uint32)
+    if device is None:
+        backend = dist.get_backend(group) if world > 1 else "gloo"
+        device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    counts = torch.tensor([int((local == 0).sum()), int(local.size)], dtype=torch.int64, device=device)
+    if world > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+    accepted, total = int(counts[0].item()), int(counts[1].item())
+    if not gather_status:
+        return local, accepted, total
+    if world == 1:
+        return local, accepted, total, local.copy()
+    # ranks may own slices that differ by one proof: pad to the longest
+    longest = (len(proofs) + world - 1) // world
+    mine = torch.full((longest,), 0xFFFFFFFF, dtype=torch.int64, device=device)
+    mine[:local.size] = torch.from_numpy(local.astype(np.int64)).to(device)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    out: List[np.ndarray] = []
+    for r, t in enumerate(parts):
+        a, b = shard_range(len(proofs), r, world)
+        out.append(t[:b - a].cpu().numpy().astype(np.uint32))
+    return local, accepted, total, np.concatenate(out)

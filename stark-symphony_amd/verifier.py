@@ -169,6 +169,18 @@ class _DeviceBatch:
         s = stream if stream is not None else torch.cuda.current_stream(self.ver.device)
         return int(s.cuda_stream)
 
+    def sibling(self):
+        """Another run slot over the SAME resident batch (own workspace / status / accept
+        count), so two passes can be in flight on two streams: the sequential transcript
+        kernel of one overlaps the Merkle kernel of the other."""
+        import copy
+        torch = _torch()
+        other = copy.copy(self)
+        other.ws = torch.empty_like(self.ws)
+        other.status_dev = torch.empty_like(self.status_dev)
+        other.accept_dev = torch.zeros_like(self.accept_dev)
+        return other
+
     def status(self) -> np.ndarray:
         """Synchronises, returns the per-proof status words (0 = ACCEPT)."""
         return self.status_dev.cpu().numpy().view(np.uint32).copy()

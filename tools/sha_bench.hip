@@ -1,0 +1,90 @@
+// SHA-256 calibration micro-benchmark for gfx950 (tools only; not part of the library).
+//
+// Measures the integer-ALU roof the Merkle kernels are bound by: every lane folds `iters`
+// register-resident siblings into its node (sha256_pair = 1 full + 1 constant-schedule
+// compression, exactly the inner step of stwo_merkle_kernel), with no memory traffic.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/sha_bench.hip -o /tmp/sha_bench
+//   /tmp/sha_bench [iters] [blocks_per_cu] [threads]
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../stark-symphony_amd/csrc/ss_sha256.h"
+
+using namespace ss;
+
+template <int WAVES_PER_EU>
+__global__ void __launch_bounds__(256, WAVES_PER_EU) chain_kernel(uint32_t iters, uint32_t *out)
+{
+    uint32_t node[8], sib[8];
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { node[j] = t * 0x9E3779B1u + j; sib[j] = t ^ (0x85EBCA6Bu * (j + 1)); }
+    uint32_t auth = t;
+    for (uint32_t it = 0; it < iters; it++) {
+        const bool right = auth & 1;
+        uint32_t w[16];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            w[j] = right ? sib[j] : node[j];
+            w[8 + j] = right ? node[j] : sib[j];
+        }
+        sha_iv(node);
+        sha256_compress(node, w);
+        sha256_compress_pad64(node);
+        auth = (auth >> 1) | (auth << 31);
+#pragma unroll
+        for (int j = 0; j < 8; j++) sib[j] += node[(j + 3) & 7];
+    }
+    uint32_t x = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) x ^= node[j];
+    out[t] = x;
+}
+
+template <int W>
+static void run(const char *name, uint32_t iters, int blocks_per_cu, int cus)
+{
+    const int grid = cus * blocks_per_cu;
+    uint32_t *out;
+    hipMalloc(&out, (size_t)grid * 256 * 4);
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    chain_kernel<W><<<grid, 256>>>(iters / 8 + 1, out);
+    hipDeviceSynchronize();
+    float best = 1e30f;
+    for (int r = 0; r < 5; r++) {
+        hipEventRecord(a);
+        chain_kernel<W><<<grid, 256>>>(iters, out);
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        float ms;
+        hipEventElapsedTime(&ms, a, b);
+        if (ms < best) best = ms;
+    }
+    const double pairs = (double)grid * 256 * iters;
+    printf("%-28s blocks/CU %2d  iters %5u  %8.3f ms  %7.2f G pair-hashes/s  %7.2f G compressions/s\n", name,
+           blocks_per_cu, iters, best, pairs / best / 1e6, 2 * pairs / best / 1e6);
+    hipFree(out);
+}
+
+int main(int argc, char **argv)
+{
+    uint32_t iters = argc > 1 ? atoi(argv[1]) : 512;
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    const int cus = prop.multiProcessorCount;
+    printf("%s, %d CUs, clock %d MHz\n", prop.gcnArchName, cus, prop.clockRate / 1000);
+    for (int bpc : {1, 2, 4, 8}) {
+        run<1>("launch_bounds(256,1)", iters, bpc, cus);
+    }
+    for (int bpc : {4, 8}) {
+        run<4>("launch_bounds(256,4)", iters, bpc, cus);
+        run<6>("launch_bounds(256,6)", iters, bpc, cus);
+        run<8>("launch_bounds(256,8)", iters, bpc, cus);
+    }
+    return 0;
+}
