@@ -129,21 +129,22 @@ def main() -> None:
         dominant = "s101_merkle"
     n_local = batch.n
 
-    # `--inflight` run slots over the same resident batch, one HIP stream each: the latency-
-    # bound transcript kernel of step i+1 overlaps the ALU-bound Merkle kernel of step i.
+    # `--inflight` run slots over the same resident batch, pipelined on a head and a tail stream:
+    # the latency-bound transcript kernel of step i+1 overlaps the ALU-bound Merkle kernel of
+    # step i; Merkle kernels themselves stay serialized on the tail stream.
     nslot = max(1, args.inflight)
     slots = [batch] + [batch.sibling() for _ in range(nslot - 1)]
-    streams = [torch.cuda.Stream(device=ver.device) for _ in range(nslot)]
+    pipe = verifier.Pipeline(slots)
     accs = [torch.zeros(1, dtype=torch.int32, device=ver.device) for _ in range(nslot)]
     acc = accs[0]
 
+    def reduce_accepts(k: int) -> None:
+        if world > 1:  # the path's only exchange: accept-count reduce over xGMI
+            accs[k].copy_(slots[k].accept_dev)
+            dist.all_reduce(accs[k], op=dist.ReduceOp.SUM)
+
     def step(i: int) -> None:
-        k = i % nslot
-        with torch.cuda.stream(streams[k]):
-            slots[k].run(streams[k])
-            if world > 1:  # the path's only exchange: accept-count reduce over xGMI
-                accs[k].copy_(slots[k].accept_dev)
-                dist.all_reduce(accs[k], op=dist.ReduceOp.SUM)
+        pipe.submit(reduce_accepts)
 
     for i in range(args.warmup):
         step(i)

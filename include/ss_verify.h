@@ -140,6 +140,25 @@ int ss_stwo_verify_batch_dev(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n,
                              void *workspace_dev, size_t workspace_bytes, uint32_t *status_dev,
                              uint32_t *accept_count_dev, void *stream);
 
+/* The same work in two separately enqueueable halves, for callers that pipeline batches:
+ *   SS_PHASE_HEAD  reset status, transcript kernel (Fiat-Shamir chain, latency bound) and
+ *                  query kernel  -> writes the workspace
+ *   SS_PHASE_TAIL  Merkle kernel (ALU bound) and finalize -> reads the workspace
+ * HEAD of batch i+1 on one stream overlaps TAIL of batch i on another (each batch needs its
+ * own workspace / status; order HEAD -> TAIL of one batch with an event).  SS_PHASE_ALL on one
+ * stream is exactly ss_*_verify_batch_dev.                                                 */
+#define SS_PHASE_HEAD 1
+#define SS_PHASE_TAIL 2
+#define SS_PHASE_ALL 3
+int ss_s101_verify_phase_dev(ss_ctx *ctx, const ss_s101_shape *shape, size_t n,
+                             const uint32_t *batch_dev, void *workspace_dev,
+                             size_t workspace_bytes, uint32_t *status_dev,
+                             uint32_t *accept_count_dev, int phases, void *stream);
+int ss_stwo_verify_phase_dev(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n,
+                             const uint32_t *batch_dev, const uint32_t *shape_status_dev,
+                             void *workspace_dev, size_t workspace_bytes, uint32_t *status_dev,
+                             uint32_t *accept_count_dev, int phases, void *stream);
+
 /* Host-buffer convenience: pack + H2D + verify + D2H, synchronous.  Allocates scratch
  * device memory for the call.  PCIe-inclusive; not what bench.py times.                 */
 int ss_s101_verify_records(ss_ctx *ctx, const ss_s101_shape *shape, size_t n,

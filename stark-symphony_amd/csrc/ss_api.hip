@@ -225,40 +225,54 @@ extern "C" int ss_stwo_pack(const ss_stwo_cfg *c, size_t n, const uint32_t *cons
     return SS_OK;
 }
 
-extern "C" int ss_stwo_verify_batch_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n,
+extern "C" int ss_stwo_verify_phase_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n,
                                         const uint32_t *batch, const uint32_t *shape_status,
                                         void *workspace, size_t workspace_bytes, uint32_t *status,
-                                        uint32_t *accept_count, void *stream_)
+                                        uint32_t *accept_count, int phases, void *stream_)
 {
     if (!ctx) return set_err(SS_ERR_ARG, "ctx is null");
     if (!cfg_ok(c)) return set_err(SS_ERR_ARG, "unsupported stwo config");
     if (!n || !batch || !workspace || !status) return set_err(SS_ERR_ARG, "null/empty argument");
     if (n * (size_t)c->n_queries > 0x7fffffffu) return set_err(SS_ERR_ARG, "batch too large");
+    if (!(phases & SS_PHASE_ALL)) return set_err(SS_ERR_ARG, "no phase selected");
     const StwoLayout y = lay_of(c, n);
     if (workspace_bytes < y.ws_total_words * 4)
         return set_err(SS_ERR_WORKSPACE, "workspace %zu < %llu bytes", workspace_bytes,
                        (unsigned long long)y.ws_total_words * 4);
     hipStream_t s = (hipStream_t)stream_;
     uint32_t *ws = (uint32_t *)workspace;
-    HIP_TRY(hipMemsetAsync(status, 0xff, n * 4, s));
-    if (accept_count) HIP_TRY(hipMemsetAsync(accept_count, 0, 4, s));
     Timer t(ctx, s);
-    t.begin();
-    hipLaunchKernelGGL(stwo_transcript_kernel, dim3((y.n + 63) / 64), dim3(64), 0, s, y, batch, ws, status);
-    t.end("stwo_transcript");
-    t.begin();
-    hipLaunchKernelGGL(stwo_query_kernel, dim3((y.ni + 63) / 64), dim3(64), 0, s, y, batch, ws, status);
-    t.end("stwo_query");
-    const uint32_t tiles = (y.K + 3) * (y.nip >> 6);
-    t.begin();
-    hipLaunchKernelGGL(stwo_merkle_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, y, batch, ws, status);
-    t.end("stwo_merkle");
-    t.begin();
-    hipLaunchKernelGGL(stwo_finalize_kernel, dim3((y.n + 255) / 256), dim3(256), 0, s, y.n, status,
-                       shape_status, accept_count);
-    t.end("stwo_finalize");
+    if (phases & SS_PHASE_HEAD) {
+        HIP_TRY(hipMemsetAsync(status, 0xff, n * 4, s));
+        if (accept_count) HIP_TRY(hipMemsetAsync(accept_count, 0, 4, s));
+        t.begin();
+        hipLaunchKernelGGL(stwo_transcript_kernel, dim3((y.n + 63) / 64), dim3(64), 0, s, y, batch, ws, status);
+        t.end("stwo_transcript");
+        t.begin();
+        hipLaunchKernelGGL(stwo_query_kernel, dim3((y.ni + 63) / 64), dim3(64), 0, s, y, batch, ws, status);
+        t.end("stwo_query");
+    }
+    if (phases & SS_PHASE_TAIL) {
+        const uint32_t tiles = (y.K + 3) * (y.nip >> 6);
+        t.begin();
+        hipLaunchKernelGGL(stwo_merkle_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, y, batch, ws, status);
+        t.end("stwo_merkle");
+        t.begin();
+        hipLaunchKernelGGL(stwo_finalize_kernel, dim3((y.n + 255) / 256), dim3(256), 0, s, y.n, status,
+                           shape_status, accept_count);
+        t.end("stwo_finalize");
+    }
     HIP_TRY(hipGetLastError());
     return SS_OK;
+}
+
+extern "C" int ss_stwo_verify_batch_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n,
+                                        const uint32_t *batch, const uint32_t *shape_status,
+                                        void *workspace, size_t workspace_bytes, uint32_t *status,
+                                        uint32_t *accept_count, void *stream_)
+{
+    return ss_stwo_verify_phase_dev(ctx, c, n, batch, shape_status, workspace, workspace_bytes, status,
+                                    accept_count, SS_PHASE_ALL, stream_);
 }
 
 // ============================================================================ stark101
@@ -310,34 +324,48 @@ extern "C" int ss_s101_pack(const ss_s101_shape *sh, size_t n, const uint32_t *c
     return SS_OK;
 }
 
-extern "C" int ss_s101_verify_batch_dev(ss_ctx *ctx, const ss_s101_shape *sh, size_t n,
+extern "C" int ss_s101_verify_phase_dev(ss_ctx *ctx, const ss_s101_shape *sh, size_t n,
                                         const uint32_t *batch, void *workspace, size_t workspace_bytes,
-                                        uint32_t *status, uint32_t *accept_count, void *stream_)
+                                        uint32_t *status, uint32_t *accept_count, int phases,
+                                        void *stream_)
 {
     if (!ctx) return set_err(SS_ERR_ARG, "ctx is null");
     if (!shape_ok(sh)) return set_err(SS_ERR_ARG, "unsupported stark101 shape");
     if (!n || !batch || !workspace || !status) return set_err(SS_ERR_ARG, "null/empty argument");
     if (n > 0x7fffffffu) return set_err(SS_ERR_ARG, "batch too large");
+    if (!(phases & SS_PHASE_ALL)) return set_err(SS_ERR_ARG, "no phase selected");
     const S101Layout y = s101_layout(sh->max_layers, sh->max_path, n);
     if (workspace_bytes < y.ws_total_words * 4) return set_err(SS_ERR_WORKSPACE, "workspace too small");
     hipStream_t s = (hipStream_t)stream_;
     uint32_t *ws = (uint32_t *)workspace;
-    HIP_TRY(hipMemsetAsync(status, 0xff, n * 4, s));
-    if (accept_count) HIP_TRY(hipMemsetAsync(accept_count, 0, 4, s));
     Timer t(ctx, s);
-    t.begin();
-    hipLaunchKernelGGL(s101_transcript_kernel, dim3((y.n + 63) / 64), dim3(64), 0, s, y, batch, ws, status);
-    t.end("s101_transcript");
-    const uint32_t tiles = y.n_types * (y.np >> 6);
-    t.begin();
-    hipLaunchKernelGGL(s101_merkle_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, y, batch, ws, status);
-    t.end("s101_merkle");
-    t.begin();
-    hipLaunchKernelGGL(stwo_finalize_kernel, dim3((y.n + 255) / 256), dim3(256), 0, s, y.n, status,
-                       (const uint32_t *)nullptr, accept_count);
-    t.end("s101_finalize");
+    if (phases & SS_PHASE_HEAD) {
+        HIP_TRY(hipMemsetAsync(status, 0xff, n * 4, s));
+        if (accept_count) HIP_TRY(hipMemsetAsync(accept_count, 0, 4, s));
+        t.begin();
+        hipLaunchKernelGGL(s101_transcript_kernel, dim3((y.n + 63) / 64), dim3(64), 0, s, y, batch, ws, status);
+        t.end("s101_transcript");
+    }
+    if (phases & SS_PHASE_TAIL) {
+        const uint32_t tiles = y.n_types * (y.np >> 6);
+        t.begin();
+        hipLaunchKernelGGL(s101_merkle_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, y, batch, ws, status);
+        t.end("s101_merkle");
+        t.begin();
+        hipLaunchKernelGGL(stwo_finalize_kernel, dim3((y.n + 255) / 256), dim3(256), 0, s, y.n, status,
+                           (const uint32_t *)nullptr, accept_count);
+        t.end("s101_finalize");
+    }
     HIP_TRY(hipGetLastError());
     return SS_OK;
+}
+
+extern "C" int ss_s101_verify_batch_dev(ss_ctx *ctx, const ss_s101_shape *sh, size_t n,
+                                        const uint32_t *batch, void *workspace, size_t workspace_bytes,
+                                        uint32_t *status, uint32_t *accept_count, void *stream_)
+{
+    return ss_s101_verify_phase_dev(ctx, sh, n, batch, workspace, workspace_bytes, status, accept_count,
+                                    SS_PHASE_ALL, stream_);
 }
 
 // ============================================================ host-buffer convenience paths

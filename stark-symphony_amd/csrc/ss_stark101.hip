@@ -105,31 +105,48 @@ s101_transcript_kernel(S101Layout lay, const uint32_t *__restrict__ batch, uint3
     ws[p] = idx;
 
     // :37-39  x = 5 * h^idx, composition polynomial (air.simf:58-101)
+    // Every divisor of the path is a canonical field element (an output of sub_mod / mul_mod),
+    // so div_mod aborts exactly when it is 0 and otherwise multiplies by the unique inverse
+    // (see f101_div).  The four independent divisors x-1, x-g^1022, x^1024-1 and x share ONE
+    // inversion (Montgomery's trick); the fold divisors 2*x^(2^i) are inverted as
+    // inv2 * (1/x)^(2^i), and "/2" is a multiplication by (p+1)/2.
     const uint32_t f_x = EV(0), f_gx = EV(1), f_ggx = EV(2);
     const uint32_t x = f101_mul(5u, f101_pow(1734477367u, idx));
-    uint32_t cp = 0;
+    const uint32_t d0 = f101_sub(x, 1), d1 = f101_sub(x, 2450347685u);
+    const uint32_t d2 = f101_sub(f101_pow(x, 1024), 1);
+    if (d0 == 0) FAIL(s101_code(3, 0));
+    if (d1 == 0) FAIL(s101_code(3, 1));
+    if (d2 == 0) FAIL(s101_code(3, 2));
+    const uint32_t e0 = d0 ? d0 : 1, e1 = d1 ? d1 : 1, e2 = d2 ? d2 : 1, e3 = x ? x : 1;
+    const uint32_t p01 = f101_mul(e0, e1), p012 = f101_mul(p01, e2), p0123 = f101_mul(p012, e3);
+    uint32_t r = f101_pow(p0123, S101_P - 2);
+    const uint32_t x_inv = f101_mul(r, p012);
+    r = f101_mul(r, e3);
+    const uint32_t i2 = f101_mul(r, p01);
+    r = f101_mul(r, e2);
+    const uint32_t i1 = f101_mul(r, e0), i0 = f101_mul(r, e1);
+    uint32_t cp;
     {
-        uint32_t p0 = 0, p1 = 0, p2 = 0;
-        if (!f101_div(f101_sub(f_x, 1), f101_sub(x, 1), p0)) FAIL(s101_code(3, 0));
-        if (!f101_div(f101_sub(f_x, 2338775057u), f101_sub(x, 2450347685u), p1)) FAIL(s101_code(3, 1));
+        const uint32_t p0 = f101_mul(f101_sub(f_x, 1), i0);
+        const uint32_t p1 = f101_mul(f101_sub(f_x, 2338775057u), i1);
         const uint32_t num0 = f101_sub(f_ggx, f101_add(f101_mul(f_x, f_x), f101_mul(f_gx, f_gx)));
         const uint32_t num1 = f101_mul(f101_mul(f101_sub(x, 2342081930u), f101_sub(x, 2450347685u)),
                                        f101_sub(x, 532203874u));
-        const uint32_t den = f101_sub(f101_pow(x, 1024), 1);
-        if (!f101_div(f101_mul(num0, num1), den, p2)) FAIL(s101_code(3, 2));
+        const uint32_t p2 = f101_mul(f101_mul(num0, num1), i2);
         cp = f101_add(f101_add(f101_mul(p0, a0), f101_mul(p1, a1)), f101_mul(p2, a2));
     }
     // :41  fri_verify_32 without the Merkle checks (fri.simf:58-62,74-91)
-    uint32_t xx = x, cur = cp;
+    constexpr uint32_t kInv2 = (S101_P + 1) / 2;
+    uint32_t xx = x, xx_inv = x_inv, cur = cp;
     for (uint32_t i = 0; i < nl; i++) {
         const uint32_t cpa = EV(3 + 2 * i), cpb = EV(4 + 2 * i), beta = H(lay.h_layer + 9 * i + 8);
         if (cur != cpa) FAIL(s101_code(4, 4 * i + 0));
-        uint32_t op0 = 0, op1 = 0;
-        bool ok = f101_div(f101_add(cpa, cpb), 2, op0);
-        ok = f101_div(f101_sub(cpa, cpb), f101_mul(xx, 2), op1) && ok;
-        if (!ok) FAIL(s101_code(4, 4 * i + 3));
+        if (f101_mul(xx, 2) == 0) FAIL(s101_code(4, 4 * i + 3));
+        const uint32_t op0 = f101_mul(f101_add(cpa, cpb), kInv2);
+        const uint32_t op1 = f101_mul(f101_sub(cpa, cpb), f101_mul(kInv2, xx_inv));
         cur = f101_add(op0, f101_mul(op1, beta));
         xx = f101_mul(xx, xx);
+        xx_inv = f101_mul(xx_inv, xx_inv);
     }
     if (cur != last) FAIL(s101_code(5, 0));
     if (fail != 0xffffffffu) atomicMin(&status[p], fail);

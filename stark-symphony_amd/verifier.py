@@ -17,6 +17,49 @@ from . import binding as B
 from .formats import Stark101Proof, StwoConfig, StwoProof
 
 MODE_LITERAL, MODE_FIXTURE = B.MODE_LITERAL, B.MODE_FIXTURE
+PHASE_HEAD, PHASE_TAIL, PHASE_ALL = 1, 2, 3
+
+
+class Pipeline:
+    """Keeps `depth` passes over resident batches in flight on two HIP streams: the HEAD half
+    (transcript + query kernels, latency bound) of pass i+1 runs on the head stream while the
+    TAIL half (Merkle kernel, ALU bound) of pass i runs on the tail stream.  Merkle kernels
+    never overlap each other, so their event-measured durations stay meaningful."""
+
+    def __init__(self, slots: Sequence["_DeviceBatch"]):
+        torch = _torch()
+        self.slots = list(slots)
+        dev = self.slots[0].ver.device
+        self.head_stream = torch.cuda.Stream(device=dev)
+        self.tail_stream = torch.cuda.Stream(device=dev)
+        self.head_done = [torch.cuda.Event() for _ in self.slots]
+        self.tail_done = [None for _ in self.slots]
+        self.i = 0
+
+    def submit(self, after_tail=None) -> int:
+        """Enqueue one pass; returns the slot it used.  `after_tail(slot)` is called with the
+        tail stream current (e.g. to all-reduce the accept count)."""
+        torch = _torch()
+        k = self.i % len(self.slots)
+        self.i += 1
+        slot = self.slots[k]
+        if self.tail_done[k] is not None:  # the slot's workspace is free again
+            self.head_stream.wait_event(self.tail_done[k])
+        slot.run(self.head_stream, PHASE_HEAD)
+        self.head_done[k].record(self.head_stream)
+        self.tail_stream.wait_event(self.head_done[k])
+        slot.run(self.tail_stream, PHASE_TAIL)
+        if after_tail is not None:
+            with torch.cuda.stream(self.tail_stream):
+                after_tail(k)
+        ev = torch.cuda.Event()
+        ev.record(self.tail_stream)
+        self.tail_done[k] = ev
+        return k
+
+    def synchronize(self) -> None:
+        self.head_stream.synchronize()
+        self.tail_stream.synchronize()
 
 
 # ----------------------------------------------------------------------------- records
@@ -199,13 +242,14 @@ class StwoDeviceBatch(_DeviceBatch):
         super().__init__(ver, len(records), host, L.ss_stwo_workspace_bytes(C.byref(self.cs), len(records)),
                          shape_status)
 
-    def run(self, stream=None) -> None:
-        """Asynchronous: enqueue the verification of the whole batch on `stream`."""
-        B.check(B.lib().ss_stwo_verify_batch_dev(
+    def run(self, stream=None, phases: int = PHASE_ALL) -> None:
+        """Asynchronous: enqueue the verification of the whole batch (or one half of it, see
+        SS_PHASE_* in include/ss_verify.h) on `stream`."""
+        B.check(B.lib().ss_stwo_verify_phase_dev(
             self.ver.ctx, C.byref(self.cs), self.n, self.batch.data_ptr(),
             self.shape_dev.data_ptr() if self.shape_dev is not None else None,
             self.ws.data_ptr(), self.ws.numel() * 4, self.status_dev.data_ptr(),
-            self.accept_dev.data_ptr(), self._stream(stream)))
+            self.accept_dev.data_ptr(), phases, self._stream(stream)))
 
 
 class S101DeviceBatch(_DeviceBatch):
@@ -216,11 +260,11 @@ class S101DeviceBatch(_DeviceBatch):
         super().__init__(ver, len(records), host, L.ss_s101_workspace_bytes(C.byref(self.sh), len(records)),
                          None)
 
-    def run(self, stream=None) -> None:
-        B.check(B.lib().ss_s101_verify_batch_dev(
+    def run(self, stream=None, phases: int = PHASE_ALL) -> None:
+        B.check(B.lib().ss_s101_verify_phase_dev(
             self.ver.ctx, C.byref(self.sh), self.n, self.batch.data_ptr(), self.ws.data_ptr(),
             self.ws.numel() * 4, self.status_dev.data_ptr(), self.accept_dev.data_ptr(),
-            self._stream(stream)))
+            phases, self._stream(stream)))
 
 
 class Verifier:

@@ -221,3 +221,47 @@ def test_stwo_batch_replicated(ver, stwo_prod):
     b = ver.stwo_batch([distinct[i] for i in idx])
     b.run()
     assert b.accepted() == sum(1 for i in idx if want_d[i] == 0)
+
+
+# ------------------------------------------------- BASELINE.json configs 3-5 (prover-made proofs)
+def _load_npz(name):
+    import os
+    from stark_symphony_amd import records
+    from conftest import GOLDEN
+    path = os.path.join(GOLDEN, name)
+    if not os.path.exists(path):
+        pytest.skip("%s not generated" % name)
+    return records.load_stwo_npz(path)
+
+
+@pytest.mark.parametrize("name", ["stwo_trace16.npz", "stwo_wide256.npz", "stwo_trace20.npz"])
+def test_stwo_baseline_configs(ver, name):
+    """configs[2] (2^16 trace, 32 queries), configs[4] (256 columns, LDE 2^18) and configs[3]
+    (2^20 trace): valid proofs accept, seeded corruptions match the oracle word for word."""
+    proofs = _load_npz(name)
+    rng = np.random.default_rng(SEED + 11)
+    batch = list(proofs)
+    for _ in range(40):
+        batch.append(formats.stwo_corrupt(proofs[0], rng)[0])
+    got = ver.verify_stwo(batch)
+    want = O.stwo_verify_batch(batch)
+    assert got.tolist() == want.tolist()
+    assert (want[:len(proofs)] == 0).all() and (want[len(proofs):] != 0).any()
+    lit = ver.verify_stwo(batch[:4], verifier.MODE_LITERAL)
+    assert lit.tolist() == O.stwo_verify_batch(batch[:4], O.MODE_LITERAL).tolist()
+
+
+def test_pipeline_matches_single_stream(ver, stwo_prod):
+    """HEAD/TAIL halves on two streams with two slots give the same verdicts."""
+    rng = np.random.default_rng(SEED + 12)
+    distinct = [stwo_prod] + [formats.stwo_corrupt(stwo_prod, rng)[0] for _ in range(7)]
+    batch = [distinct[i % 8] for i in range(256)]
+    ref = ver.verify_stwo(batch)
+    a = ver.stwo_batch(batch)
+    pipe = verifier.Pipeline([a, a.sibling()])
+    used = [pipe.submit() for _ in range(5)]
+    pipe.synchronize()
+    assert used == [0, 1, 0, 1, 0]
+    for slot in pipe.slots:
+        assert slot.status().tolist() == ref.tolist()
+        assert slot.accepted() == int((ref == 0).sum())

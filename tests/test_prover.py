@@ -50,3 +50,21 @@ def test_records_roundtrip(stwo_prod, tmp_path):
     records.save_stwo_npz(path, [stwo_prod, stwo_prod])
     back = records.load_stwo_npz(path)
     assert len(back) == 2 and ss.stwo_to_json(back[1]) == ss.stwo_to_json(stwo_prod)
+
+
+@pytest.mark.parametrize("name,cfg", [
+    ("stwo_trace16.npz", ss.StwoConfig(4, 16, 20, 32, 15, 5)),
+    ("stwo_wide256.npz", ss.StwoConfig(256, 14, 18, 16, 13, 5)),
+    ("stwo_trace20.npz", ss.StwoConfig(4, 20, 24, 16, 19, 5)),
+])
+def test_committed_baseline_fixtures(name, cfg):
+    """The proofs bench.py / the GPU tests use for BASELINE.json configs 3-5 (made by
+    tools/stwo_prover.py) are accepted by the oracle and have the documented shape."""
+    from stark_symphony_amd import records
+    path = os.path.join(GOLDEN, name)
+    if not os.path.exists(path):
+        pytest.skip("%s not generated" % name)
+    proofs = records.load_stwo_npz(path)
+    for p in proofs:
+        assert p.cfg == cfg
+        assert O.stwo_verify(p, O.MODE_FIXTURE) == 0
