@@ -32,9 +32,10 @@ sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E spec peak
-# integer VALU peak: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz lane-ops/s (same issue rate as the
-# 157.3 TFLOP/s fp32 vector peak counted as 1 op, MI355X_MICROARCH.md chip table)
-VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9
+# The roof that actually binds: SHA-256 compressions/s of a register-only pair-hash chain on
+# the whole chip (tools/sha_bench.hip, measured on MI355X: 34.7 G/s; rotates are half-rate
+# v_alignbit_b32, see tools/valu_bench.hip and DESIGN.md section 5).
+SHA_CALIBRATED_PEAK = 34.7e9
 
 
 def load_workload(name: str):
@@ -55,6 +56,21 @@ def load_workload(name: str):
         p = ss.stark101_from_json(json.load(open(os.path.join(GOLDEN, "stark101_proof.json"))))
         return name, "stark101", [p], "reference stark101 proof replicated (only one valid proof exists)"
     raise SystemExit("unknown workload %r" % name)
+
+
+def pmc_traffic(wname: str, n_local: int):
+    """HBM bytes per launch of the dominant kernel from the PMC counters.  Counters cannot be
+    read from inside this process: they come from the separate rocprofv3 `--pmc FETCH_SIZE` /
+    `--pmc WRITE_SIZE` passes over this same command, summarised (with the guide's gfx950
+    correction) in profiles/r01_hbm_traffic.json.  Traffic is linear in the proofs per launch."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    try:
+        d = json.load(open(path))
+    except OSError:
+        return None
+    if d.get("workload") != wname:
+        return None
+    return d["hbm_bytes_per_proof"] * n_local
 
 
 def cpu_baseline(family, proofs, seconds: float):
@@ -87,13 +103,13 @@ def cpu_baseline(family, proofs, seconds: float):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--workload", default="auto")
     ap.add_argument("--proofs-per-gpu", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=3,
                     help="batch passes in flight (one HIP stream each)")
     args = ap.parse_args()
 
@@ -198,13 +214,16 @@ def main() -> None:
             "hbm_gb_s": value * bytes_per_proof / 1e9,
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None,
+                         "traffic": pmc_traffic(wname, n_local),
                          "kernel_avg_ms": k_avg_s * 1e3, "kernel_launches": k_n,
                          "algorithmic_bytes_per_launch": launch_bytes,
                          "note": "integer-ALU bound by construction (2 SHA-256 compressions per "
                                  "32-byte sibling); see alu_roofline"},
             "alu_roofline": {"sha256_compressions_per_s": compr_s,
-                             "valu_peak_lane_ops_per_s": VALU_PEAK_LANE_OPS},
+                             "calibrated_peak_compressions_per_s": SHA_CALIBRATED_PEAK,
+                             "frac": compr_s / SHA_CALIBRATED_PEAK,
+                             "note": "peak = tools/sha_bench.hip (registers only) on MI355X, "
+                                     "profiles/r01_sha_calibration.txt"},
             "kernels_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in timing.items()},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -30,7 +30,9 @@ class Pipeline:
         torch = _torch()
         self.slots = list(slots)
         dev = self.slots[0].ver.device
-        self.head_stream = torch.cuda.Stream(device=dev)
+        # one head stream per slot: HEAD halves are latency bound (a few waves per CU), so
+        # several of them also overlap each other; TAIL halves share one stream.
+        self.head_streams = [torch.cuda.Stream(device=dev) for _ in self.slots]
         self.tail_stream = torch.cuda.Stream(device=dev)
         self.head_done = [torch.cuda.Event() for _ in self.slots]
         self.tail_done = [None for _ in self.slots]
@@ -42,11 +44,11 @@ class Pipeline:
         torch = _torch()
         k = self.i % len(self.slots)
         self.i += 1
-        slot = self.slots[k]
+        slot, hs = self.slots[k], self.head_streams[k]
         if self.tail_done[k] is not None:  # the slot's workspace is free again
-            self.head_stream.wait_event(self.tail_done[k])
-        slot.run(self.head_stream, PHASE_HEAD)
-        self.head_done[k].record(self.head_stream)
+            hs.wait_event(self.tail_done[k])
+        slot.run(hs, PHASE_HEAD)
+        self.head_done[k].record(hs)
         self.tail_stream.wait_event(self.head_done[k])
         slot.run(self.tail_stream, PHASE_TAIL)
         if after_tail is not None:
@@ -58,7 +60,8 @@ class Pipeline:
         return k
 
     def synchronize(self) -> None:
-        self.head_stream.synchronize()
+        for s in self.head_streams:
+            s.synchronize()
         self.tail_stream.synchronize()
 
 
