@@ -15,6 +15,8 @@ Workloads (`--workload`):
                  quoted on.  Proofs: tests/golden/stwo_trace20.npz (made by tools/stwo_prover.py).
   stwo_fixture   the reference's own proof (tests/golden/stwo_proof.json: trace 2^9, LDE 2^13,
                  16 queries) replicated -- used when the 2^20 fixture is absent.
+  stwo_2p16      BASELINE.json configs[2]: 2^16 trace, 32 queries.
+  stwo_wide256   BASELINE.json configs[4]: 256 columns, LDE 2^18.
   stark101       BASELINE.json configs[1]: the stark101 proof x 4096.
 """
 from __future__ import annotations
@@ -49,6 +51,13 @@ def load_workload(name: str):
         from stark_symphony_amd import records
         proofs = records.load_stwo_npz(big)
         return name, "stwo", proofs, "wide-Fibonacci 2^20 x 4, LDE 2^24, Q=16, K=19, SHA-256"
+    if name in ("stwo_2p16", "stwo_wide256"):
+        from stark_symphony_amd import records
+        fn = {"stwo_2p16": "stwo_trace16.npz", "stwo_wide256": "stwo_wide256.npz"}[name]
+        proofs = records.load_stwo_npz(os.path.join(GOLDEN, fn))
+        c = proofs[0].cfg
+        return name, "stwo", proofs, "wide-Fibonacci 2^%d x %d, LDE 2^%d, Q=%d, K=%d, SHA-256" % (
+            c.trace_log, c.n_cols, c.lde_log, c.n_queries, c.n_layers)
     if name == "stwo_fixture":
         p = ss.stwo_from_json(json.load(open(os.path.join(GOLDEN, "stwo_proof.json"))))
         return name, "stwo", [p], "reference proof.json (trace 2^9, LDE 2^13, Q=16, K=8) replicated"
@@ -160,7 +169,7 @@ def main() -> None:
             dist.all_reduce(accs[k], op=dist.ReduceOp.SUM)
 
     def step(i: int) -> None:
-        pipe.submit(reduce_accepts)
+        pipe.submit(reduce_accepts if world > 1 else None)
 
     for i in range(args.warmup):
         step(i)

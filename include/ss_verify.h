@@ -126,6 +126,13 @@ typedef struct ss_ctx ss_ctx;
 int ss_ctx_create(int device, ss_ctx **out);
 void ss_ctx_destroy(ss_ctx *ctx);
 
+/* Same permutation as ss_stwo_pack, done by the GPU: records_dev holds the n records back to
+ * back (n * ss_stwo_record_words words, device memory), batch_dev receives
+ * ss_stwo_batch_words words.  Asynchronous on `stream`.  This is what the host-buffer entry
+ * point uses after uploading the raw records, so the host never re-tiles 170 KB proofs.    */
+int ss_stwo_pack_dev(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const uint32_t *records_dev,
+                     uint32_t *batch_dev, void *stream);
+
 /* Device-resident entry points: every pointer is device memory on ctx's GPU, `stream` is a
  * hipStream_t (NULL = default stream).  Asynchronous; status_dev is valid once the stream
  * has drained.  shape_status_dev may be NULL.  accept_count_dev (may be NULL) receives the

@@ -39,7 +39,7 @@ EXPORTS = [
     "ss_s101_record_words", "ss_s101_batch_words", "ss_s101_workspace_bytes", "ss_s101_pack",
     "ss_stwo_record_words", "ss_stwo_batch_words", "ss_stwo_workspace_bytes", "ss_stwo_pack",
     "ss_ctx_create", "ss_ctx_destroy", "ss_s101_verify_batch_dev", "ss_stwo_verify_batch_dev",
-    "ss_s101_verify_phase_dev", "ss_stwo_verify_phase_dev",
+    "ss_s101_verify_phase_dev", "ss_stwo_verify_phase_dev", "ss_stwo_pack_dev",
     "ss_s101_verify_records", "ss_stwo_verify_records", "ss_ctx_set_timing", "ss_ctx_collect_timing",
     "ss_selftest",
 ]
@@ -83,6 +83,7 @@ def lib() -> C.CDLL:
     sig("ss_stwo_verify_batch_dev", C.c_int, vp, cp, sz, vp, vp, vp, sz, vp, vp, vp)
     sig("ss_s101_verify_phase_dev", C.c_int, vp, sp, sz, vp, vp, sz, vp, vp, C.c_int, vp)
     sig("ss_stwo_verify_phase_dev", C.c_int, vp, cp, sz, vp, vp, vp, sz, vp, vp, C.c_int, vp)
+    sig("ss_stwo_pack_dev", C.c_int, vp, cp, sz, vp, vp, vp)
     sig("ss_s101_verify_records", C.c_int, vp, sp, sz, pp, vp)
     sig("ss_stwo_verify_records", C.c_int, vp, cp, sz, pp, vp, vp)
     sig("ss_ctx_set_timing", C.c_int, vp, C.c_int)

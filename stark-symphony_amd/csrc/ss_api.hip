@@ -55,11 +55,24 @@ struct TimedSpan {
     hipEvent_t start, stop;
 };
 
+// Grow-only scratch of the host-buffer entry points (ss_*_verify_records): pinned staging for
+// the chunked upload and the device buffers, so repeated calls do not pay hipMalloc /
+// hipHostMalloc again.
+struct HostPath {
+    void *pinned[2] = {nullptr, nullptr};
+    size_t pinned_bytes = 0;
+    hipEvent_t pinned_free[2] = {nullptr, nullptr};
+    void *dev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // records, batch, ws, status, shape
+    size_t dev_bytes[5] = {0, 0, 0, 0, 0};
+    hipStream_t stream = nullptr;
+};
+
 struct ss_ctx {
     int device;
     int timing;
     std::vector<TimedSpan> spans;   // recorded since the last collect
     std::vector<hipEvent_t> pool;   // recycled events
+    HostPath hp;
 };
 
 static constexpr size_t kMaxSpans = 1 << 16;
@@ -88,6 +101,13 @@ extern "C" void ss_ctx_destroy(ss_ctx *ctx)
     if (!ctx) return;
     for (auto &sp : ctx->spans) { (void)hipEventDestroy(sp.start); (void)hipEventDestroy(sp.stop); }
     for (auto &e : ctx->pool) (void)hipEventDestroy(e);
+    for (int i = 0; i < 2; i++) {
+        if (ctx->hp.pinned[i]) (void)hipHostFree(ctx->hp.pinned[i]);
+        if (ctx->hp.pinned_free[i]) (void)hipEventDestroy(ctx->hp.pinned_free[i]);
+    }
+    for (auto &d : ctx->hp.dev)
+        if (d) (void)hipFree(d);
+    if (ctx->hp.stream) (void)hipStreamDestroy(ctx->hp.stream);
     delete ctx;
 }
 
@@ -374,32 +394,197 @@ struct DevBuf {
     ~DevBuf() { if (p) (void)hipFree(p); }
 };
 
+// ------------------------------------------------------------- device-side packing (stwo)
+// records_dev holds n natural-order records back to back; every word of the batch is written
+// (padding instances get zeros), destination-major so the stores are contiguous.
+namespace ss {
+
+struct StwoRecordMap {
+    uint64_t W;        // record words
+    uint32_t qstride;  // words per query in the decommitment section
+    uint32_t fbase;    // first word of the FRI section
+    uint32_t foff[kMaxList + 1];  // FRI layer l starts at fbase + foff[l]
+};
+
+__device__ __forceinline__ uint32_t rec_word(const uint32_t *rec, const StwoRecordMap &m, uint32_t p,
+                                             uint32_t off)
+{
+    return rec[(uint64_t)p * m.W + off];
+}
+
+// head[w][proof], trace_vals[k][inst], cp_vals[k][inst], fri_wit[l][w][inst]: one word per thread
+__global__ void stwo_pack_words_kernel(StwoLayout y, StwoRecordMap m, const uint32_t *__restrict__ rec,
+                                       uint32_t *__restrict__ out)
+{
+    const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= y.off_trace_path) return;
+    uint32_t v = 0;
+    if (d < y.off_trace_vals) {
+        const uint32_t w = (uint32_t)(d / y.np), p = (uint32_t)(d - (uint64_t)w * y.np);
+        if (p < y.n) v = rec_word(rec, m, p, w);
+    } else {
+        uint64_t e;
+        uint32_t row, off0;
+        if (d < y.off_cp_vals) { e = d - y.off_trace_vals; row = (uint32_t)(e / y.nip); off0 = row; }
+        else if (d < y.off_fri_wit) { e = d - y.off_cp_vals; row = (uint32_t)(e / y.nip); off0 = y.N + row; }
+        else { e = d - y.off_fri_wit; row = (uint32_t)(e / y.nip); off0 = 0; }
+        const uint32_t inst = (uint32_t)(e - (uint64_t)row * y.nip);
+        if (inst < y.ni) {
+            const uint32_t p = inst / y.Q, q = inst - p * y.Q;
+            if (d < y.off_fri_wit) {
+                v = rec_word(rec, m, p, y.head_words + q * m.qstride + off0);
+            } else {
+                const uint32_t l = row >> 2, w = row & 3, len = y.L - 1 - l;
+                v = rec_word(rec, m, p, m.fbase + m.foff[l] + q * (4 + 8 * len) + w);
+            }
+        }
+    }
+    out[d] = v;
+}
+
+// Merkle path tiles: one 16-byte unit (level, half, lane) per thread
+__global__ void stwo_pack_paths_kernel(StwoLayout y, StwoRecordMap m, const uint32_t *__restrict__ rec,
+                                       uint32_t *__restrict__ out)
+{
+    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // uint4 index in the path area
+    const uint64_t first = y.off_trace_path >> 2, total = (y.total_words >> 2) - first;
+    if (u >= total) return;
+    const uint64_t d = (first + u) << 2;  // word offset
+    // which section
+    uint64_t base;
+    uint32_t len, src0, per_q;  // src0: record offset of level 0 word 0 for query 0
+    if (d < y.off_cp_path) { base = y.off_trace_path; len = y.L; src0 = y.head_words + y.N + kCp; per_q = m.qstride; }
+    else if (d < y.off_fri_path[0]) { base = y.off_cp_path; len = y.L; src0 = y.head_words + y.N + kCp + 8 * y.L; per_q = m.qstride; }
+    else {
+        uint32_t l = 0;
+        while (l < y.K && d >= y.off_fri_path[l + 1]) l++;
+        base = y.off_fri_path[l];
+        len = y.L - 1 - l;
+        src0 = m.fbase + m.foff[l] + 4;
+        per_q = 4 + 8 * len;
+    }
+    const uint64_t r = (d - base) >> 2;           // uint4 units inside the section
+    const uint32_t lane = (uint32_t)(r & 63);
+    const uint64_t r2 = r >> 6;
+    const uint32_t half = (uint32_t)(r2 & 1);
+    const uint64_t r3 = r2 >> 1;                   // g * len + level
+    const uint32_t g = (uint32_t)(r3 / len), level = (uint32_t)(r3 - (uint64_t)g * len);
+    const uint32_t inst = g * 64 + lane;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (inst < y.ni) {
+        const uint32_t p = inst / y.Q, q = inst - p * y.Q;
+        const uint32_t *s = rec + (uint64_t)p * m.W + src0 + q * per_q + level * 8 + half * 4;
+        v = make_uint4(s[0], s[1], s[2], s[3]);
+    }
+    reinterpret_cast<uint4 *>(out)[first + u] = v;
+}
+
+}  // namespace ss
+
+static StwoRecordMap record_map(const StwoLayout &y)
+{
+    StwoRecordMap m{};
+    m.W = stwo_record_words(y.N, y.L, y.Q, y.K);
+    m.qstride = y.N + kCp + 16 * y.L;
+    m.fbase = y.head_words + y.Q * m.qstride;
+    uint32_t o = 0;
+    for (uint32_t l = 0; l <= y.K; l++) {
+        m.foff[l] = o;
+        o += y.Q * (4 + 8 * (y.L - 1 - l));
+    }
+    return m;
+}
+
+extern "C" int ss_stwo_pack_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const uint32_t *records_dev,
+                                uint32_t *batch_dev, void *stream_)
+{
+    if (!ctx) return set_err(SS_ERR_ARG, "ctx is null");
+    if (!cfg_ok(c)) return set_err(SS_ERR_ARG, "unsupported stwo config");
+    if (!n || !records_dev || !batch_dev) return set_err(SS_ERR_ARG, "null/empty argument");
+    if (n * (size_t)c->n_queries > 0x7fffffffu) return set_err(SS_ERR_ARG, "batch too large");
+    const StwoLayout y = lay_of(c, n);
+    const StwoRecordMap m = record_map(y);
+    hipStream_t s = (hipStream_t)stream_;
+    Timer t(ctx, s);
+    t.begin();
+    hipLaunchKernelGGL(stwo_pack_words_kernel, dim3((unsigned)((y.off_trace_path + 255) / 256)), dim3(256), 0,
+                       s, y, m, records_dev, batch_dev);
+    const uint64_t units = (y.total_words - y.off_trace_path) >> 2;
+    hipLaunchKernelGGL(stwo_pack_paths_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, s, y, m,
+                       records_dev, batch_dev);
+    t.end("stwo_pack");
+    HIP_TRY(hipGetLastError());
+    return SS_OK;
+}
+
+static int hp_reserve(ss_ctx *ctx, int slot, size_t bytes)
+{
+    HostPath &hp = ctx->hp;
+    if (hp.dev_bytes[slot] >= bytes) return SS_OK;
+    if (hp.dev[slot]) { HIP_TRY(hipFree(hp.dev[slot])); hp.dev[slot] = nullptr; hp.dev_bytes[slot] = 0; }
+    HIP_TRY(hipMalloc(&hp.dev[slot], bytes));
+    hp.dev_bytes[slot] = bytes;
+    return SS_OK;
+}
+
+static int hp_pinned(ss_ctx *ctx, size_t bytes)
+{
+    HostPath &hp = ctx->hp;
+    if (!hp.stream) HIP_TRY(hipStreamCreateWithFlags(&hp.stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++)
+        if (!hp.pinned_free[i]) HIP_TRY(hipEventCreateWithFlags(&hp.pinned_free[i], hipEventDisableTiming));
+    if (hp.pinned_bytes >= bytes) return SS_OK;
+    for (int i = 0; i < 2; i++) {
+        if (hp.pinned[i]) { HIP_TRY(hipHostFree(hp.pinned[i])); hp.pinned[i] = nullptr; }
+        HIP_TRY(hipHostMalloc(&hp.pinned[i], bytes, hipHostMallocDefault));
+    }
+    hp.pinned_bytes = bytes;
+    return SS_OK;
+}
+
+// Host records -> verdicts: records are gathered into pinned staging in chunks (host threads),
+// uploaded asynchronously (two buffers in flight), re-tiled ON THE GPU (ss_stwo_pack_dev) and
+// verified.  PCIe-bound.
 extern "C" int ss_stwo_verify_records(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n,
                                       const uint32_t *const *records, const uint32_t *shape_status_host,
                                       uint32_t *status_host)
 {
-    if (!ctx || !status_host) return set_err(SS_ERR_ARG, "null argument");
+    if (!ctx || !status_host || !records) return set_err(SS_ERR_ARG, "null argument");
     if (!cfg_ok(c)) return set_err(SS_ERR_ARG, "unsupported stwo config");
     if (!n) return set_err(SS_ERR_ARG, "empty batch");
+    if (n * (size_t)c->n_queries > 0x7fffffffu) return set_err(SS_ERR_ARG, "batch too large");
     HIP_TRY(hipSetDevice(ctx->device));
-    const size_t words = ss_stwo_batch_words(c, n), wsb = ss_stwo_workspace_bytes(c, n);
-    std::vector<uint32_t> host(words);
-    int rc = ss_stwo_pack(c, n, records, host.data());
-    if (rc) return rc;
-    DevBuf b, w, st, sh;
-    HIP_TRY(hipMalloc(&b.p, words * 4));
-    HIP_TRY(hipMalloc(&w.p, wsb));
-    HIP_TRY(hipMalloc(&st.p, n * 4));
-    HIP_TRY(hipMemcpy(b.p, host.data(), words * 4, hipMemcpyHostToDevice));
-    if (shape_status_host) {
-        HIP_TRY(hipMalloc(&sh.p, n * 4));
-        HIP_TRY(hipMemcpy(sh.p, shape_status_host, n * 4, hipMemcpyHostToDevice));
+    const size_t W = ss_stwo_record_words(c), words = ss_stwo_batch_words(c, n);
+    const size_t wsb = ss_stwo_workspace_bytes(c, n);
+    int rc;
+    if ((rc = hp_reserve(ctx, 0, n * W * 4))) return rc;
+    if ((rc = hp_reserve(ctx, 1, words * 4))) return rc;
+    if ((rc = hp_reserve(ctx, 2, wsb))) return rc;
+    if ((rc = hp_reserve(ctx, 3, n * 4))) return rc;
+    if (shape_status_host && (rc = hp_reserve(ctx, 4, n * 4))) return rc;
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, (64u << 20) / (W * 4)));
+    if ((rc = hp_pinned(ctx, chunk * W * 4))) return rc;
+    HostPath &hp = ctx->hp;
+    hipStream_t s = hp.stream;
+    uint32_t *rec_dev = (uint32_t *)hp.dev[0];
+    int buf = 0;
+    for (size_t lo = 0; lo < n; lo += chunk, buf ^= 1) {
+        const size_t cnt = std::min(chunk, n - lo);
+        HIP_TRY(hipEventSynchronize(hp.pinned_free[buf]));  // previous upload from this buffer done
+        uint32_t *stage = (uint32_t *)hp.pinned[buf];
+        parallel_for(cnt, [&](size_t i) { memcpy(stage + i * W, records[lo + i], W * 4); });
+        HIP_TRY(hipMemcpyAsync(rec_dev + lo * W, stage, cnt * W * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipEventRecord(hp.pinned_free[buf], s));
     }
-    rc = ss_stwo_verify_batch_dev(ctx, c, n, (const uint32_t *)b.p, (const uint32_t *)sh.p, w.p, wsb,
-                                  (uint32_t *)st.p, nullptr, nullptr);
+    if (shape_status_host)
+        HIP_TRY(hipMemcpyAsync(hp.dev[4], shape_status_host, n * 4, hipMemcpyHostToDevice, s));
+    if ((rc = ss_stwo_pack_dev(ctx, c, n, rec_dev, (uint32_t *)hp.dev[1], s))) return rc;
+    rc = ss_stwo_verify_batch_dev(ctx, c, n, (const uint32_t *)hp.dev[1],
+                                  shape_status_host ? (const uint32_t *)hp.dev[4] : nullptr, hp.dev[2], wsb,
+                                  (uint32_t *)hp.dev[3], nullptr, s);
     if (rc) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(status_host, st.p, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(status_host, hp.dev[3], n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     return SS_OK;
 }
 

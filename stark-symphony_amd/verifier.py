@@ -34,13 +34,15 @@ class Pipeline:
         # several of them also overlap each other; TAIL halves share one stream.
         self.head_streams = [torch.cuda.Stream(device=dev) for _ in self.slots]
         self.tail_stream = torch.cuda.Stream(device=dev)
+        self.comm_stream = torch.cuda.Stream(device=dev)  # accept-reduce, off the kernels' path
         self.head_done = [torch.cuda.Event() for _ in self.slots]
         self.tail_done = [None for _ in self.slots]
         self.i = 0
 
     def submit(self, after_tail=None) -> int:
         """Enqueue one pass; returns the slot it used.  `after_tail(slot)` is called with the
-        tail stream current (e.g. to all-reduce the accept count)."""
+        communication stream current, ordered after the pass (e.g. to all-reduce its accept
+        count); the slot is not reused before it has completed."""
         torch = _torch()
         k = self.i % len(self.slots)
         self.i += 1
@@ -51,11 +53,16 @@ class Pipeline:
         self.head_done[k].record(hs)
         self.tail_stream.wait_event(self.head_done[k])
         slot.run(self.tail_stream, PHASE_TAIL)
-        if after_tail is not None:
-            with torch.cuda.stream(self.tail_stream):
-                after_tail(k)
         ev = torch.cuda.Event()
         ev.record(self.tail_stream)
+        if after_tail is not None:
+            # e.g. the RCCL accept-reduce: on its own stream, so the next Merkle kernel on the
+            # tail stream never waits for a collective (or for a slower rank)
+            self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
+                after_tail(k)
+            ev = torch.cuda.Event()
+            ev.record(self.comm_stream)
         self.tail_done[k] = ev
         return k
 
@@ -63,6 +70,7 @@ class Pipeline:
         for s in self.head_streams:
             s.synchronize()
         self.tail_stream.synchronize()
+        self.comm_stream.synchronize()
 
 
 # ----------------------------------------------------------------------------- records
@@ -330,6 +338,35 @@ class Verifier:
         b = self.stwo_batch(proofs, mode)
         b.run()
         return b.status()
+
+    def verify_stwo_records(self, cfg: StwoConfig, records: Sequence[np.ndarray],
+                            mode: int = MODE_FIXTURE,
+                            shape_status: Optional[np.ndarray] = None) -> np.ndarray:
+        """Host-buffer path (ss_stwo_verify_records): raw records are uploaded in pinned
+        chunks, re-tiled on the GPU and verified.  PCIe-bound; synchronous."""
+        cs = stwo_cfg_struct(cfg, mode)
+        status = np.zeros(len(records), dtype=np.uint32)
+        sh = None
+        if shape_status is not None and np.any(shape_status):
+            sh = np.ascontiguousarray(shape_status, dtype=np.uint32)
+        B.check(B.lib().ss_stwo_verify_records(self.ctx, C.byref(cs), len(records), _ptr_array(records),
+                                               sh.ctypes.data if sh is not None else None,
+                                               status.ctypes.data))
+        return status
+
+    def pack_stwo_on_device(self, cfg: StwoConfig, mode: int, records: Sequence[np.ndarray]):
+        """Upload records as they are and re-tile them with ss_stwo_pack_dev; returns the batch
+        tensor (int32 view of the u32 words)."""
+        torch = _torch()
+        cs = stwo_cfg_struct(cfg, mode)
+        flat = np.ascontiguousarray(np.stack(records), dtype=np.uint32)
+        rec_dev = _to_dev(flat.reshape(-1), self.device)
+        words = B.lib().ss_stwo_batch_words(C.byref(cs), len(records))
+        out = torch.empty(words, dtype=torch.int32, device=self.device)
+        B.check(B.lib().ss_stwo_pack_dev(self.ctx, C.byref(cs), len(records), rec_dev.data_ptr(),
+                                         out.data_ptr(), int(torch.cuda.current_stream(self.device).cuda_stream)))
+        torch.cuda.synchronize(self.device)
+        return out
 
     # -- primitives self-test (tests only) ------------------------------------------------
     def selftest(self, op: int, inputs: np.ndarray) -> np.ndarray:

@@ -265,3 +265,29 @@ def test_pipeline_matches_single_stream(ver, stwo_prod):
     for slot in pipe.slots:
         assert slot.status().tolist() == ref.tolist()
         assert slot.accepted() == int((ref == 0).sum())
+
+
+@pytest.mark.parametrize("which,n", [("small", 3), ("prod", 70), ("wide", 5)])
+def test_device_pack_equals_host_pack(ver, stwo_small, stwo_prod, which, n):
+    """ss_stwo_pack_dev (GPU re-tiling of raw records) writes the same words as ss_stwo_pack."""
+    base = {"small": stwo_small, "prod": stwo_prod}.get(which) or _load_npz("stwo_wide256.npz")[0]
+    rng = np.random.default_rng(SEED + 13)
+    proofs = [base] + [formats.stwo_corrupt(base, rng)[0] for _ in range(n - 1)]
+    recs = [verifier.stwo_record(p)[0] for p in proofs]
+    host = verifier.pack_stwo(base.cfg, verifier.MODE_FIXTURE, recs)
+    dev = ver.pack_stwo_on_device(base.cfg, verifier.MODE_FIXTURE, recs)
+    assert np.array_equal(dev.cpu().numpy().view(np.uint32), host)
+
+
+def test_host_buffer_entry_point(ver, stwo_prod):
+    """ss_stwo_verify_records: pinned chunked upload + GPU packing + verify, several chunks
+    (1300 proofs of 54 KB > one 64 MiB staging buffer), called twice to reuse its scratch."""
+    rng = np.random.default_rng(SEED + 14)
+    distinct = [stwo_prod] + [formats.stwo_corrupt(stwo_prod, rng)[0] for _ in range(6)]
+    recs, shapes = zip(*[verifier.stwo_record(p) for p in distinct])
+    want_d = O.stwo_verify_batch(list(distinct))
+    for n in (1300, 17):
+        idx = [i % 7 for i in range(n)]
+        got = ver.verify_stwo_records(stwo_prod.cfg, [recs[i] for i in idx],
+                                      shape_status=np.array([shapes[i] for i in idx]))
+        assert got.tolist() == [int(want_d[i]) for i in idx]

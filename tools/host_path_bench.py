@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the host-buffer entry point (records in host memory -> verdicts):
+ss_stwo_verify_records, timed around the single C call.  Not the metric of bench.py."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from stark_symphony_amd import binding as B, records, verifier  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+proofs = records.load_stwo_npz(os.path.join(ROOT, "tests", "golden", "stwo_trace20.npz"))
+recs = [verifier.stwo_record(p)[0] for p in proofs]
+cfg = verifier.stwo_cfg_struct(proofs[0].cfg, verifier.MODE_FIXTURE)
+ver = verifier.Verifier(0)
+ptrs = verifier._ptr_array([recs[i % len(recs)] for i in range(n)])
+status = np.zeros(n, dtype=np.uint32)
+lib = B.lib()
+for rep in range(3):
+    t0 = time.perf_counter()
+    B.check(lib.ss_stwo_verify_records(ver.ctx, C.byref(cfg), n, ptrs, None, status.ctypes.data))
+    dt = time.perf_counter() - t0
+    assert (status == 0).all()
+    print("host path: %d proofs in %.3f s = %.0f proofs/s, %.2f GB/s of records"
+          % (n, dt, n / dt, n * recs[0].nbytes / dt / 1e9))
