@@ -90,7 +90,15 @@ typedef struct ss_stwo_cfg {
     uint32_t n_layers;   /* NUM_FRI_LAYERS, inner layers (<= 30, < lde_log) */
     uint32_t mode;       /* SS_MODE_*                                      */
     uint64_t pow_target; /* POW_TARGET_64: digest value must be < target   */
+    uint32_t hash;       /* SS_HASH_*                                      */
 } ss_stwo_cfg;
+
+/* SS_HASH_SHA256 is the reference (hasher.simf:13-104, channel.simf:36-172).  SS_HASH_BLAKE2S is
+ * the "Blake2s Merkle" variant BASELINE.json names: the same protocol over the same byte
+ * strings with Blake2s-256 (RFC 7693) as the hash.  The reference has no Blake2s, so that
+ * variant's parity is unpinned (RFC vectors + prover/oracle/GPU agreement only).          */
+#define SS_HASH_SHA256 0u
+#define SS_HASH_BLAKE2S 1u
 
 /* SS_MODE_LITERAL follows the .simf text (single DEEP batch fri/answers.simf:97-130,
  * `log_size_ex == 0` fri/verify.simf:127, `folded_query == 0` fri/layers.simf:75).

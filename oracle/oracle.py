@@ -85,7 +85,8 @@ class Path(C.Structure):
 
 class StwoCfg(C.Structure):
     _fields_ = [("n_cols", C.c_uint32), ("trace_log", C.c_uint32), ("lde_log", C.c_uint32),
-                ("n_queries", C.c_uint32), ("n_layers", C.c_uint32), ("pow_target", C.c_uint64)]
+                ("n_queries", C.c_uint32), ("n_layers", C.c_uint32), ("pow_target", C.c_uint64),
+                ("hash", C.c_uint32)]
 
 
 class StwoProofC(C.Structure):
@@ -119,6 +120,8 @@ def lib() -> C.CDLL:
         f.restype = res
         f.argtypes = list(args)
     sig("so_sha256", None, C.c_char_p, C.c_size_t, u8p)
+    sig("so_blake2s", None, C.c_char_p, C.c_size_t, u8p)
+    sig("so_set_hash", None, C.c_int)
     sig("so_sha256_blocks", C.c_uint64)
     sig("so_sha256_blocks_reset", None)
     for n in ("add_mod", "sub_mod", "mul_mod", "exp_mod"):
@@ -198,6 +201,12 @@ def sha256(msg: bytes) -> bytes:
     return bytes(out)
 
 
+def blake2s(msg: bytes) -> bytes:
+    out = (C.c_uint8 * 32)()
+    lib().so_blake2s(msg, len(msg), out)
+    return bytes(out)
+
+
 def qm(v: Sequence[int]) -> QM31:
     return QM31(int(v[0]), int(v[1]), int(v[2]), int(v[3]))
 
@@ -267,7 +276,8 @@ class StwoHolder:
     def __init__(self, p):
         cfg = p.cfg
         Q, K = cfg.n_queries, cfg.n_layers
-        self.cfg = StwoCfg(cfg.n_cols, cfg.trace_log, cfg.lde_log, Q, K, cfg.pow_target)
+        self.cfg = StwoCfg(cfg.n_cols, cfg.trace_log, cfg.lde_log, Q, K, cfg.pow_target,
+                           1 if getattr(cfg, "hash", "sha256") == "blake2s" else 0)
         self.keep: List[np.ndarray] = []
         c = StwoProofC()
         C.memmove(c.roots, np.ascontiguousarray(p.roots).ctypes.data, 96)

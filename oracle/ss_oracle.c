@@ -61,7 +61,56 @@ typedef struct {
     uint8_t buf[64];
     size_t fill;
     uint64_t total;
+    int kind; /* 0 SHA-256 (the reference), 1 Blake2s-256 (extension, parity unpinned) */
 } sha_ctx;
+
+/* Hash family of the running stwo verification (so_stwo_cfg.hash).  The reference only has
+ * SHA-256; Blake2s is the BASELINE.json variant, pinned by RFC 7693 vectors only.  The byte
+ * strings that get hashed are identical in both variants. */
+static __thread int g_hash_kind;
+
+/* ---- Blake2s-256 (RFC 7693), unkeyed */
+static const uint32_t B2S_IV[8] = {0x6A09E667, 0xBB67AE85, 0x3C6EF372, 0xA54FF53A,
+                                   0x510E527F, 0x9B05688C, 0x1F83D9AB, 0x5BE0CD19};
+static const uint8_t B2S_SIGMA[10][16] = {
+    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+    {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+    {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+    {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+    {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0}};
+
+static void b2s_compress(uint32_t h[8], const uint8_t blk[64], uint64_t t, int last)
+{
+    uint32_t m[16], v[16];
+    for (int i = 0; i < 16; i++)
+        m[i] = (uint32_t)blk[4 * i] | ((uint32_t)blk[4 * i + 1] << 8) | ((uint32_t)blk[4 * i + 2] << 16) |
+               ((uint32_t)blk[4 * i + 3] << 24);
+    for (int i = 0; i < 8; i++) { v[i] = h[i]; v[8 + i] = B2S_IV[i]; }
+    v[12] ^= (uint32_t)t;
+    v[13] ^= (uint32_t)(t >> 32);
+    if (last) v[14] = ~v[14];
+#define B2S_G(a, b, c, d, x, y)                                   \
+    do {                                                          \
+        v[a] = v[a] + v[b] + (x); v[d] = rotr(v[d] ^ v[a], 16);   \
+        v[c] = v[c] + v[d];       v[b] = rotr(v[b] ^ v[c], 12);   \
+        v[a] = v[a] + v[b] + (y); v[d] = rotr(v[d] ^ v[a], 8);    \
+        v[c] = v[c] + v[d];       v[b] = rotr(v[b] ^ v[c], 7);    \
+    } while (0)
+    for (int r = 0; r < 10; r++) {
+        const uint8_t *s = B2S_SIGMA[r];
+        B2S_G(0, 4, 8, 12, m[s[0]], m[s[1]]);
+        B2S_G(1, 5, 9, 13, m[s[2]], m[s[3]]);
+        B2S_G(2, 6, 10, 14, m[s[4]], m[s[5]]);
+        B2S_G(3, 7, 11, 15, m[s[6]], m[s[7]]);
+        B2S_G(0, 5, 10, 15, m[s[8]], m[s[9]]);
+        B2S_G(1, 6, 11, 12, m[s[10]], m[s[11]]);
+        B2S_G(2, 7, 8, 13, m[s[12]], m[s[13]]);
+        B2S_G(3, 4, 9, 14, m[s[14]], m[s[15]]);
+    }
+#undef B2S_G
+    for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[8 + i];
+    g_blocks++;
+}
 
 static void sha_init(sha_ctx *c)
 {
@@ -70,10 +119,27 @@ static void sha_init(sha_ctx *c)
     memcpy(c->h, iv, sizeof iv);
     c->fill = 0;
     c->total = 0;
+    c->kind = g_hash_kind;
+    if (c->kind == 1) c->h[0] ^= 0x01010020u; /* digest length 32, no key, fanout = depth = 1 */
 }
 
 static void sha_add(sha_ctx *c, const uint8_t *p, size_t n)
 {
+    if (c->kind == 1) {
+        /* the last block must be compressed with the final flag: keep it buffered */
+        while (n) {
+            if (c->fill == 64) {
+                c->total += 64;
+                b2s_compress(c->h, c->buf, c->total, 0);
+                c->fill = 0;
+            }
+            size_t k = 64 - c->fill;
+            if (k > n) k = n;
+            memcpy(c->buf + c->fill, p, k);
+            c->fill += k; p += k; n -= k;
+        }
+        return;
+    }
     c->total += n;
     while (n) {
         size_t k = 64 - c->fill;
@@ -99,6 +165,18 @@ static void sha_add_u64(sha_ctx *c, uint64_t v)
 
 static void sha_final(sha_ctx *c, uint8_t out[32])
 {
+    if (c->kind == 1) {
+        c->total += c->fill;
+        memset(c->buf + c->fill, 0, 64 - c->fill);
+        b2s_compress(c->h, c->buf, c->total, 1);
+        for (int i = 0; i < 8; i++) {
+            out[4 * i] = (uint8_t)c->h[i];
+            out[4 * i + 1] = (uint8_t)(c->h[i] >> 8);
+            out[4 * i + 2] = (uint8_t)(c->h[i] >> 16);
+            out[4 * i + 3] = (uint8_t)(c->h[i] >> 24);
+        }
+        return;
+    }
     uint64_t bits = c->total * 8;
     uint8_t pad = 0x80;
     sha_add(c, &pad, 1);
@@ -121,6 +199,21 @@ void so_sha256(const uint8_t *msg, size_t len, uint8_t out[32])
     sha_init(&c);
     sha_add(&c, msg, len);
     sha_final(&c, out);
+}
+
+/* hash family used by the stwo leaf functions when called one by one (tests); so_stwo_verify
+ * sets it from cfg->hash itself */
+void so_set_hash(int kind) { g_hash_kind = kind == 1 ? 1 : 0; }
+
+void so_blake2s(const uint8_t *msg, size_t len, uint8_t out[32])
+{
+    int saved = g_hash_kind;
+    g_hash_kind = 1;
+    sha_ctx c;
+    sha_init(&c);
+    sha_add(&c, msg, len);
+    sha_final(&c, out);
+    g_hash_kind = saved;
 }
 
 /* sha256.simf:11 / hasher.simf:13 */
@@ -1030,6 +1123,7 @@ uint32_t so_stwo_verify(const so_stwo_cfg *cfg, const so_stwo_proof *p, int mode
     uint32_t draw_ord = 0;
 
     if (Q > 64 || K > SO_MAX_LIST) return 0xffffffffu;
+    g_hash_kind = cfg->hash == 1 ? 1 : 0;
     memset(&oods, 0, sizeof oods);
     memset(fold_alpha, 0, sizeof fold_alpha);
 
@@ -1157,5 +1251,6 @@ uint32_t so_stwo_verify(const so_stwo_cfg *cfg, const so_stwo_proof *p, int mode
         if (tr) { tr->folded[q] = evals[q]; tr->folded_query[q] = queries[q]; }
     }
     if (tr) tr->final_log_size = log_size_ex;
+    g_hash_kind = 0;
     return status;
 }

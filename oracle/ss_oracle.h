@@ -35,6 +35,11 @@ extern "C" {
 
 /* ------------------------------------------------------------------ sha256 */
 void so_sha256(const uint8_t *msg, size_t len, uint8_t out[32]);
+/* Blake2s-256 (RFC 7693): the hash of the BASELINE.json "Blake2s Merkle" variant.  The
+ * reference has no Blake2s, so this variant's parity is UNPINNED: only the
+ * hash itself is checked against RFC 7693 vectors.  Same byte strings, other hash function. */
+void so_blake2s(const uint8_t *msg, size_t len, uint8_t out[32]);
+void so_set_hash(int kind); /* 0 sha256, 1 blake2s: for calling stwo leaf functions one by one */
 /* number of compression-function calls since the last reset (for work counts) */
 uint64_t so_sha256_blocks(void);
 void so_sha256_blocks_reset(void);
@@ -187,6 +192,7 @@ typedef struct {
     uint32_t n_queries;    /* NUM_FRI_QUERIES  config.simf:25,43 */
     uint32_t n_layers;     /* NUM_FRI_LAYERS   config.simf:29,47 (inner layers) */
     uint64_t pow_target;   /* POW_TARGET_64    config.simf:32,51 */
+    uint32_t hash;         /* 0 SHA-256 (reference), 1 Blake2s-256 (extension, unpinned) */
 } so_stwo_cfg;
 
 typedef struct {

@@ -26,7 +26,7 @@ class StwoCfg(C.Structure):
     """ss_stwo_cfg"""
     _fields_ = [("n_cols", C.c_uint32), ("trace_log", C.c_uint32), ("lde_log", C.c_uint32),
                 ("n_queries", C.c_uint32), ("n_layers", C.c_uint32), ("mode", C.c_uint32),
-                ("pow_target", C.c_uint64)]
+                ("pow_target", C.c_uint64), ("hash", C.c_uint32)]
 
 
 class S101Shape(C.Structure):

@@ -188,7 +188,8 @@ static void parallel_for(size_t n, F f)
 // ================================================================================ stwo
 static bool cfg_ok(const ss_stwo_cfg *c)
 {
-    return c && stwo_cfg_ok(c->n_cols, c->trace_log, c->lde_log, c->n_queries, c->n_layers, c->mode);
+    return c && c->hash <= SS_HASH_BLAKE2S &&
+           stwo_cfg_ok(c->n_cols, c->trace_log, c->lde_log, c->n_queries, c->n_layers, c->mode);
 }
 static StwoLayout lay_of(const ss_stwo_cfg *c, size_t n)
 {
@@ -266,7 +267,8 @@ extern "C" int ss_stwo_verify_phase_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_
         HIP_TRY(hipMemsetAsync(status, 0xff, n * 4, s));
         if (accept_count) HIP_TRY(hipMemsetAsync(accept_count, 0, 4, s));
         t.begin();
-        hipLaunchKernelGGL(stwo_transcript_kernel, dim3((y.n + 63) / 64), dim3(64), 0, s, y, batch, ws, status);
+        hipLaunchKernelGGL(c->hash == SS_HASH_BLAKE2S ? stwo_transcript_kernel_b2s : stwo_transcript_kernel_sha,
+                           dim3((y.n + 63) / 64), dim3(64), 0, s, y, batch, ws, status);
         t.end("stwo_transcript");
         t.begin();
         hipLaunchKernelGGL(stwo_query_kernel, dim3((y.ni + 63) / 64), dim3(64), 0, s, y, batch, ws, status);
@@ -275,7 +277,8 @@ extern "C" int ss_stwo_verify_phase_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_
     if (phases & SS_PHASE_TAIL) {
         const uint32_t tiles = (y.K + 3) * (y.nip >> 6);
         t.begin();
-        hipLaunchKernelGGL(stwo_merkle_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, y, batch, ws, status);
+        hipLaunchKernelGGL(c->hash == SS_HASH_BLAKE2S ? stwo_merkle_kernel_b2s : stwo_merkle_kernel_sha,
+                           dim3((tiles + 3) / 4), dim3(256), 0, s, y, batch, ws, status);
         t.end("stwo_merkle");
         t.begin();
         hipLaunchKernelGGL(stwo_finalize_kernel, dim3((y.n + 255) / 256), dim3(256), 0, s, y.n, status,

@@ -4,7 +4,7 @@
 // calls.  The seven stages of docs/verifier_flow.md:3-36 are regrouped by their parallelism:
 //
 //   stwo_transcript_kernel   one lane per PROOF.   Stages I-IV + query generation: the
-//        Fiat-Shamir chain is ~(3K+25) dependent SHA-256 compressions, so lanes (not
+//        Fiat-Shamir chain is ~(3K+25) dependent hash compressions, so lanes (not
 //        wavefronts) are the unit; it also hoists everything of stage VI that does not
 //        depend on the query (DEEP line coefficients, fri/answers.simf:44-64).
 //   stwo_query_kernel        one lane per QUERY.   Stage VI (DEEP quotient at the query
@@ -15,14 +15,17 @@
 //        and the per-layer FRI decommitments (fri/layers.simf:40-48).  >90 % of the work.
 //   stwo_finalize_kernel     one lane per proof: first-failure code -> status, accept count.
 //
+// The transcript and Merkle kernels exist once per hash family (ss_hash.h): *_sha is the
+// reference's SHA-256, *_b2s the Blake2s variant (same byte strings, parity unpinned).
+//
 // A failed assert never stops a lane: each check contributes its code through atomicMin, and
 // because the codes are ordered like the reference's evaluation order the minimum IS the
 // first failing assert (every check is a pure function of the proof).
 #include <hip/hip_runtime.h>
 
 #include "ss_fields.h"
+#include "ss_hash.h"
 #include "ss_layout.h"
-#include "ss_sha256.h"
 
 namespace ss {
 
@@ -31,78 +34,60 @@ __device__ __forceinline__ uint32_t stwo_code(uint32_t stage, uint32_t layer, ui
     return (stage << 24) | (layer << 16) | (query << 4) | sub;
 }
 
-struct Dig { uint32_t v[8]; };
-struct W16 { uint32_t v[16]; };
+// ------------------------------------------------------------------ channel (channel.simf)
+// The digest is kept in the hash's native form; `ctr` is num_sent.
+template <int HF>
+struct Channel {
+    Dig dig;
+    uint32_t ctr;
 
-// Out-of-line compression for the sequential transcript (keeps its code footprint small).
-__device__ __noinline__ Dig compress_call(Dig st, W16 w)
-{
-    sha256_compress(st.v, w.v);
-    return st;
-}
-__device__ __noinline__ Dig compress_pad64_call(Dig st)
-{
-    sha256_compress_pad64(st.v);
-    return st;
-}
-__device__ __forceinline__ Dig dig_iv()
-{
-    Dig d;
-    sha_iv(d.v);
-    return d;
-}
-
-// channel_mix_u256 (channel.simf:154-161): digest <- H(digest || in)
-__device__ inline void channel_mix(Dig &dig, uint32_t &ctr, const Dig &in)
-{
-    W16 w;
+    __device__ void init()  // channel_init, channel.simf:31
+    {
 #pragma unroll
-    for (int i = 0; i < 8; i++) { w.v[i] = dig.v[i]; w.v[8 + i] = in.v[i]; }
-    dig = compress_pad64_call(compress_call(dig_iv(), w));
-    ctr = 0;
-}
-
-// H(digest || m[0..n)) for n <= 5 words: one block (draws, mix_u64, mix_line_poly)
-template <int NW>
-__device__ inline Dig hash_digest_words(const Dig &dig, const uint32_t (&m)[NW])
-{
-    static_assert(NW <= 5, "single block");
-    W16 w;
-#pragma unroll
-    for (int i = 0; i < 16; i++) w.v[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) w.v[i] = dig.v[i];
-#pragma unroll
-    for (int i = 0; i < NW; i++) w.v[8 + i] = m[i];
-    w.v[8 + NW] = 0x80000000u;
-    w.v[15] = 32u * (8 + NW);
-    return compress_call(dig_iv(), w);
-}
-
-// channel_draw_words (channel.simf:36-65)
-__device__ inline Dig channel_draw_words(const Dig &dig, uint32_t &ctr)
-{
-    uint32_t m[1] = {ctr};
-    Dig out = hash_digest_words<1>(dig, m);
-    ctr = ctr + 1;
-    return out;
-}
-
-// channel_draw_qm31 (channel.simf:115-140): retry while any of the first four words >= 2^32 - 2;
-// the for_while counter is a u8, so at most 256 attempts.
-__device__ inline bool channel_draw_qm31(const Dig &dig, uint32_t &ctr, QM31 &out)
-{
-    for (int it = 0; it < 256; it++) {
-        Dig w = channel_draw_words(dig, ctr);
-        if (w.v[0] < 4294967294u && w.v[1] < 4294967294u && w.v[2] < 4294967294u &&
-            w.v[3] < 4294967294u) {
-            out = {m31_red(w.v[0]), m31_red(w.v[1]), m31_red(w.v[2]), m31_red(w.v[3])};
-            return true;
-        }
+        for (int i = 0; i < 8; i++) dig.v[i] = 0;
+        ctr = 0;
     }
-    out = qm31_zero();
-    return false;
-}
+    // channel_mix_u256 (channel.simf:154-161): digest <- H(digest || in); `in` is stored words
+    __device__ void mix(const uint32_t (&in)[8])
+    {
+        uint32_t r[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) r[i] = Hasher<HF>::native(in[i]);
+        Hasher<HF>::template pair<false>(dig.v, r, dig.v);
+        ctr = 0;
+    }
+    // digest <- H(digest || NV value words): mix_u64, mix_line_poly (one block)
+    template <int NV>
+    __device__ void mix_values(const uint32_t (&vals)[NV])
+    {
+        Hasher<HF>::template block<false, 8, NV>(dig.v, vals, dig.v);
+        ctr = 0;
+    }
+    // channel_draw_words (channel.simf:36-65): the 8 big-endian words of H(digest || be4(ctr))
+    __device__ void draw_words(uint32_t (&w)[8])
+    {
+        uint32_t m[1] = {ctr}, d[8];
+        Hasher<HF>::template block<false, 8, 1>(dig.v, m, d);
+        ctr = ctr + 1;
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = Hasher<HF>::native(d[i]);  // native -> stored is the same swap
+    }
+    // channel_draw_qm31 (channel.simf:115-140): retry while any of the first four words
+    // >= 2^32 - 2; the for_while counter is a u8, so at most 256 attempts.
+    __device__ bool draw_qm31(QM31 &out)
+    {
+        for (int it = 0; it < 256; it++) {
+            uint32_t w[8];
+            draw_words(w);
+            if (w[0] < 4294967294u && w[1] < 4294967294u && w[2] < 4294967294u && w[3] < 4294967294u) {
+                out = {m31_red(w[0]), m31_red(w[1]), m31_red(w[2]), m31_red(w[3])};
+                return true;
+            }
+        }
+        out = qm31_zero();
+        return false;
+    }
+};
 
 // deep_quotient_interpolant_coefficients (deep/quotients.simf:25-36)
 __device__ inline void interpolant_coefficients(const QM31Point &sp, QM31 value, QM31 alpha_i,
@@ -120,9 +105,9 @@ __device__ inline void interpolant_coefficients(const QM31Point &sp, QM31 value,
 }
 
 // ========================================================================== transcript
-__global__ void __launch_bounds__(64)
-stwo_transcript_kernel(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,
-                       uint32_t *__restrict__ status)
+template <int HF>
+__device__ __forceinline__ void stwo_transcript_body(const StwoLayout &lay, const uint32_t *__restrict__ batch,
+                                                     uint32_t *__restrict__ ws, uint32_t *__restrict__ status)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= lay.n) return;
@@ -137,23 +122,21 @@ stwo_transcript_kernel(StwoLayout lay, const uint32_t *__restrict__ batch, uint3
     auto FAIL = [&](uint32_t code) { fail = code < fail ? code : fail; };
     uint32_t draw_ord = 0;
 
-    Dig dig;
-#pragma unroll
-    for (int i = 0; i < 8; i++) dig.v[i] = 0;
-    uint32_t ctr = 0;  // channel_init, channel.simf:31
+    Channel<HF> ch;
+    ch.init();
 
     // ---- stage I: evals_commit (evals/commit.simf:20-35)
     QM31 cp_alpha, deep_alpha;
     {
-        Dig r;
-        for (int i = 0; i < 8; i++) r.v[i] = H(lay.h_roots + i);
-        channel_mix(dig, ctr, r);
-        for (int i = 0; i < 8; i++) r.v[i] = H(lay.h_roots + 8 + i);
-        channel_mix(dig, ctr, r);
-        if (!channel_draw_qm31(dig, ctr, cp_alpha)) FAIL(stwo_code(1, 0, 0, draw_ord));
+        uint32_t r[8];
+        for (int i = 0; i < 8; i++) r[i] = H(lay.h_roots + i);
+        ch.mix(r);
+        for (int i = 0; i < 8; i++) r[i] = H(lay.h_roots + 8 + i);
+        ch.mix(r);
+        if (!ch.draw_qm31(cp_alpha)) FAIL(stwo_code(1, 0, 0, draw_ord));
         draw_ord++;
-        for (int i = 0; i < 8; i++) r.v[i] = H(lay.h_roots + 16 + i);
-        channel_mix(dig, ctr, r);
+        for (int i = 0; i < 8; i++) r[i] = H(lay.h_roots + 16 + i);
+        ch.mix(r);
     }
 
     // ---- stage II: oods (deep/oods.simf:44-64)
@@ -161,38 +144,20 @@ stwo_transcript_kernel(StwoLayout lay, const uint32_t *__restrict__ batch, uint3
     {
         // channel_draw_qm31_point (channel.simf:143-151)
         QM31 t, inv;
-        if (!channel_draw_qm31(dig, ctr, t)) FAIL(stwo_code(1, 0, 0, draw_ord));
+        if (!ch.draw_qm31(t)) FAIL(stwo_code(1, 0, 0, draw_ord));
         draw_ord++;
         QM31 t_sq = qm31_mul(t, t);
         if (!qm31_inv(qm31_add(qm31_one(), t_sq), inv)) FAIL(stwo_code(2, 0, 0, 1));
         P.x = qm31_mul(qm31_sub(qm31_one(), t_sq), inv);
         P.y = qm31_mul(qm31_add(t, t), inv);
 
-        // channel_mix_oods_evals (deep/oods.simf:23-39): H(digest || 4(N+16) words)
+        // channel_mix_oods_evals (deep/oods.simf:23-39): H(digest || 4(N+16) value words);
+        // oods_trace and oods_cp are adjacent in the head section
         {
-            const uint32_t total = 8 + 4 * (lay.N + kCp);  // message words
-            const uint32_t nblk = (total + 2) / 16 + 1;      // + 0x80 word + 64-bit length
-            Dig st = dig_iv();
-            for (uint32_t b = 0; b < nblk; b++) {
-                W16 w;
-#pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    const uint32_t i = b * 16 + j;
-                    uint32_t v = 0;
-                    if (i < 8) v = 0;  // patched below (static indexing of the digest)
-                    else if (i < total) v = H(lay.h_oods_trace + (i - 8));
-                    else if (i == total) v = 0x80000000u;
-                    else if (i == nblk * 16 - 1) v = 32u * total;
-                    w.v[j] = v;
-                }
-                if (b == 0) {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) w.v[j] = dig.v[j];
-                }
-                st = compress_call(st, w);
-            }
-            dig = st;
-            ctr = 0;
+            const uint32_t base = lay.h_oods_trace;
+            Hasher<HF>::template stream<false, 8>(ch.dig.v, [&](uint32_t i) { return H(base + i); },
+                                                  4 * (lay.N + kCp), ch.dig.v);
+            ch.ctr = 0;
         }
 
         // eval_composition_poly (constraints/wide_fibonacci.simf:24-62)
@@ -237,44 +202,41 @@ stwo_transcript_kernel(StwoLayout lay, const uint32_t *__restrict__ batch, uint3
         sampled = qm31_add(sampled, qm31_mul(part[3], qm31_mul(P.x, P.y)));
         if (!qm31_eq(cp_eval, sampled)) FAIL(stwo_code(2, 0, 0, 3));
 
-        if (!channel_draw_qm31(dig, ctr, deep_alpha)) FAIL(stwo_code(1, 0, 0, draw_ord));
+        if (!ch.draw_qm31(deep_alpha)) FAIL(stwo_code(1, 0, 0, draw_ord));
         draw_ord++;
     }
 
     // ---- stage III: fri_commit (fri/commit.simf:70-85)
     for (uint32_t l = 0; l <= lay.K; l++) {
-        Dig r;
-        for (int i = 0; i < 8; i++) r.v[i] = H(lay.h_fri_roots + 8 * l + i);
-        channel_mix(dig, ctr, r);
+        uint32_t r[8];
+        for (int i = 0; i < 8; i++) r[i] = H(lay.h_fri_roots + 8 * l + i);
+        ch.mix(r);
         QM31 fa;
-        if (!channel_draw_qm31(dig, ctr, fa)) FAIL(stwo_code(1, 0, 0, draw_ord));
+        if (!ch.draw_qm31(fa)) FAIL(stwo_code(1, 0, 0, draw_ord));
         draw_ord++;
         CQ(lay.c_fold + 4 * l, fa);
     }
     {
         uint32_t m[4] = {H(lay.h_last), H(lay.h_last + 1), H(lay.h_last + 2), H(lay.h_last + 3)};
-        dig = hash_digest_words<4>(dig, m);  // channel_mix_line_poly, fri/commit.simf:48-57
-        ctr = 0;
+        ch.template mix_values<4>(m);  // channel_mix_line_poly, fri/commit.simf:48-57
     }
 
     // ---- stage IV: check_proof_of_work (pow.simf:22-36)
     {
         uint32_t m[2] = {H(lay.h_nonce), H(lay.h_nonce + 1)};
-        dig = hash_digest_words<2>(dig, m);  // channel_mix_u64
-        ctr = 0;
-        // last 8 digest bytes, read little-endian: (bswap(h) << 32) | bswap(g)
-        uint64_t value = ((uint64_t)__builtin_bswap32(dig.v[7]) << 32) | __builtin_bswap32(dig.v[6]);
-        if (!(value < lay.pow_target)) FAIL(stwo_code(4, 0, 0, 0));
+        ch.template mix_values<2>(m);  // channel_mix_u64
+        if (!(Hasher<HF>::pow_value(ch.dig.v) < lay.pow_target)) FAIL(stwo_code(4, 0, 0, 0));
     }
 
     // ---- stage V (first half): fri_generate_queries (fri/queries.simf:29-43)
     {
         const uint32_t mask = shl32(lay.L, 1) - 1;
         for (uint32_t base = 0; base < lay.Q; base += 8) {
-            Dig w = channel_draw_words(dig, ctr);
+            uint32_t w[8];
+            ch.draw_words(w);
 #pragma unroll
             for (int j = 0; j < 8; j++)
-                if (base + j < lay.Q) CW(lay.c_queries + base + j, w.v[j] & mask);
+                if (base + j < lay.Q) CW(lay.c_queries + base + j, w[j] & mask);
         }
     }
 
@@ -322,6 +284,19 @@ stwo_transcript_kernel(StwoLayout lay, const uint32_t *__restrict__ batch, uint3
         }
     }
     if (fail != 0xffffffffu) atomicMin(&status[p], fail);
+}
+
+__global__ void __launch_bounds__(64)
+stwo_transcript_kernel_sha(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,
+                           uint32_t *__restrict__ status)
+{
+    stwo_transcript_body<0>(lay, batch, ws, status);
+}
+__global__ void __launch_bounds__(64)
+stwo_transcript_kernel_b2s(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,
+                           uint32_t *__restrict__ status)
+{
+    stwo_transcript_body<1>(lay, batch, ws, status);
 }
 
 // =============================================================================== query
@@ -464,9 +439,9 @@ stwo_query_kernel(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *
 // ============================================================================== merkle
 // One wavefront = 64 chains of one kind.  Tile order: trace, cp, FRI layer 0..K (longest
 // chains first, so the tail of the grid is made of the shortest ones).
-__global__ void __launch_bounds__(256)
-stwo_merkle_kernel(StwoLayout lay, const uint32_t *__restrict__ batch, const uint32_t *__restrict__ ws,
-                   uint32_t *__restrict__ status)
+template <int HF>
+__device__ __forceinline__ void stwo_merkle_body(const StwoLayout &lay, const uint32_t *__restrict__ batch,
+                                                 const uint32_t *__restrict__ ws, uint32_t *__restrict__ status)
 {
     const uint32_t tiles_per_type = lay.nip >> 6;
     const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -482,29 +457,15 @@ stwo_merkle_kernel(StwoLayout lay, const uint32_t *__restrict__ batch, const uin
     const uint32_t *head = batch + lay.off_head;
     const uint32_t query = ctx[(size_t)(lay.c_queries + q) * np + p];
 
-    uint32_t node[8];
+    uint32_t node[8];  // native form
     uint32_t auth, len, root_w, code_base;
     const uint32_t *path;
     if (type < 2) {
-        // verify_trace_evals / verify_cp_evals (evals/verify.simf:47-69)
+        // verify_trace_evals / verify_cp_evals (evals/verify.simf:47-69); the leaf is
+        // hash_node_m31_trace / hash_node_m31_cp (hasher.simf:85-97): H of ncol value words
         const uint32_t ncol = type == 0 ? lay.N : kCp;
         const uint32_t *vals = batch + (type == 0 ? lay.off_trace_vals : lay.off_cp_vals) + inst;
-        // hash_node_m31_trace / hash_node_m31_cp (hasher.simf:85-97): SHA-256 of ncol BE words
-        const uint32_t nblk = (ncol + 2) / 16 + 1;
-        sha_iv(node);
-        for (uint32_t b = 0; b < nblk; b++) {
-            uint32_t w[16];
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const uint32_t i = b * 16 + j;
-                uint32_t v = 0;
-                if (i < ncol) v = vals[(size_t)i * nip];
-                else if (i == ncol) v = 0x80000000u;
-                else if (i == nblk * 16 - 1) v = 32u * ncol;
-                w[j] = v;
-            }
-            sha256_compress(node, w);
-        }
+        Hasher<HF>::template stream<true, 0>(nullptr, [&](uint32_t i) { return vals[(size_t)i * nip]; }, ncol, node);
         auth = query + shl32(lay.L, 1);
         len = lay.L;
         path = batch + (type == 0 ? lay.off_trace_path : lay.off_cp_path);
@@ -517,9 +478,9 @@ stwo_merkle_kernel(StwoLayout lay, const uint32_t *__restrict__ batch, const uin
         uint32_t e0[4], e1[4], l0[8], l1[8];
 #pragma unroll
         for (int j = 0; j < 4; j++) { e0[j] = lf[(size_t)j * nip]; e1[j] = lf[(size_t)(4 + j) * nip]; }
-        sha256_words<4>(e0, l0);  // hash_node_qm31 (hasher.simf:100-104)
-        sha256_words<4>(e1, l1);
-        sha256_pair(l0, l1, node);
+        Hasher<HF>::template block<true, 0, 4>(nullptr, e0, l0);  // hash_node_qm31 (hasher.simf:100-104)
+        Hasher<HF>::template block<true, 0, 4>(nullptr, e1, l1);
+        Hasher<HF>::template pair<true>(l0, l1, node);
         const uint32_t logl = lay.L - l;
         const uint32_t position = (query >> l) & ~1u;
         auth = (position + shl32(logl, 1)) >> 1;
@@ -539,17 +500,17 @@ stwo_merkle_kernel(StwoLayout lay, const uint32_t *__restrict__ batch, const uin
             n0 = tp[(size_t)(lvl + 1) * 128];
             n1 = tp[(size_t)(lvl + 1) * 128 + 64];
         }
-        const uint32_t sib[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const uint32_t sib[8] = {Hasher<HF>::native(s0.x), Hasher<HF>::native(s0.y), Hasher<HF>::native(s0.z),
+                                 Hasher<HF>::native(s0.w), Hasher<HF>::native(s1.x), Hasher<HF>::native(s1.y),
+                                 Hasher<HF>::native(s1.z), Hasher<HF>::native(s1.w)};
         const bool right = auth & 1;  // node is the right child: H(sibling || node)
-        uint32_t w[16];
+        uint32_t lft[8], rgt[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            w[j] = right ? sib[j] : node[j];
-            w[8 + j] = right ? node[j] : sib[j];
+            lft[j] = right ? sib[j] : node[j];
+            rgt[j] = right ? node[j] : sib[j];
         }
-        sha_iv(node);
-        sha256_compress(node, w);
-        sha256_compress_pad64(node);
+        Hasher<HF>::template pair<true>(lft, rgt, node);
         auth >>= 1;
         s0 = n0; s1 = n1;
     }
@@ -557,10 +518,23 @@ stwo_merkle_kernel(StwoLayout lay, const uint32_t *__restrict__ batch, const uin
     uint32_t fail = 0xffffffffu;
     bool same = true;
 #pragma unroll
-    for (int j = 0; j < 8; j++) same &= node[j] == head[(size_t)(root_w + j) * np + p];
+    for (int j = 0; j < 8; j++) same &= node[j] == Hasher<HF>::native(head[(size_t)(root_w + j) * np + p]);
     if (!same) fail = code_base + 1;   // assert!(eq_256(computed_root, root))  merkle.simf:43
     if (auth != 1) fail = code_base;   // assert!(eq_32(path, 1))              merkle.simf:42
     if (fail != 0xffffffffu) atomicMin(&status[p], fail);
+}
+
+__global__ void __launch_bounds__(256)
+stwo_merkle_kernel_sha(StwoLayout lay, const uint32_t *__restrict__ batch, const uint32_t *__restrict__ ws,
+                       uint32_t *__restrict__ status)
+{
+    stwo_merkle_body<0>(lay, batch, ws, status);
+}
+__global__ void __launch_bounds__(256)
+stwo_merkle_kernel_b2s(StwoLayout lay, const uint32_t *__restrict__ batch, const uint32_t *__restrict__ ws,
+                       uint32_t *__restrict__ status)
+{
+    stwo_merkle_body<1>(lay, batch, ws, status);
 }
 
 // ============================================================================ finalize

@@ -262,6 +262,7 @@ class StwoConfig:
     n_queries: int = 16    # NUM_FRI_QUERIES
     n_layers: int = 8      # NUM_FRI_LAYERS (inner layers)
     pow_bits: int = 5      # POW_TARGET_64 = 2^(64-pow_bits) - 1, strict '<'
+    hash: str = "sha256"   # "sha256" = the reference; "blake2s" = BASELINE.json variant (unpinned)
 
     @property
     def pow_target(self) -> int:
@@ -284,13 +285,20 @@ class StwoConfig:
 
     @property
     def compressions(self) -> int:
-        """SHA-256 compression calls per proof of the reference algorithm."""
+        """Hash compression calls per proof of the reference algorithm."""
         N, L, K, Q = self.n_cols, self.lde_log, self.n_layers, self.n_queries
+        b2s = self.hash == "blake2s"
 
         def blk(n: int) -> int:
+            if b2s:  # no padding block: ceil(n / 64), at least one
+                return max(1, (n + 63) // 64)
             return (n + 9 + 63) // 64
-        return (Q * (blk(4 * N) + 2 + 4 * L) + Q * sum(4 + 2 * (L - 1 - i) for i in range(K + 1))
-                + 6 + (4 + K + (Q + 7) // 8) + blk(32 + 16 * (N + 16)) + 2 * (K + 1) + 2)
+        pair = blk(64)  # 2 for SHA-256 (padding block), 1 for Blake2s
+        per_query = blk(4 * N) + blk(64) + 2 * L * pair
+        fri = sum(2 * blk(16) + (L - i) * pair for i in range(K + 1))
+        channel = (3 * pair + (3 + K + 1 + (Q + 7) // 8) + blk(32 + 16 * (N + 16)) + (K + 1) * pair
+                   + blk(48) + blk(40))
+        return Q * (per_query + fri) + channel
 
 
 TESTING_CONFIG = StwoConfig(4, 3, 4, 1, 2, 5)      # config.simf:16-33
@@ -340,7 +348,7 @@ def _split(lst: Sequence[Any], n: int) -> List[Sequence[Any]]:
     return [lst[i * k:(i + 1) * k] for i in range(n)]
 
 
-def stwo_from_json(data: Any, trace_log: int | None = None) -> StwoProof:
+def stwo_from_json(data: Any, trace_log: int | None = None, hash: str | None = None) -> StwoProof:
     """Format C.  The JSON carries pow_bits / log_blowup / n_queries; the LDE size is
     implied by the Merkle path length (the reference hard-codes it: config.simf:21,39)."""
     if isinstance(data, (str, bytes)):
@@ -387,7 +395,10 @@ def stwo_from_json(data: Any, trace_log: int | None = None) -> StwoProof:
         lde_log = len(trace_paths[0]) if Q else 0
         log_blowup = int(fri_conf.get("log_blowup_factor", 0))
         tl = trace_log if trace_log is not None else lde_log - log_blowup
-        cfg = StwoConfig(N, tl, lde_log, Q, K, int(conf.get("pow_bits", 0)))
+        hname = hash or conf.get("hash", "sha256")
+        if hname not in ("sha256", "blake2s"):
+            raise MalformedProof("unknown hash %r" % (hname,))
+        cfg = StwoConfig(N, tl, lde_log, Q, K, int(conf.get("pow_bits", 0)), hname)
         nonce = int(data.get("proof_of_work", 0))
         if not (0 <= nonce < 1 << 64):
             raise MalformedProof("u64 out of range")
@@ -410,10 +421,13 @@ def stwo_to_json(p: StwoProof) -> dict:
                 "decommitment": {"hash_witness": hw(p.fri_paths[i]), "column_witness": []},
                 "commitment": [int(b) for b in p.fri_roots[i]]}
     c = p.cfg
+    conf = {"pow_bits": c.pow_bits,
+            "fri_config": {"log_blowup_factor": c.log_blowup,
+                           "log_last_layer_degree_bound": 0, "n_queries": c.n_queries}}
+    if c.hash != "sha256":
+        conf["hash"] = c.hash  # extension key; the reference's JSON has none (always SHA-256)
     return {
-        "config": {"pow_bits": c.pow_bits,
-                   "fri_config": {"log_blowup_factor": c.log_blowup,
-                                  "log_last_layer_degree_bound": 0, "n_queries": c.n_queries}},
+        "config": conf,
         "commitments": [[int(b) for b in r] for r in p.roots],
         "sampled_values": [[], [[q(v)] for v in p.oods_trace], [[q(v)] for v in p.oods_cp]],
         "decommitments": [{"hash_witness": [], "column_witness": []},
@@ -428,7 +442,7 @@ def stwo_to_json(p: StwoProof) -> dict:
     }
 
 
-def stwo_from_wit(text: Any, trace_log: int, pow_bits: int = 5) -> StwoProof:
+def stwo_from_wit(text: Any, trace_log: int, pow_bits: int = 5, hash: str = "sha256") -> StwoProof:
     """Format D (stwo-verifier/scripts/generate_wit.py:218-243).  A ``.wit`` carries no
     config, so TRACE_LOG_SIZE and the PoW target come from the caller, as they come from
     config.simf for the reference."""
@@ -464,7 +478,7 @@ def stwo_from_wit(text: Any, trace_log: int, pow_bits: int = 5) -> StwoProof:
                 or fri_witness.shape != (K + 1, Q, 4) or oods_cp.shape[0] != N_CP_PARTITIONS):
             raise MalformedProof("witness shape mismatch")
         lde_log = len(trace_paths[0]) if Q else 0
-        cfg = StwoConfig(N, trace_log, lde_log, Q, K, pow_bits)
+        cfg = StwoConfig(N, trace_log, lde_log, Q, K, pow_bits, hash)
         return StwoProof(cfg, roots.copy(), oods_trace, oods_cp, trace_vals, cp_vals, trace_paths,
                          cp_paths, fri_roots.copy(), last, fri_witness, fri_paths, int(nonce))
     except (IndexError, TypeError, ValueError) as e:

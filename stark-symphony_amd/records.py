@@ -68,11 +68,13 @@ def save_stwo_npz(path: str, proofs: Sequence[StwoProof]) -> None:
             raise ValueError("non-uniform proof cannot be stored as a record")
         recs.append(rec)
     np.savez_compressed(path, cfg=np.array([cfg.n_cols, cfg.trace_log, cfg.lde_log, cfg.n_queries,
-                                            cfg.n_layers, cfg.pow_bits], dtype=np.uint32),
+                                            cfg.n_layers, cfg.pow_bits,
+                                            1 if cfg.hash == "blake2s" else 0], dtype=np.uint32),
                         records=np.stack(recs))
 
 
 def load_stwo_npz(path: str) -> List[StwoProof]:
     z = np.load(path)
-    cfg = StwoConfig(*[int(x) for x in z["cfg"]])
+    c = [int(x) for x in z["cfg"]]
+    cfg = StwoConfig(*c[:6], "blake2s" if len(c) > 6 and c[6] == 1 else "sha256")
     return [stwo_from_record(cfg, r) for r in z["records"]]

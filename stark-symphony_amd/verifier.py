@@ -161,7 +161,7 @@ def _ptr_array(records: Sequence[np.ndarray]):
 
 def stwo_cfg_struct(cfg: StwoConfig, mode: int) -> B.StwoCfg:
     return B.StwoCfg(cfg.n_cols, cfg.trace_log, cfg.lde_log, cfg.n_queries, cfg.n_layers, mode,
-                     cfg.pow_target)
+                     cfg.pow_target, 1 if cfg.hash == "blake2s" else 0)
 
 
 def pack_stwo(cfg: StwoConfig, mode: int, records: Sequence[np.ndarray]) -> np.ndarray:

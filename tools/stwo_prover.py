@@ -242,11 +242,15 @@ def be_words(arr: np.ndarray) -> bytes:
     return np.ascontiguousarray(arr, dtype=">u4").tobytes()
 
 
+HASHES = {"sha256": hashlib.sha256, "blake2s": lambda b=b"": hashlib.blake2s(b, digest_size=32)}
+_H = hashlib.sha256  # hash family of the running proof (set by prove())
+
+
 def hash_rows(rows: np.ndarray) -> np.ndarray:
-    """rows uint[n, w] -> sha256 of each row's big-endian words, uint8[n, 32]."""
+    """rows uint[n, w] -> hash of each row's big-endian words, uint8[n, 32]."""
     n, w = rows.shape
     buf = be_words(rows)
-    sha = hashlib.sha256
+    sha = _H
     step = 4 * w
     out = b"".join([sha(buf[i:i + step]).digest() for i in range(0, n * step, step)])
     return np.frombuffer(out, dtype=np.uint8).reshape(n, 32)
@@ -255,7 +259,7 @@ def hash_rows(rows: np.ndarray) -> np.ndarray:
 def merkle_levels(leaves: np.ndarray):
     """[leaf level, ..., root level]; node = sha256(left || right)."""
     levels = [leaves]
-    sha = hashlib.sha256
+    sha = _H
     cur = leaves
     while len(cur) > 1:
         buf = cur.tobytes()
@@ -283,14 +287,14 @@ class Channel:
         self.counter = 0
 
     def mix_u256(self, b: bytes):
-        self.digest = hashlib.sha256(self.digest + b).digest()
+        self.digest = _H(self.digest + b).digest()
         self.counter = 0
 
     def mix_bytes(self, b: bytes):
         self.mix_u256(b)
 
     def draw_words(self):
-        d = hashlib.sha256(self.digest + self.counter.to_bytes(4, "big")).digest()
+        d = _H(self.digest + self.counter.to_bytes(4, "big")).digest()
         self.counter += 1
         return [int.from_bytes(d[4 * i:4 * i + 4], "big") for i in range(8)]
 
@@ -302,10 +306,12 @@ class Channel:
 
 
 def prove(n_cols: int = 4, trace_log: int = 9, log_blowup: int = 4, n_queries: int = 16,
-          pow_bits: int = 5, verbose: bool = False, seed: int = 0) -> dict:
+          pow_bits: int = 5, verbose: bool = False, seed: int = 0, hash: str = "sha256") -> dict:
     """seed = 0 is the external prover's trace (row r starts 1, r); other seeds start row r at
     (1, r + seed * 0x9E3779B1) -- any start satisfies the wide-Fibonacci transition constraints
     (constraints/wide_fibonacci.simf:24-38), so every seed gives a distinct valid proof."""
+    global _H
+    _H = HASHES[hash]
     t_start = time.time()
 
     def log(msg):
@@ -327,7 +333,7 @@ def prove(n_cols: int = 4, trace_log: int = 9, log_blowup: int = 4, n_queries: i
     lde = np.stack([fft(c, dom_L) for c in coefs], axis=1)  # [2^L, N]
     log("trace LDE")
     trace_tree = merkle_levels(hash_rows(lde))
-    const_root = hashlib.sha256(b"").digest()
+    const_root = _H(b"").digest()
     trace_root = trace_tree[-1][0].tobytes()
     log("trace tree")
     ch.mix_u256(const_root)
@@ -447,7 +453,7 @@ def prove(n_cols: int = 4, trace_log: int = 9, log_blowup: int = 4, n_queries: i
     target = (1 << (64 - pow_bits)) - 1
     nonce = 0
     while True:
-        d = hashlib.sha256(ch.digest + nonce.to_bytes(8, "big")).digest()
+        d = _H(ch.digest + nonce.to_bytes(8, "big")).digest()
         if int.from_bytes(d[24:32], "little") < target:
             break
         nonce += 1
@@ -485,10 +491,13 @@ def prove(n_cols: int = 4, trace_log: int = 9, log_blowup: int = 4, n_queries: i
                          "decommitment": {"hash_witness": hwl, "column_witness": []},
                          "commitment": [int(b) for b in fri_roots[l]]})
     log("decommit")
+    conf = {"pow_bits": pow_bits,
+            "fri_config": {"log_blowup_factor": log_blowup, "log_last_layer_degree_bound": 0,
+                           "n_queries": n_queries}}
+    if hash != "sha256":
+        conf["hash"] = hash  # extension: the reference's proofs are always SHA-256
     return {
-        "config": {"pow_bits": pow_bits,
-                   "fri_config": {"log_blowup_factor": log_blowup, "log_last_layer_degree_bound": 0,
-                                  "n_queries": n_queries}},
+        "config": conf,
         "commitments": [[int(b) for b in const_root], [int(b) for b in trace_root],
                         [int(b) for b in cp_root]],
         "sampled_values": [[], [[qj(v)] for v in oods_trace], [[qj(v)] for v in oods_cp]],
@@ -522,6 +531,7 @@ def main():
     ap.add_argument("--n-queries", type=int, default=16)
     ap.add_argument("--pow-bits", type=int, default=5)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--hash", choices=["sha256", "blake2s"], default="sha256")
     ap.add_argument("-o", "--out", default="-")
     args = ap.parse_args()
     here = os.path.dirname(os.path.abspath(__file__))
@@ -529,7 +539,7 @@ def main():
         self_check(os.path.join(here, "..", "tests", "golden"))
         return
     proof = prove(args.n_cols, args.trace_log, args.log_blowup, args.n_queries, args.pow_bits,
-                  verbose=True, seed=args.seed)
+                  verbose=True, seed=args.seed, hash=args.hash)
     text = json.dumps(proof)
     if args.out == "-":
         print(text)
