@@ -17,6 +17,8 @@ Workloads (`--workload`):
                  16 queries) replicated -- used when the 2^20 fixture is absent.
   stwo_2p16      BASELINE.json configs[2]: 2^16 trace, 32 queries.
   stwo_wide256   BASELINE.json configs[4]: 256 columns, LDE 2^18.
+  stwo_2p20_blake2s  the metric config with Blake2s-256 as the hash (BASELINE.json says "Blake2s
+                 Merkle"; the reference has no Blake2s, so this variant's parity is unpinned).
   stark101       BASELINE.json configs[1]: the stark101 proof x 4096.
 """
 from __future__ import annotations
@@ -38,6 +40,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E spec peak
 # the whole chip (tools/sha_bench.hip, measured on MI355X: 34.7 G/s; rotates are half-rate
 # v_alignbit_b32, see tools/valu_bench.hip and DESIGN.md section 5).
 SHA_CALIBRATED_PEAK = 34.7e9
+B2S_CALIBRATED_PEAK = 38.9e9  # Blake2s-256 compressions/s, same tool (one compression per node)
 
 
 def load_workload(name: str):
@@ -51,13 +54,14 @@ def load_workload(name: str):
         from stark_symphony_amd import records
         proofs = records.load_stwo_npz(big)
         return name, "stwo", proofs, "wide-Fibonacci 2^20 x 4, LDE 2^24, Q=16, K=19, SHA-256"
-    if name in ("stwo_2p16", "stwo_wide256"):
+    if name in ("stwo_2p16", "stwo_wide256", "stwo_2p20_blake2s"):
         from stark_symphony_amd import records
-        fn = {"stwo_2p16": "stwo_trace16.npz", "stwo_wide256": "stwo_wide256.npz"}[name]
+        fn = {"stwo_2p16": "stwo_trace16.npz", "stwo_wide256": "stwo_wide256.npz",
+              "stwo_2p20_blake2s": "stwo_trace20_blake2s.npz"}[name]
         proofs = records.load_stwo_npz(os.path.join(GOLDEN, fn))
         c = proofs[0].cfg
-        return name, "stwo", proofs, "wide-Fibonacci 2^%d x %d, LDE 2^%d, Q=%d, K=%d, SHA-256" % (
-            c.trace_log, c.n_cols, c.lde_log, c.n_queries, c.n_layers)
+        return name, "stwo", proofs, "wide-Fibonacci 2^%d x %d, LDE 2^%d, Q=%d, K=%d, %s" % (
+            c.trace_log, c.n_cols, c.lde_log, c.n_queries, c.n_layers, c.hash)
     if name == "stwo_fixture":
         p = ss.stwo_from_json(json.load(open(os.path.join(GOLDEN, "stwo_proof.json"))))
         return name, "stwo", [p], "reference proof.json (trace 2^9, LDE 2^13, Q=16, K=8) replicated"
@@ -147,11 +151,14 @@ def main() -> None:
         batch = ver.stwo_batch(proofs, verifier.MODE_FIXTURE, replicate=reps)
         bytes_per_proof, compr_per_proof = cfg.packed_bytes, cfg.compressions
         dominant = "stwo_merkle"
+        hash_name = cfg.hash
+        alu_peak = B2S_CALIBRATED_PEAK if cfg.hash == "blake2s" else SHA_CALIBRATED_PEAK
     else:
         per_gpu = args.proofs_per_gpu or 4096
         batch = ver.stark101_batch(proofs, replicate=per_gpu)
         bytes_per_proof, compr_per_proof = 7176, 480
         dominant = "s101_merkle"
+        hash_name, alu_peak = "sha256", SHA_CALIBRATED_PEAK
     n_local = batch.n
 
     # `--inflight` run slots over the same resident batch, pipelined on a head and a tail stream:
@@ -217,7 +224,7 @@ def main() -> None:
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": wname, "note": note, "proofs_per_gpu": n_local,
                        "distinct_proofs": len(proofs), "bytes_per_proof": bytes_per_proof,
-                       "sha256_compressions_per_proof": compr_per_proof, "hash": "sha256",
+                       "hash_compressions_per_proof": compr_per_proof, "hash": hash_name,
                        "mode": "fixture_correct", "inflight_streams": nslot,
                        "parallelism": "proofs sharded over %d GPU(s)" % world},
             "hbm_gb_s": value * bytes_per_proof / 1e9,
@@ -226,11 +233,11 @@ def main() -> None:
                          "traffic": pmc_traffic(wname, n_local),
                          "kernel_avg_ms": k_avg_s * 1e3, "kernel_launches": k_n,
                          "algorithmic_bytes_per_launch": launch_bytes,
-                         "note": "integer-ALU bound by construction (2 SHA-256 compressions per "
-                                 "32-byte sibling); see alu_roofline"},
-            "alu_roofline": {"sha256_compressions_per_s": compr_s,
-                             "calibrated_peak_compressions_per_s": SHA_CALIBRATED_PEAK,
-                             "frac": compr_s / SHA_CALIBRATED_PEAK,
+                         "note": "integer-ALU bound by construction (2 SHA-256 / 1 Blake2s compression "
+                                 "per 32-byte sibling); see alu_roofline"},
+            "alu_roofline": {"hash_compressions_per_s": compr_s,
+                             "calibrated_peak_compressions_per_s": alu_peak,
+                             "frac": compr_s / alu_peak,
                              "note": "peak = tools/sha_bench.hip (registers only) on MI355X, "
                                      "profiles/r01_sha_calibration.txt"},
             "kernels_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in timing.items()},

@@ -35,6 +35,8 @@ static int set_err(int code, const char *fmt, ...)
             return set_err(SS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));    \
     } while (0)
 
+extern "C" int ss_internal_set_err(int code, const char *msg) { return set_err(code, "%s", msg); }
+
 extern "C" int ss_version(void) { return SS_VERSION; }
 extern "C" const char *ss_last_error(void) { return g_err; }
 

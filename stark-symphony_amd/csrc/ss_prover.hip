@@ -1,0 +1,429 @@
+// GPU building blocks of the wide-Fibonacci circle-STARK prover (include/ss_prover.h).
+//
+// Each kernel is one data-parallel step of tools/stwo_prover.py (the numpy prover that
+// reproduces the reference's proofs byte for byte); stark-symphony_amd/prover.py chains them.
+// All arithmetic is exact M31 / QM31 on canonical words, so any evaluation order gives the same
+// bits as the numpy code.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+
+#include "../../include/ss_prover.h"
+#include "ss_fields.h"
+#include "ss_hash.h"
+#include "ss_layout.h"
+
+using namespace ss;
+
+extern "C" int ss_internal_set_err(int code, const char *msg);
+
+#define P_TRY(expr)                                                                  \
+    do {                                                                             \
+        hipError_t e_ = (expr);                                                      \
+        if (e_ != hipSuccess) {                                                      \
+            char buf_[256];                                                          \
+            snprintf(buf_, sizeof buf_, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+            return ss_internal_set_err(SS_ERR_HIP, buf_);                            \
+        }                                                                            \
+    } while (0)
+
+static inline unsigned blocks_for(uint64_t n, unsigned bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+
+namespace ss {
+
+__device__ __forceinline__ QM31 ldq(const uint32_t *p) { return QM31{p[0], p[1], p[2], p[3]}; }
+__device__ __forceinline__ void stq(uint32_t *p, QM31 v) { p[0] = v.a; p[1] = v.b; p[2] = v.c; p[3] = v.d; }
+
+// ---------------------------------------------------------------------------------- trace
+__global__ void p_trace_kernel(uint32_t n, uint32_t n_cols, uint32_t seed_term, uint32_t *__restrict__ out)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    uint32_t a = 1, b = m31_add(m31_red(r), seed_term);
+    out[r] = a;
+    if (n_cols > 1) out[(size_t)n + r] = b;
+    for (uint32_t k = 2; k < n_cols; k++) {
+        uint32_t c = m31_add(m31_sqr(b), m31_sqr(a));
+        out[(size_t)k * n + r] = c;
+        a = b;
+        b = c;
+    }
+}
+
+// ------------------------------------------------------------------------------- twiddles
+// Half coset of the canonic coset of log size m: index 2^(30-m) + j 2^(32-m); storage pair h
+// is the natural position bitrev(h, m-1) (groups/circle_domain.simf:17-37).
+__global__ void p_twiddles_kernel(uint32_t m, uint32_t *__restrict__ tw, uint32_t *__restrict__ itw,
+                                  uint32_t *__restrict__ hx_out)
+{
+    const uint32_t half = 1u << (m - 1);
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= half) return;
+    const uint32_t j = m > 1 ? (__brev(h) >> (32 - (m - 1))) : 0;
+    const uint32_t idx = ((1u << (30 - m)) + j * (1u << (32 - m))) & 0x7fffffffu;
+    const M31Point pt = circle_point(idx);
+    uint32_t inv;
+    tw[h] = pt.y;
+    m31_inv(pt.y, inv);
+    itw[h] = inv;
+    if (hx_out) hx_out[h] = pt.x;
+    uint32_t cur = pt.x;
+    for (uint32_t i = 1; i < m; i++) {
+        if (h & ((1u << i) - 1)) break;
+        const size_t off = ((size_t)1 << m) - ((size_t)1 << (m - i));
+        tw[off + (h >> i)] = cur;
+        m31_inv(cur, inv);
+        itw[off + (h >> i)] = inv;
+        cur = m31_dbl_x(cur);
+    }
+}
+
+// ------------------------------------------------------------------------------------ fft
+// One butterfly layer over `ncols` columns; t indexes the 2^(m-1) butterflies of a column.
+__global__ void p_fft_layer_kernel(uint32_t m, uint32_t layer, uint32_t *__restrict__ data,
+                                   const uint32_t *__restrict__ tw, int inverse, uint32_t scale)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (1u << (m - 1))) return;
+    uint32_t *col = data + ((size_t)blockIdx.y << m);
+    const uint32_t h = t >> layer, l = t & ((1u << layer) - 1);
+    const size_t i0 = ((size_t)h << (layer + 1)) + l, i1 = i0 + ((size_t)1 << layer);
+    const size_t off = ((size_t)1 << m) - ((size_t)1 << (m - layer));
+    const uint32_t w = tw[off + h];
+    uint32_t v0 = col[i0], v1 = col[i1];
+    if (inverse) {
+        uint32_t s = m31_add(v0, v1), d = m31_mul(m31_sub(v0, v1), w);
+        if (scale != 1) { s = m31_mul(s, scale); d = m31_mul(d, scale); }
+        col[i0] = s;
+        col[i1] = d;
+    } else {
+        const uint32_t x = m31_mul(v1, w);
+        col[i0] = m31_add(v0, x);
+        col[i1] = m31_sub(v0, x);
+    }
+}
+
+// --------------------------------------------------------------------------------- hashing
+template <int HF>
+__global__ void p_hash_rows_kernel(size_t n, uint32_t w, const uint32_t *__restrict__ cols, size_t stride,
+                                   uint32_t *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t d[8];
+    Hasher<HF>::template stream<true, 0>(nullptr, [&](uint32_t k) { return cols[(size_t)k * stride + i]; }, w, d);
+    uint4 *o = reinterpret_cast<uint4 *>(out + i * 8);
+    o[0] = make_uint4(Hasher<HF>::native(d[0]), Hasher<HF>::native(d[1]), Hasher<HF>::native(d[2]), Hasher<HF>::native(d[3]));
+    o[1] = make_uint4(Hasher<HF>::native(d[4]), Hasher<HF>::native(d[5]), Hasher<HF>::native(d[6]), Hasher<HF>::native(d[7]));
+}
+
+template <int HF>
+__global__ void p_hash_qm31_kernel(size_t n, const uint32_t *__restrict__ vals, uint32_t *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 v = reinterpret_cast<const uint4 *>(vals)[i];
+    const uint32_t e[4] = {v.x, v.y, v.z, v.w};
+    uint32_t d[8];
+    Hasher<HF>::template block<true, 0, 4>(nullptr, e, d);
+    uint4 *o = reinterpret_cast<uint4 *>(out + i * 8);
+    o[0] = make_uint4(Hasher<HF>::native(d[0]), Hasher<HF>::native(d[1]), Hasher<HF>::native(d[2]), Hasher<HF>::native(d[3]));
+    o[1] = make_uint4(Hasher<HF>::native(d[4]), Hasher<HF>::native(d[5]), Hasher<HF>::native(d[6]), Hasher<HF>::native(d[7]));
+}
+
+template <int HF>
+__global__ void p_merkle_level_kernel(size_t n_parents, const uint32_t *__restrict__ children,
+                                      uint32_t *__restrict__ parents)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_parents) return;
+    const uint4 *c = reinterpret_cast<const uint4 *>(children + i * 16);
+    const uint4 a0 = c[0], a1 = c[1], b0 = c[2], b1 = c[3];
+    const uint32_t l[8] = {Hasher<HF>::native(a0.x), Hasher<HF>::native(a0.y), Hasher<HF>::native(a0.z),
+                           Hasher<HF>::native(a0.w), Hasher<HF>::native(a1.x), Hasher<HF>::native(a1.y),
+                           Hasher<HF>::native(a1.z), Hasher<HF>::native(a1.w)};
+    const uint32_t r[8] = {Hasher<HF>::native(b0.x), Hasher<HF>::native(b0.y), Hasher<HF>::native(b0.z),
+                           Hasher<HF>::native(b0.w), Hasher<HF>::native(b1.x), Hasher<HF>::native(b1.y),
+                           Hasher<HF>::native(b1.z), Hasher<HF>::native(b1.w)};
+    uint32_t d[8];
+    Hasher<HF>::template pair<true>(l, r, d);
+    uint4 *o = reinterpret_cast<uint4 *>(parents + i * 8);
+    o[0] = make_uint4(Hasher<HF>::native(d[0]), Hasher<HF>::native(d[1]), Hasher<HF>::native(d[2]), Hasher<HF>::native(d[3]));
+    o[1] = make_uint4(Hasher<HF>::native(d[4]), Hasher<HF>::native(d[5]), Hasher<HF>::native(d[6]), Hasher<HF>::native(d[7]));
+}
+
+// ----------------------------------------------------------------------------- composition
+__global__ void p_composition_kernel(uint32_t n_log, uint32_t n_cols, const uint32_t *__restrict__ ev,
+                                     const uint32_t *__restrict__ hx, QM31 alpha, uint32_t *__restrict__ out)
+{
+    const uint32_t size = 1u << (n_log + 1);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= size) return;
+    uint32_t van = hx[i >> 1];
+    for (uint32_t k = 1; k < n_log; k++) van = m31_dbl_x(van);
+    uint32_t van_inv;
+    m31_inv(van, van_inv);
+    QM31 acc = qm31_zero();
+    uint32_t a = ev[i], b = n_cols > 1 ? ev[(size_t)size + i] : 0;
+    for (uint32_t k = 2; k < n_cols; k++) {
+        const uint32_t c = ev[(size_t)k * size + i];
+        const uint32_t cons = m31_sub(c, m31_add(m31_sqr(b), m31_sqr(a)));
+        acc = qm31_mul(acc, alpha);
+        acc.a = m31_add(acc.a, cons);
+        a = b;
+        b = c;
+    }
+    out[i] = m31_mul(acc.a, van_inv);
+    out[(size_t)size + i] = m31_mul(acc.b, van_inv);
+    out[(size_t)2 * size + i] = m31_mul(acc.c, van_inv);
+    out[(size_t)3 * size + i] = m31_mul(acc.d, van_inv);
+}
+
+// -------------------------------------------------------------------------- eval at point
+__global__ void p_fold_m31_kernel(size_t n_out, const uint32_t *__restrict__ in, QM31 f, uint32_t *__restrict__ out)
+{
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_out) return;
+    QM31 r = qm31_mul_m31(f, in[2 * j + 1]);
+    r.a = m31_add(r.a, in[2 * j]);
+    stq(out + 4 * j, r);
+}
+__global__ void p_fold_qm31_kernel(size_t n_out, const uint32_t *__restrict__ in, QM31 f, uint32_t *__restrict__ out)
+{
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_out) return;
+    stq(out + 4 * j, qm31_add(ldq(in + 8 * j), qm31_mul(ldq(in + 8 * j + 4), f)));
+}
+
+// ------------------------------------------------------------------------------ quotients
+struct QuotArgs {
+    QM31 px, py, p2x, p2y, a1, c1, a2, c2, alpha16;
+};
+
+__device__ __forceinline__ CM31 deep_den_inv(QM31 sx, QM31 sy, uint32_t x, uint32_t y)
+{
+    // deep/quotients.simf:15-22
+    CM31 dx = cm31_sub_m31(q_re(sx), x), dy = cm31_sub_m31(q_re(sy), y);
+    CM31 d = cm31_sub(cm31_mul(dx, q_im(sy)), cm31_mul(dy, q_im(sx)));
+    CM31 inv;
+    cm31_inv(d, inv);
+    return inv;
+}
+
+__global__ void p_quotients_kernel(uint32_t lde_log, uint32_t n_cols, const uint32_t *__restrict__ trace_lde,
+                                   const uint32_t *__restrict__ cp_lde, const uint32_t *__restrict__ hx,
+                                   const uint32_t *__restrict__ hy, const uint32_t *__restrict__ bcoef, QuotArgs q,
+                                   uint32_t *__restrict__ out)
+{
+    const size_t size = (size_t)1 << lde_log;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= size) return;
+    const uint32_t x = hx[i >> 1];
+    uint32_t y = hy[i >> 1];
+    if (i & 1) y = m31_sub(0, y);
+    QM31 s1 = qm31_zero(), s2 = qm31_zero();
+    for (uint32_t k = 0; k < n_cols; k++)
+        s1 = qm31_add(s1, qm31_mul_m31(ldq(bcoef + 4 * k), trace_lde[(size_t)k * size + i]));
+    for (uint32_t k = 0; k < kCp; k++)
+        s2 = qm31_add(s2, qm31_mul_m31(ldq(bcoef + 4 * (n_cols + k)), cp_lde[(size_t)k * size + i]));
+    QM31 n1 = qm31_sub(s1, qm31_add(qm31_mul_m31(q.a1, y), q.c1));
+    QM31 n2 = qm31_sub(s2, qm31_add(qm31_mul_m31(q.a2, y), q.c2));
+    QM31 b1 = qm31_mul_cm31(n1, deep_den_inv(q.px, q.py, x, y));
+    QM31 b2 = qm31_mul_cm31(n2, deep_den_inv(q.p2x, q.p2y, x, y));
+    stq(out + 4 * i, qm31_add(qm31_mul(b1, q.alpha16), b2));
+}
+
+// ------------------------------------------------------------------------------- fri fold
+__global__ void p_fri_fold_kernel(size_t n_out, const uint32_t *__restrict__ in, const uint32_t *__restrict__ cinv,
+                                  QM31 alpha, uint32_t *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    const QM31 v0 = ldq(in + 8 * i), v1 = ldq(in + 8 * i + 4);
+    const QM31 f0 = qm31_add(v0, v1);
+    const QM31 f1 = qm31_mul_m31(qm31_sub(v0, v1), cinv[i]);
+    stq(out + 4 * i, qm31_add(f0, qm31_mul(f1, alpha)));
+}
+
+// ------------------------------------------------------------------------------------ pow
+template <int HF>
+__global__ void p_pow_kernel(Dig digest_native, uint64_t target, uint64_t start, uint64_t count,
+                             unsigned long long *__restrict__ best)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const uint64_t nonce = start + t;
+    const uint32_t m[2] = {(uint32_t)(nonce >> 32), (uint32_t)nonce};
+    uint32_t d[8];
+    Hasher<HF>::template block<true, 8, 2>(digest_native.v, m, d);
+    if (Hasher<HF>::pow_value(d) < target) atomicMin(best, (unsigned long long)nonce);
+}
+
+}  // namespace ss
+
+// =============================================================================== C ABI
+static QM31 q4(const uint32_t v[4]) { return QM31{v[0], v[1], v[2], v[3]}; }
+
+extern "C" int ss_p_trace(ss_ctx *, uint32_t n_log, uint32_t n_cols, uint32_t seed_term, uint32_t *cols_out,
+                          void *stream)
+{
+    if (!cols_out || n_log > 26 || !n_cols) return ss_internal_set_err(SS_ERR_ARG, "ss_p_trace: bad argument");
+    const uint32_t n = 1u << n_log;
+    hipLaunchKernelGGL(p_trace_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, n, n_cols,
+                       seed_term % M31_P, cols_out);
+    P_TRY(hipGetLastError());
+    return SS_OK;
+}
+
+extern "C" int ss_p_twiddles(ss_ctx *, uint32_t m, uint32_t *tw_out, uint32_t *itw_out, uint32_t *hx_out,
+                             void *stream)
+{
+    if (!tw_out || !itw_out || m < 1 || m > 28) return ss_internal_set_err(SS_ERR_ARG, "ss_p_twiddles: bad argument");
+    hipLaunchKernelGGL(p_twiddles_kernel, dim3(blocks_for(1u << (m - 1))), dim3(256), 0, (hipStream_t)stream, m,
+                       tw_out, itw_out, hx_out);
+    P_TRY(hipGetLastError());
+    return SS_OK;
+}
+
+extern "C" int ss_p_fft(ss_ctx *, uint32_t m, uint32_t ncols, uint32_t *data, const uint32_t *tw, int inverse,
+                        void *stream)
+{
+    if (!data || !tw || m < 1 || m > 28 || !ncols) return ss_internal_set_err(SS_ERR_ARG, "ss_p_fft: bad argument");
+    const dim3 grid(blocks_for(1u << (m - 1)), ncols);
+    if (inverse) {
+        // 2^-m mod P = 2^(31-m) because 2^31 == 1
+        const uint32_t scale = (1u << ((31 - (m % 31)) % 31)) % M31_P;
+        for (uint32_t i = 0; i < m; i++)
+            hipLaunchKernelGGL(p_fft_layer_kernel, grid, dim3(256), 0, (hipStream_t)stream, m, i, data, tw, 1,
+                               i + 1 == m ? scale : 1u);
+    } else {
+        for (uint32_t i = m; i-- > 0;)
+            hipLaunchKernelGGL(p_fft_layer_kernel, grid, dim3(256), 0, (hipStream_t)stream, m, i, data, tw, 0, 1u);
+    }
+    P_TRY(hipGetLastError());
+    return SS_OK;
+}
+
+extern "C" int ss_p_hash_rows(ss_ctx *, uint32_t hash, size_t n, uint32_t w, const uint32_t *cols,
+                              size_t col_stride, uint32_t *out, void *stream)
+{
+    if (!cols || !out || !n || !w || hash > 1) return ss_internal_set_err(SS_ERR_ARG, "ss_p_hash_rows: bad argument");
+    if (hash)
+        hipLaunchKernelGGL(p_hash_rows_kernel<1>, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, n, w, cols,
+                           col_stride, out);
+    else
+        hipLaunchKernelGGL(p_hash_rows_kernel<0>, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, n, w, cols,
+                           col_stride, out);
+    P_TRY(hipGetLastError());
+    return SS_OK;
+}
+
+extern "C" int ss_p_hash_qm31(ss_ctx *, uint32_t hash, size_t n, const uint32_t *vals, uint32_t *out, void *stream)
+{
+    if (!vals || !out || !n || hash > 1) return ss_internal_set_err(SS_ERR_ARG, "ss_p_hash_qm31: bad argument");
+    if (hash)
+        hipLaunchKernelGGL(p_hash_qm31_kernel<1>, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, n, vals, out);
+    else
+        hipLaunchKernelGGL(p_hash_qm31_kernel<0>, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, n, vals, out);
+    P_TRY(hipGetLastError());
+    return SS_OK;
+}
+
+extern "C" int ss_p_merkle(ss_ctx *, uint32_t hash, size_t n_leaves, uint32_t *levels, void *stream)
+{
+    if (!levels || !n_leaves || (n_leaves & (n_leaves - 1)) || hash > 1)
+        return ss_internal_set_err(SS_ERR_ARG, "ss_p_merkle: bad argument");
+    size_t off = 0;
+    for (size_t n = n_leaves; n > 1; n >>= 1) {
+        const size_t parents = n >> 1;
+        uint32_t *children = levels + off * 8, *out = levels + (off + n) * 8;
+        if (hash)
+            hipLaunchKernelGGL(p_merkle_level_kernel<1>, dim3(blocks_for(parents)), dim3(256), 0, (hipStream_t)stream,
+                               parents, children, out);
+        else
+            hipLaunchKernelGGL(p_merkle_level_kernel<0>, dim3(blocks_for(parents)), dim3(256), 0, (hipStream_t)stream,
+                               parents, children, out);
+        off += n;
+    }
+    P_TRY(hipGetLastError());
+    return SS_OK;
+}
+
+extern "C" int ss_p_composition(ss_ctx *, uint32_t n_log, uint32_t n_cols, const uint32_t *ev, const uint32_t *hx_c,
+                                const uint32_t alpha[4], uint32_t *out, void *stream)
+{
+    if (!ev || !hx_c || !alpha || !out || n_log < 1 || n_log > 26)
+        return ss_internal_set_err(SS_ERR_ARG, "ss_p_composition: bad argument");
+    hipLaunchKernelGGL(p_composition_kernel, dim3(blocks_for(1u << (n_log + 1))), dim3(256), 0, (hipStream_t)stream,
+                       n_log, n_cols, ev, hx_c, q4(alpha), out);
+    P_TRY(hipGetLastError());
+    return SS_OK;
+}
+
+// factors: m QM31 values on the HOST (y, x, pi(x), pi^2(x), ...), bit 0 first
+extern "C" int ss_p_eval_at_point(ss_ctx *, uint32_t m, const uint32_t *coeffs, const uint32_t *factors_host,
+                                  uint32_t *scratch, uint32_t *out, void *stream)
+{
+    if (!coeffs || !factors_host || !scratch || !out || m < 1 || m > 28)
+        return ss_internal_set_err(SS_ERR_ARG, "ss_p_eval_at_point: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    size_t n = (size_t)1 << (m - 1);
+    uint32_t *a = scratch, *b = scratch + 4 * n;  // ping-pong: a holds n QM31, b n/2
+    hipLaunchKernelGGL(p_fold_m31_kernel, dim3(blocks_for(n)), dim3(256), 0, s, n, coeffs, q4(factors_host),
+                       m == 1 ? out : a);
+    uint32_t *src = a, *dst = b;
+    for (uint32_t lvl = 1; lvl < m; lvl++) {
+        n >>= 1;
+        hipLaunchKernelGGL(p_fold_qm31_kernel, dim3(blocks_for(n)), dim3(256), 0, s, n, src,
+                           q4(factors_host + 4 * lvl), lvl + 1 == m ? out : dst);
+        uint32_t *t = src; src = dst; dst = t;
+    }
+    P_TRY(hipGetLastError());
+    return SS_OK;
+}
+
+extern "C" int ss_p_quotients(ss_ctx *, uint32_t lde_log, uint32_t n_cols, const uint32_t *trace_lde,
+                              const uint32_t *cp_lde, const uint32_t *hx_hy, const uint32_t *bcoef,
+                              const uint32_t p[8], const uint32_t p2[8], const uint32_t sums_alpha16[20],
+                              uint32_t *out, void *stream)
+{
+    if (!trace_lde || !cp_lde || !hx_hy || !bcoef || !p || !p2 || !sums_alpha16 || !out || lde_log < 2 || lde_log > 28)
+        return ss_internal_set_err(SS_ERR_ARG, "ss_p_quotients: bad argument");
+    QuotArgs q;
+    q.px = q4(p); q.py = q4(p + 4); q.p2x = q4(p2); q.p2y = q4(p2 + 4);
+    q.a1 = q4(sums_alpha16); q.c1 = q4(sums_alpha16 + 4); q.a2 = q4(sums_alpha16 + 8); q.c2 = q4(sums_alpha16 + 12);
+    q.alpha16 = q4(sums_alpha16 + 16);
+    const size_t half = (size_t)1 << (lde_log - 1);
+    hipLaunchKernelGGL(p_quotients_kernel, dim3(blocks_for((size_t)1 << lde_log)), dim3(256), 0, (hipStream_t)stream,
+                       lde_log, n_cols, trace_lde, cp_lde, hx_hy, hx_hy + half, bcoef, q, out);
+    P_TRY(hipGetLastError());
+    return SS_OK;
+}
+
+extern "C" int ss_p_fri_fold(ss_ctx *, size_t n_out, const uint32_t *in, const uint32_t *coord_inv,
+                             const uint32_t alpha[4], uint32_t *out, void *stream)
+{
+    if (!in || !coord_inv || !alpha || !out || !n_out) return ss_internal_set_err(SS_ERR_ARG, "ss_p_fri_fold: bad argument");
+    hipLaunchKernelGGL(p_fri_fold_kernel, dim3(blocks_for(n_out)), dim3(256), 0, (hipStream_t)stream, n_out, in,
+                       coord_inv, q4(alpha), out);
+    P_TRY(hipGetLastError());
+    return SS_OK;
+}
+
+extern "C" int ss_p_pow(ss_ctx *, uint32_t hash, const uint32_t digest[8], uint64_t target, uint64_t start,
+                        uint64_t count, uint64_t *nonce_out_dev, void *stream)
+{
+    if (!digest || !nonce_out_dev || !count || hash > 1) return ss_internal_set_err(SS_ERR_ARG, "ss_p_pow: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    P_TRY(hipMemsetAsync(nonce_out_dev, 0xff, 8, s));
+    Dig d;
+    for (int i = 0; i < 8; i++) d.v[i] = hash ? __builtin_bswap32(digest[i]) : digest[i];
+    if (hash)
+        hipLaunchKernelGGL(p_pow_kernel<1>, dim3(blocks_for(count)), dim3(256), 0, s, d, target, start, count,
+                           (unsigned long long *)nonce_out_dev);
+    else
+        hipLaunchKernelGGL(p_pow_kernel<0>, dim3(blocks_for(count)), dim3(256), 0, s, d, target, start, count,
+                           (unsigned long long *)nonce_out_dev);
+    P_TRY(hipGetLastError());
+    return SS_OK;
+}

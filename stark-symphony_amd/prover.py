@@ -1,0 +1,404 @@
+"""GPU wide-Fibonacci circle-STARK prover.
+
+Chains the kernels of include/ss_prover.h into the protocol of the external stwo fork that made
+the reference's proofs (stwo-verifier/tests/data/proof*.json): trace -> circle iFFT/LDE ->
+Merkle commit -> composition polynomial in 16 partition columns -> OODS samples at P / 2P ->
+two-batch DEEP quotients -> FRI commit -> proof of work -> queries -> decommit.  The
+Fiat-Shamir channel (a few dozen hashes) and the O(columns) scalar QM31 algebra stay on the
+host; everything proportional to the domain size runs in HIP kernels.
+
+Output: the reference's `proof.json` schema (format C), byte for byte equal to
+tools/stwo_prover.py -- and therefore to the reference's two fixtures
+(tests/test_gpu_prover.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import hashlib
+import time
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import binding as B
+
+P = (1 << 31) - 1
+Q4 = Tuple[int, int, int, int]
+HASHES = {"sha256": hashlib.sha256, "blake2s": lambda b=b"": hashlib.blake2s(b, digest_size=32)}
+
+
+# ------------------------------------------------------------- host QM31 scalars (Python ints)
+def _cmul(a, b):
+    return ((a[0] * b[0] - a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+
+
+def qmul(x: Q4, y: Q4) -> Q4:
+    ac = _cmul(x[0:2], y[0:2])
+    bd = _cmul(x[2:4], y[2:4])
+    r = _cmul(bd, (2, 1))
+    ad = _cmul(x[0:2], y[2:4])
+    bc = _cmul(x[2:4], y[0:2])
+    return ((ac[0] + r[0]) % P, (ac[1] + r[1]) % P, (ad[0] + bc[0]) % P, (ad[1] + bc[1]) % P)
+
+
+def qadd(x: Q4, y: Q4) -> Q4:
+    return tuple((a + b) % P for a, b in zip(x, y))
+
+
+def qsub(x: Q4, y: Q4) -> Q4:
+    return tuple((a - b) % P for a, b in zip(x, y))
+
+
+def _cinv(a):
+    n = pow((a[0] * a[0] + a[1] * a[1]) % P, P - 2, P)
+    return (a[0] * n % P, (-a[1]) * n % P)
+
+
+def qinv(x: Q4) -> Q4:
+    a2 = _cmul(x[0:2], x[0:2])
+    b2 = _cmul(x[2:4], x[2:4])
+    t = _cmul(b2, (2, 1))
+    den = ((a2[0] - t[0]) % P, (a2[1] - t[1]) % P)
+    di = _cinv(den)
+    re = _cmul(x[0:2], di)
+    im = _cmul(((-x[2]) % P, (-x[3]) % P), di)
+    return (re[0], re[1], im[0], im[1])
+
+
+ONE: Q4 = (1, 0, 0, 0)
+ZERO: Q4 = (0, 0, 0, 0)
+
+
+def _interpolant(sp_y: Q4, value: Q4, alpha_i: Q4):
+    """deep/quotients.simf:25-36 on canonical values."""
+    a0 = (0, 0, (-2 * value[2]) % P, (-2 * value[3]) % P)
+    b0 = (0, 0, (-2 * sp_y[2]) % P, (-2 * sp_y[3]) % P)
+    c0 = qsub(qmul(b0, value), qmul(a0, sp_y))
+    return qmul(alpha_i, a0), qmul(alpha_i, b0), qmul(alpha_i, c0)
+
+
+class _Channel:
+    """stwo-verifier/src/channel.simf:31-172 (host side of the Fiat-Shamir transcript)."""
+
+    def __init__(self, h):
+        self.h = h
+        self.digest = bytes(32)
+        self.counter = 0
+
+    def mix(self, b: bytes) -> None:
+        self.digest = self.h(self.digest + b).digest()
+        self.counter = 0
+
+    def draw_words(self) -> List[int]:
+        d = self.h(self.digest + self.counter.to_bytes(4, "big")).digest()
+        self.counter += 1
+        return [int.from_bytes(d[4 * i:4 * i + 4], "big") for i in range(8)]
+
+    def draw_qm31(self) -> Q4:
+        while True:
+            w = self.draw_words()
+            if all(x < 4294967294 for x in w[:4]):
+                return tuple(x % P for x in w[:4])
+
+
+def _be(words: Sequence[int]) -> bytes:
+    return b"".join(int(w).to_bytes(4, "big") for w in words)
+
+
+class GpuProver:
+    """Proves on one MI355X through the ss_p_* kernels.  `ver` is a verifier.Verifier (it owns
+    the library context and the device)."""
+
+    def __init__(self, ver):
+        import torch
+        self.torch = torch
+        self.ver = ver
+        self.dev = ver.device
+        self.lib = B.lib()
+        u32p, vp, sz = C.c_void_p, C.c_void_p, C.c_size_t
+        L = self.lib
+
+        def sig(name, *args):
+            f = getattr(L, name)
+            f.restype = C.c_int
+            f.argtypes = [vp] + list(args) + [vp]
+        sig("ss_p_trace", C.c_uint32, C.c_uint32, C.c_uint32, u32p)
+        sig("ss_p_twiddles", C.c_uint32, u32p, u32p, u32p)
+        sig("ss_p_fft", C.c_uint32, C.c_uint32, u32p, u32p, C.c_int)
+        sig("ss_p_hash_rows", C.c_uint32, sz, C.c_uint32, u32p, sz, u32p)
+        sig("ss_p_hash_qm31", C.c_uint32, sz, u32p, u32p)
+        sig("ss_p_merkle", C.c_uint32, sz, u32p)
+        sig("ss_p_composition", C.c_uint32, C.c_uint32, u32p, u32p, u32p, u32p)
+        sig("ss_p_eval_at_point", C.c_uint32, u32p, u32p, u32p, u32p)
+        sig("ss_p_quotients", C.c_uint32, C.c_uint32, u32p, u32p, u32p, u32p, u32p, u32p, u32p, u32p)
+        sig("ss_p_fri_fold", sz, u32p, u32p, u32p, u32p)
+        sig("ss_p_pow", C.c_uint32, u32p, C.c_uint64, C.c_uint64, C.c_uint64, u32p)
+        self._dom: Dict[int, tuple] = {}
+        self.timings: Dict[str, float] = {}
+
+    # -- small helpers ---------------------------------------------------------------------
+    def _stream(self) -> int:
+        return int(self.torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def _empty(self, *shape):
+        return self.torch.empty(shape, dtype=self.torch.int32, device=self.dev)
+
+    def _zeros(self, *shape):
+        return self.torch.zeros(shape, dtype=self.torch.int32, device=self.dev)
+
+    @staticmethod
+    def _q(v: Q4):
+        return (C.c_uint32 * 4)(*[int(x) for x in v])
+
+    def _call(self, name: str, *args) -> None:
+        B.check(getattr(self.lib, name)(self.ver.ctx, *args, self._stream()))
+
+    def _host(self, t) -> np.ndarray:
+        return t.detach().cpu().numpy().view(np.uint32)
+
+    def domain(self, m: int):
+        """(tw, itw, hx_hy) of the canonic coset of log size m."""
+        if m not in self._dom:
+            tw, itw = self._empty(1 << m), self._empty(1 << m)
+            hxhy = self._empty(1 << m)
+            half = 1 << (m - 1)
+            self._call("ss_p_twiddles", m, tw.data_ptr(), itw.data_ptr(), hxhy.data_ptr())
+            hxhy[half:] = tw[:half]  # pair y = twiddle layer 0
+            self._dom[m] = (tw, itw, hxhy)
+        return self._dom[m]
+
+    def fft(self, m: int, data, inverse: bool) -> None:
+        tw, itw, _ = self.domain(m)
+        self._call("ss_p_fft", m, data.shape[0], data.data_ptr(), (itw if inverse else tw).data_ptr(),
+                   1 if inverse else 0)
+
+    def extend(self, coefs, m: int):
+        """Coefficients [ncols, 2^k] -> evaluations on the canonic coset of log size m."""
+        out = self._zeros(coefs.shape[0], 1 << m)
+        out[:, :coefs.shape[1]] = coefs
+        self.fft(m, out, False)
+        return out
+
+    def merkle(self, hsel: int, leaves_fn, n: int):
+        """levels[(2n - 1), 8]: leaves first, root last."""
+        levels = self._empty(2 * n, 8)
+        leaves_fn(levels)
+        self._call("ss_p_merkle", hsel, n, levels.data_ptr())
+        return levels
+
+    def _root(self, levels, n: int) -> bytes:
+        return self._host(levels[2 * n - 2]).astype(">u4").tobytes()
+
+    def _path(self, levels, n: int, index: int, skip: int = 0) -> List[List[int]]:
+        """Sibling hashes leaf -> root for `index` at level `skip` (bytes as int lists)."""
+        torch = self.torch
+        idxs, off, size, idx = [], 0, n, index
+        for _ in range(skip):
+            off += size
+            size >>= 1
+        while size > 1:
+            idxs.append(off + (idx ^ 1))
+            off += size
+            size >>= 1
+            idx >>= 1
+        if not idxs:
+            return []
+        rows = self._host(levels[torch.tensor(idxs, device=self.dev)])
+        return [[int(b) for b in r.astype(">u4").tobytes()] for r in rows]
+
+    # -- the protocol ----------------------------------------------------------------------
+    def prove(self, n_cols: int = 4, trace_log: int = 9, log_blowup: int = 4, n_queries: int = 16,
+              pow_bits: int = 5, seed: int = 0, hash: str = "sha256") -> dict:
+        torch = self.torch
+        t_start = time.perf_counter()
+        marks: List[Tuple[str, float]] = []
+
+        def mark(name: str) -> None:
+            torch.cuda.synchronize(self.dev)
+            marks.append((name, time.perf_counter()))
+        n, L, N = trace_log, trace_log + log_blowup, n_cols
+        K = L - 1 - log_blowup
+        hsel = 1 if hash == "blake2s" else 0
+        H = HASHES[hash]
+        ch = _Channel(H)
+        size_L = 1 << L
+
+        # ---- trace, interpolation, LDE, commitment
+        cols = self._empty(N, 1 << n)
+        self._call("ss_p_trace", n, N, (seed * 0x9E3779B1) % P, cols.data_ptr())
+        coefs = cols
+        self.fft(n, coefs, True)
+        lde = self.extend(coefs, L)
+        trace_tree = self.merkle(hsel, lambda lv: self._call(
+            "ss_p_hash_rows", hsel, size_L, N, lde.data_ptr(), size_L, lv.data_ptr()), size_L)
+        const_root = H(b"").digest()
+        trace_root = self._root(trace_tree, size_L)
+        mark("trace commit")
+        ch.mix(const_root)
+        ch.mix(trace_root)
+        cp_alpha = ch.draw_qm31()
+
+        # ---- composition polynomial on the coset of log size n + 1, 16 partition columns
+        ev = self.extend(coefs, n + 1)
+        _, _, hxhy_c = self.domain(n + 1)
+        F = self._empty(4, 1 << (n + 1))
+        self._call("ss_p_composition", n, N, ev.data_ptr(), hxhy_c.data_ptr(), self._q(cp_alpha), F.data_ptr())
+        self.fft(n + 1, F, True)
+        cp_coefs = self._zeros(16, 1 << n)
+        for c in range(4):
+            for part in range(4):
+                cp_coefs[4 * c + part, 0::2] = F[c, part::4]
+        cp_lde = self.extend(cp_coefs, L)
+        cp_tree = self.merkle(hsel, lambda lv: self._call(
+            "ss_p_hash_rows", hsel, size_L, 16, cp_lde.data_ptr(), size_L, lv.data_ptr()), size_L)
+        cp_root = self._root(cp_tree, size_L)
+        mark("composition commit")
+        ch.mix(cp_root)
+
+        # ---- OODS point, samples
+        t = ch.draw_qm31()
+        t_sq = qmul(t, t)
+        inv = qinv(qadd(ONE, t_sq))
+        px, py = qmul(qsub(ONE, t_sq), inv), qmul(qadd(t, t), inv)
+        p2x = qsub(qadd(qmul(px, px), qmul(px, px)), ONE)
+        p2y = qadd(qmul(px, py), qmul(px, py))
+
+        def factors(x: Q4, y: Q4, m: int) -> np.ndarray:
+            f = [y, x]
+            cur = x
+            for _ in range(2, m):
+                cur = qsub(qadd(qmul(cur, cur), qmul(cur, cur)), ONE)
+                f.append(cur)
+            return np.array(f[:m], dtype=np.uint32).reshape(-1)
+        scratch = self._empty(3 << n)
+        samples = self._empty(N + 16, 4)
+        f1, f2 = factors(px, py, n), factors(p2x, p2y, n)
+        for k in range(N):
+            self._call("ss_p_eval_at_point", n, coefs[k].data_ptr(), f1.ctypes.data, scratch.data_ptr(),
+                       samples[k].data_ptr())
+        for k in range(16):
+            self._call("ss_p_eval_at_point", n, cp_coefs[k].data_ptr(), f2.ctypes.data, scratch.data_ptr(),
+                       samples[N + k].data_ptr())
+        samp = self._host(samples).astype(np.int64)
+        oods_trace = [tuple(int(x) for x in samp[k]) for k in range(N)]
+        oods_cp = [tuple(int(x) for x in samp[N + k]) for k in range(16)]
+        ch.mix(b"".join(_be(v) for v in oods_trace) + b"".join(_be(v) for v in oods_cp))
+        deep_alpha = ch.draw_qm31()
+        mark("oods")
+
+        # ---- DEEP quotients (trace batch at P, composition batch at 2P)
+        bco: List[Q4] = []
+        sums: List[Q4] = []
+        for sp_y, vals in ((py, oods_trace), (p2y, oods_cp)):
+            A, Cc, alpha_i = ZERO, ZERO, deep_alpha
+            for v in vals:
+                a, b, c = _interpolant(sp_y, v, alpha_i)
+                bco.append(b)
+                A, Cc = qadd(A, a), qadd(Cc, c)
+                alpha_i = qmul(alpha_i, deep_alpha)
+            sums += [A, Cc]
+        a16 = ONE
+        for _ in range(16):
+            a16 = qmul(a16, deep_alpha)
+        bcoef = torch.from_numpy(np.array(bco, dtype=np.uint32).view(np.int32)).to(self.dev)
+        pts = (C.c_uint32 * 8)(*px, *py)
+        pts2 = (C.c_uint32 * 8)(*p2x, *p2y)
+        sa = (C.c_uint32 * 20)(*[x for v in sums + [a16] for x in v])
+        _, itw_L, hxhy_L = self.domain(L)
+        layer = self._empty(size_L, 4)
+        self._call("ss_p_quotients", L, N, lde.data_ptr(), cp_lde.data_ptr(), hxhy_L.data_ptr(),
+                   bcoef.data_ptr(), pts, pts2, sa, layer.data_ptr())
+        mark("quotients")
+
+        # ---- FRI commit
+        layers, trees, roots = [], [], []
+        for l in range(K + 1):
+            size = size_L >> l
+            layers.append(layer)
+            cur = layer
+            tree = self.merkle(hsel, lambda lv: self._call(
+                "ss_p_hash_qm31", hsel, size, cur.data_ptr(), lv.data_ptr()), size)
+            trees.append(tree)
+            root = self._root(tree, size)
+            roots.append(root)
+            ch.mix(root)
+            alpha = ch.draw_qm31()
+            nxt = self._empty(size >> 1, 4)
+            off = size_L - (size_L >> l)  # inverse twiddle layer l = 1 / fold coordinate
+            self._call("ss_p_fri_fold", size >> 1, layer.data_ptr(), itw_L[off:].data_ptr(), self._q(alpha),
+                       nxt.data_ptr())
+            layer = nxt
+        last_all = self._host(layer)
+        if not (last_all == last_all[0]).all():
+            raise AssertionError("last FRI layer is not constant: the quotient is not low degree")
+        last = tuple(int(x) for x in last_all[0])
+        ch.mix(_be(last))
+        mark("fri commit")
+
+        # ---- proof of work (pow.simf:22-36): smallest nonce, searched on the GPU
+        target = (1 << (64 - pow_bits)) - 1
+        dig = (C.c_uint32 * 8)(*np.frombuffer(ch.digest, dtype=">u4").astype(np.uint32))
+        out = torch.zeros(2, dtype=torch.int32, device=self.dev)
+        start, span = 0, 1 << 22
+        while True:
+            self._call("ss_p_pow", hsel, dig, target, start, span, out.data_ptr())
+            nonce = int(self._host(out).view(np.uint64)[0])
+            if nonce != 0xFFFFFFFFFFFFFFFF:
+                break
+            start += span
+        ch.mix(nonce.to_bytes(8, "big"))
+        mark("pow")
+
+        # ---- queries (fri/queries.simf:29-43) and decommitment
+        mask = (1 << L) - 1
+        queries: List[int] = []
+        while len(queries) < n_queries:
+            queries += [w & mask for w in ch.draw_words()]
+        queries = queries[:n_queries]
+        qi = torch.tensor(queries, device=self.dev)
+        tq = self._host(lde[:, qi]).T  # [Q, N]
+        cq = self._host(cp_lde[:, qi]).T
+        trace_q = [int(v) for row in tq for v in row]
+        cp_q = [int(v) for row in cq for v in row]
+        trace_hw = [nd for q in queries for nd in self._path(trace_tree, size_L, q)]
+        cp_hw = [nd for q in queries for nd in self._path(cp_tree, size_L, q)]
+
+        def qj(v):
+            return [[int(v[0]), int(v[1])], [int(v[2]), int(v[3])]]
+        fri_json = []
+        cur_q = list(queries)
+        for l in range(K + 1):
+            size = size_L >> l
+            sib = self._host(layers[l][torch.tensor([q ^ 1 for q in cur_q], device=self.dev)])
+            hwl = []
+            for j, q in enumerate(cur_q):
+                hwl += self._path(trees[l], size, q >> 1, skip=1)
+                cur_q[j] = q >> 1
+            fri_json.append({"fri_witness": [qj(w) for w in sib],
+                             "decommitment": {"hash_witness": hwl, "column_witness": []},
+                             "commitment": [int(b) for b in roots[l]]})
+        mark("decommit")
+        prev = t_start
+        self.timings = {}
+        for name, ts in marks:
+            self.timings[name] = ts - prev
+            prev = ts
+        self.timings["total"] = prev - t_start
+        conf = {"pow_bits": pow_bits,
+                "fri_config": {"log_blowup_factor": log_blowup, "log_last_layer_degree_bound": 0,
+                               "n_queries": n_queries}}
+        if hash != "sha256":
+            conf["hash"] = hash
+        return {
+            "config": conf,
+            "commitments": [[int(b) for b in const_root], [int(b) for b in trace_root],
+                            [int(b) for b in cp_root]],
+            "sampled_values": [[], [[qj(v)] for v in oods_trace], [[qj(v)] for v in oods_cp]],
+            "decommitments": [{"hash_witness": [], "column_witness": []},
+                              {"hash_witness": trace_hw, "column_witness": []},
+                              {"hash_witness": cp_hw, "column_witness": []}],
+            "queried_values": [[], trace_q, cp_q],
+            "proof_of_work": nonce,
+            "fri_proof": {"first_layer": fri_json[0], "inner_layers": fri_json[1:],
+                          "last_layer_poly": {"coeffs": [qj(last)], "log_size": 0}},
+        }

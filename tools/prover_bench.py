@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""GPU prover timing: one 2^k-row wide-Fibonacci proof on one MI355X,
+checked against the committed proof made by the numpy prover (tests/golden/stwo_trace20.npz)
+and verified by the GPU verifier.  `python tools/prover_bench.py [trace_log] [reps]`."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import stark_symphony_amd as ss  # noqa: E402
+from stark_symphony_amd import prover, records, verifier  # noqa: E402
+
+trace_log = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+hash_name = sys.argv[3] if len(sys.argv) > 3 else "sha256"
+ver = verifier.Verifier(0)
+gp = prover.GpuProver(ver)
+best = None
+for r in range(reps):
+    t0 = time.perf_counter()
+    pj = gp.prove(n_cols=4, trace_log=trace_log, log_blowup=4, n_queries=16, pow_bits=5, seed=0, hash=hash_name)
+    dt = time.perf_counter() - t0
+    if best is None or dt < best[0]:
+        best = (dt, dict(gp.timings))
+    print("run %d: %.3f s" % (r, dt), {k: round(v, 4) for k, v in gp.timings.items()}, flush=True)
+proof = ss.stwo_from_json(pj)
+print("verify on GPU:", ver.verify_stwo([proof]).tolist())
+gold = os.path.join(ROOT, "tests", "golden", "stwo_trace20.npz")
+if trace_log == 20 and hash_name == "sha256" and os.path.exists(gold):
+    want = records.load_stwo_npz(gold)[0]
+    same = ss.stwo_to_json(want) == ss.stwo_to_json(proof)
+    print("identical to the numpy prover's committed 2^20 proof:", same)
+    assert same
+print(json.dumps({"metric": "prove time, wide-Fibonacci 2^%d x 4, blowup 16, Q=16" % trace_log, "value": best[0],
+                  "unit": "s", "hash": hash_name, "stages_s": best[1]}))
