@@ -122,6 +122,8 @@ def main() -> None:
     ap.add_argument("--proofs-per-gpu", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--distinct", type=int, default=16,
+                    help="distinct valid proofs in the batch (made by the GPU prover; 0 = fixtures only)")
     ap.add_argument("--inflight", type=int, default=3,
                     help="batch passes in flight (one HIP stream each)")
     args = ap.parse_args()
@@ -143,6 +145,24 @@ def main() -> None:
     from stark_symphony_amd import verifier
     wname, family, proofs, note = load_workload(args.workload)
     ver = verifier.Verifier(local)
+
+    if family == "stwo" and args.distinct > len(proofs) and wname != "stwo_fixture":
+        # More distinct valid proofs of the same configuration, made on this GPU by the prover
+        # of SURVEY.md 8f-1 (different trace seeds; seed 0 must reproduce the committed proof,
+        # which the numpy prover made -- a full-size byte-for-byte self-check).
+        import stark_symphony_amd as ss
+        from stark_symphony_amd import prover
+        c = proofs[0].cfg
+        gp = prover.GpuProver(ver)
+        made = [ss.stwo_from_json(gp.prove(c.n_cols, c.trace_log, c.log_blowup, c.n_queries, c.pow_bits,
+                                           seed=s + rank * args.distinct, hash=c.hash))
+                for s in range(args.distinct)]
+        if rank == 0:
+            assert ss.stwo_to_json(made[0]) == ss.stwo_to_json(proofs[0]), "GPU prover != committed proof"
+        proofs = made
+        note += "; %d distinct proofs made by the GPU prover (seed 0 == committed fixture)" % len(proofs)
+        del gp
+        torch.cuda.empty_cache()
 
     if family == "stwo":
         cfg = proofs[0].cfg

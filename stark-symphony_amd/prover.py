@@ -189,22 +189,25 @@ class GpuProver:
     def _root(self, levels, n: int) -> bytes:
         return self._host(levels[2 * n - 2]).astype(">u4").tobytes()
 
-    def _path(self, levels, n: int, index: int, skip: int = 0) -> List[List[int]]:
-        """Sibling hashes leaf -> root for `index` at level `skip` (bytes as int lists)."""
+    def _paths(self, levels, n: int, indices: Sequence[int], skip: int = 0) -> List[List[int]]:
+        """Sibling hashes leaf -> root (bytes as int lists) of every index at level `skip`,
+        concatenated in query order; one gather + one download per tree."""
         torch = self.torch
-        idxs, off, size, idx = [], 0, n, index
-        for _ in range(skip):
-            off += size
-            size >>= 1
-        while size > 1:
-            idxs.append(off + (idx ^ 1))
-            off += size
-            size >>= 1
-            idx >>= 1
+        idxs: List[int] = []
+        for index in indices:
+            off, size, idx = 0, n, index
+            for _ in range(skip):
+                off += size
+                size >>= 1
+            while size > 1:
+                idxs.append(off + (idx ^ 1))
+                off += size
+                size >>= 1
+                idx >>= 1
         if not idxs:
             return []
         rows = self._host(levels[torch.tensor(idxs, device=self.dev)])
-        return [[int(b) for b in r.astype(">u4").tobytes()] for r in rows]
+        return rows.astype(">u4").view(np.uint8).reshape(len(idxs), 32).tolist()
 
     # -- the protocol ----------------------------------------------------------------------
     def prove(self, n_cols: int = 4, trace_log: int = 9, log_blowup: int = 4, n_queries: int = 16,
@@ -360,8 +363,8 @@ class GpuProver:
         cq = self._host(cp_lde[:, qi]).T
         trace_q = [int(v) for row in tq for v in row]
         cp_q = [int(v) for row in cq for v in row]
-        trace_hw = [nd for q in queries for nd in self._path(trace_tree, size_L, q)]
-        cp_hw = [nd for q in queries for nd in self._path(cp_tree, size_L, q)]
+        trace_hw = self._paths(trace_tree, size_L, queries)
+        cp_hw = self._paths(cp_tree, size_L, queries)
 
         def qj(v):
             return [[int(v[0]), int(v[1])], [int(v[2]), int(v[3])]]
@@ -370,10 +373,8 @@ class GpuProver:
         for l in range(K + 1):
             size = size_L >> l
             sib = self._host(layers[l][torch.tensor([q ^ 1 for q in cur_q], device=self.dev)])
-            hwl = []
-            for j, q in enumerate(cur_q):
-                hwl += self._path(trees[l], size, q >> 1, skip=1)
-                cur_q[j] = q >> 1
+            hwl = self._paths(trees[l], size, [q >> 1 for q in cur_q], skip=1)
+            cur_q = [q >> 1 for q in cur_q]
             fri_json.append({"fri_witness": [qj(w) for w in sib],
                              "decommitment": {"hash_witness": hwl, "column_witness": []},
                              "commitment": [int(b) for b in roots[l]]})
