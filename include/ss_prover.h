@@ -88,6 +88,25 @@ int ss_p_fri_fold(ss_ctx *ctx, size_t n_out, const uint32_t *in, const uint32_t 
 int ss_p_pow(ss_ctx *ctx, uint32_t hash, const uint32_t digest[8], uint64_t target, uint64_t start,
              uint64_t count, uint64_t *nonce_out_dev, void *stream);
 
+/* ------------------------------------------------------------------ stark101 prover (8f row 2)
+ * Data-parallel steps of stark101/scripts/fibsquare/prover.py:25-171 (csrc/ss_s101_prover.hip);
+ * the host side is stark-symphony_amd/prover101.py.  Sizes are the reference's: 1023-step trace,
+ * size-1024 subgroup, 8192-point coset 5 * <h>, natural order.                                 */
+
+/* trace_out[1023]: a_0 = 1, a_1 = seed, a_i = a_{i-2}^2 + a_{i-1}^2 (prover.py:25-30; the reference's
+ * seed is 3141592); coef_out[1024]: the interpolant of degree < 1023 through (g^i, a_i) (prover.py:111). */
+int ss_p101_trace_poly(ss_ctx *ctx, uint32_t seed, uint32_t *trace_out, uint32_t *coef_out, void *stream);
+/* out[j] = p(5 h^j), j < 8192 (prover.py:112).                                               */
+int ss_p101_lde(ss_ctx *ctx, const uint32_t *coef, uint32_t *out, void *stream);
+/* Composition polynomial on the coset from the trace LDE (prover.py:42-65,117-118); alphas = the
+ * three channel coefficients (host); claim = a_1022 (2338775057 for the reference's seed).     */
+int ss_p101_composition(ss_ctx *ctx, const uint32_t *p_ev, const uint32_t alphas[3], uint32_t claim,
+                        uint32_t *out, void *stream);
+/* FRI layer `layer` (len = 8192 >> layer evaluations) -> the next layer (len / 2) with the
+ * channel's beta (prover.py:68-88).                                                           */
+int ss_p101_fold(ss_ctx *ctx, uint32_t layer, uint32_t len, uint32_t beta, const uint32_t *in,
+                 uint32_t *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,15 @@ def test_library_exports_every_declared_symbol():
     assert lib.ss_version() == 0x00010000
 
 
+def test_library_exports_every_prover_symbol():
+    lib = binding.lib()
+    hdr = open(os.path.join(ROOT, "include", "ss_prover.h")).read()
+    declared = set(re.findall(r"\b(ss_p[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) == 15
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
 def test_no_device_is_a_loud_error():
     """Without a GPU the context cannot be created; nothing falls back to the CPU."""
     import torch
