@@ -17,6 +17,7 @@ Workloads (`--workload`):
                  16 queries) replicated -- used when the 2^20 fixture is absent.
   stwo_2p16      BASELINE.json configs[2]: 2^16 trace, 32 queries.
   stwo_wide256   BASELINE.json configs[4]: 256 columns, LDE 2^18.
+  stwo_2p16_blake2s, stwo_wide256_blake2s  configs[2] / configs[4] with Blake2s; proofs made at start-up.
   stwo_2p20_blake2s  the metric config with Blake2s-256 as the hash (BASELINE.json says "Blake2s
                  Merkle"; the reference has no Blake2s, so this variant's parity is unpinned).
   stark101       BASELINE.json configs[1]: the stark101 proof x 4096.
@@ -43,6 +44,16 @@ SHA_CALIBRATED_PEAK = 34.7e9
 B2S_CALIBRATED_PEAK = 38.9e9  # Blake2s-256 compressions/s, same tool (one compression per node)
 
 
+# BASELINE.json configs[2] / configs[4] with the hash they name (Blake2s): no committed fixture,
+# every proof of the batch is made by the GPU prover at start-up (parity unpinned).
+GEN_ONLY = {
+    "stwo_2p16_blake2s": dict(n_cols=4, trace_log=16, lde_log=20, n_queries=32, n_layers=15, pow_bits=5,
+                              hash="blake2s"),
+    "stwo_wide256_blake2s": dict(n_cols=256, trace_log=14, lde_log=18, n_queries=16, n_layers=13, pow_bits=5,
+                                 hash="blake2s"),
+}
+
+
 def load_workload(name: str):
     """-> (workload name, family, list of distinct proofs, note)"""
     import stark_symphony_amd as ss
@@ -61,6 +72,10 @@ def load_workload(name: str):
         proofs = records.load_stwo_npz(os.path.join(GOLDEN, fn))
         c = proofs[0].cfg
         return name, "stwo", proofs, "wide-Fibonacci 2^%d x %d, LDE 2^%d, Q=%d, K=%d, %s" % (
+            c.trace_log, c.n_cols, c.lde_log, c.n_queries, c.n_layers, c.hash)
+    if name in GEN_ONLY:
+        c = formats.StwoConfig(**GEN_ONLY[name])
+        return name, "stwo", [], "wide-Fibonacci 2^%d x %d, LDE 2^%d, Q=%d, K=%d, %s" % (
             c.trace_log, c.n_cols, c.lde_log, c.n_queries, c.n_layers, c.hash)
     if name == "stwo_fixture":
         p = ss.stwo_from_json(json.load(open(os.path.join(GOLDEN, "stwo_proof.json"))))
@@ -152,18 +167,22 @@ def main() -> None:
         # which the numpy prover made -- a full-size byte-for-byte self-check).
         import stark_symphony_amd as ss
         from stark_symphony_amd import prover
-        c = proofs[0].cfg
+        from stark_symphony_amd import formats
+        c = proofs[0].cfg if proofs else formats.StwoConfig(**GEN_ONLY[wname])
         gp = prover.GpuProver(ver)
         made = [ss.stwo_from_json(gp.prove(c.n_cols, c.trace_log, c.log_blowup, c.n_queries, c.pow_bits,
                                            seed=s + rank * args.distinct, hash=c.hash))
                 for s in range(args.distinct)]
-        if rank == 0:
+        if rank == 0 and proofs:
             assert ss.stwo_to_json(made[0]) == ss.stwo_to_json(proofs[0]), "GPU prover != committed proof"
+        note += "; %d distinct proofs made by the GPU prover%s" % (
+            len(made), " (seed 0 == committed fixture)" if proofs else "")
         proofs = made
-        note += "; %d distinct proofs made by the GPU prover (seed 0 == committed fixture)" % len(proofs)
         del gp
         torch.cuda.empty_cache()
 
+    if not proofs:
+        raise SystemExit("workload %s has no committed proof: needs --distinct >= 1" % wname)
     if family == "stwo":
         cfg = proofs[0].cfg
         per_gpu = args.proofs_per_gpu or (8192 if cfg.lde_log >= 20 else 32768)

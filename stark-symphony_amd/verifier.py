@@ -126,6 +126,14 @@ def stwo_record(p: StwoProof) -> Tuple[np.ndarray, int]:
     return rec, shape
 
 
+def group_by_config(proofs: Sequence[StwoProof]) -> List[List[int]]:
+    """Indices of `proofs` grouped by StwoConfig, groups in order of first appearance."""
+    groups: dict = {}
+    for i, p in enumerate(proofs):
+        groups.setdefault(p.cfg, []).append(i)
+    return list(groups.values())
+
+
 def s101_shape_of(proofs: Sequence[Stark101Proof]) -> Tuple[int, int]:
     ml = max([len(p.layers) for p in proofs] + [0])
     pm = 0
@@ -335,9 +343,14 @@ class Verifier:
                                np.array(list(shapes) * replicate, dtype=np.uint32))
 
     def verify_stwo(self, proofs: Sequence[StwoProof], mode: int = MODE_FIXTURE) -> np.ndarray:
-        b = self.stwo_batch(proofs, mode)
-        b.run()
-        return b.status()
+        """Status word per proof.  Proofs of different shapes (StwoConfig) may be mixed: each
+        shape is verified as its own device batch and the statuses return in input order."""
+        out = np.zeros(len(proofs), dtype=np.uint32)
+        for idx in group_by_config(proofs):
+            b = self.stwo_batch([proofs[i] for i in idx], mode)
+            b.run()
+            out[idx] = b.status()
+        return out
 
     def verify_stwo_records(self, cfg: StwoConfig, records: Sequence[np.ndarray],
                             mode: int = MODE_FIXTURE,

@@ -291,3 +291,17 @@ def test_host_buffer_entry_point(ver, stwo_prod):
         got = ver.verify_stwo_records(stwo_prod.cfg, [recs[i] for i in idx],
                                       shape_status=np.array([shapes[i] for i in idx]))
         assert got.tolist() == [int(want_d[i]) for i in idx]
+
+
+def test_stwo_mixed_shapes_in_one_call(ver, stwo_small, stwo_prod):
+    """verify_stwo groups proofs by StwoConfig; statuses come back in input order."""
+    rng = np.random.default_rng(SEED + 15)
+    wide = _load_npz("stwo_wide256.npz")[0]
+    proofs = []
+    for k in range(30):
+        base = (stwo_small, stwo_prod, wide)[int(rng.integers(3))]
+        proofs.append(base if rng.integers(2) else formats.stwo_corrupt(base, rng)[0])
+    assert len(verifier.group_by_config(proofs)) == 3
+    got = ver.verify_stwo(proofs)
+    want = [O.stwo_verify(p, O.MODE_FIXTURE) for p in proofs]
+    assert got.tolist() == want and 0 in want and any(want)

@@ -222,3 +222,11 @@ def test_corruption_helpers_are_seeded(s101_proof, stwo_prod):
     q1, _ = formats.stwo_corrupt(stwo_prod, np.random.default_rng(11))
     q2, _ = formats.stwo_corrupt(stwo_prod, np.random.default_rng(11))
     assert ss.stwo_to_json(q1) == ss.stwo_to_json(q2) != ss.stwo_to_json(stwo_prod)
+
+
+def test_group_by_config_keeps_input_order():
+    g = os.path.join(ROOT, "tests", "golden")
+    a = ss.stwo_from_json(json.load(open(os.path.join(g, "stwo_proof.json"))))
+    b = ss.stwo_from_json(json.load(open(os.path.join(g, "stwo_proof_test.json"))))
+    assert verifier.group_by_config([a, b, a, a, b]) == [[0, 2, 3], [1, 4]]
+    assert verifier.group_by_config([]) == []
