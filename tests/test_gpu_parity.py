@@ -305,3 +305,21 @@ def test_stwo_mixed_shapes_in_one_call(ver, stwo_small, stwo_prod):
     got = ver.verify_stwo(proofs)
     want = [O.stwo_verify(p, O.MODE_FIXTURE) for p in proofs]
     assert got.tolist() == want and 0 in want and any(want)
+
+
+def test_stwo_full_size_batch_2p20(ver):
+    """BASELINE.json configs[3] at its per-GPU size: 8 192 proofs of the 2^20-trace shape (1.4 GB
+    resident), half of them seeded corruptions.  Size-independent property: the
+    status vector equals the oracle's verdicts of the distinct proofs, gathered through the
+    replication map, and the device accept count equals the number of valid entries."""
+    proofs = _load_npz("stwo_trace20.npz")
+    rng = np.random.default_rng(SEED + 16)
+    distinct = list(proofs) + [formats.stwo_corrupt(proofs[i % len(proofs)], rng)[0] for i in range(62)]
+    want_d = O.stwo_verify_batch(distinct)
+    n = 8192
+    idx = [(i // 2) % len(proofs) if i % 2 == 0 else len(proofs) + (i // 2) % 62 for i in range(n)]
+    b = ver.stwo_batch([distinct[i] for i in idx])
+    b.run()
+    got = b.status()
+    assert got.tolist() == [int(want_d[i]) for i in idx]
+    assert b.accepted() == sum(1 for i in idx if want_d[i] == 0) >= n // 2
