@@ -127,6 +127,70 @@ __device__ __forceinline__ bool qm31_eq(QM31 x, QM31 y)
     return x.a == y.a && x.b == y.b && x.c == y.c && x.d == y.d;
 }
 
+// ------------------------------------------------------------ lazily reduced arithmetic
+// For operands that are field elements in [0, P] (canonical words, or the word P that m31_neg(0)
+// returns) every reference primitive computes the exact field operation and returns the canonical
+// word in [0, P - 1], so any algebraically equal evaluation gives the same bits.  The helpers
+// below accumulate 32x32 products in 64 bits (one v_mad_u64_u32 each, 4.4 cycles/wave on gfx950,
+// tools/probes/valu_mad64.hip) and reduce once per output word: a * b <= P^2 < 2^62, so four
+// products fit.  A subtraction is a product with P - b.  A raw witness word may only enter
+// through m31_red first, and only where the reference feeds it to multiplications alone.
+__device__ __forceinline__ uint64_t m31_mac(uint64_t acc, uint32_t a, uint32_t b)
+{
+    return acc + (uint64_t)a * (uint64_t)b;
+}
+__device__ __forceinline__ uint32_t m31_red64(uint64_t x)
+{
+    const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    uint32_t s = (lo & M31_P) + (((lo >> 31) | (hi << 1)) & M31_P);  // x0 + x1 < 2^32
+    s = (s & M31_P) + (s >> 31) + (hi >> 30);                          // + x2, <= P + 4
+    return s >= M31_P ? s - M31_P : s;
+}
+// x < 2^64 -> a congruent value < 2^62 + 4 (2^62 == 1 mod P): keeps a running sum of products open
+__device__ __forceinline__ uint64_t m31_fold62(uint64_t x) { return (x & 0x3fffffffffffffffull) + (x >> 62); }
+
+__device__ __forceinline__ CM31 cm31_mul_c(CM31 x, CM31 y)
+{
+    return {m31_red64(m31_mac(m31_mac(0, x.a, y.a), x.b, M31_P - y.b)),
+            m31_red64(m31_mac(m31_mac(0, x.a, y.b), x.b, y.a))};
+}
+// (re, im) += (2 + i) t for a canonical t, as small terms of the open accumulators
+__device__ __forceinline__ void cm31_acc_r(uint64_t &re, uint64_t &im, CM31 t)
+{
+    re += (uint64_t)t.a + t.a + (M31_P - t.b);
+    im += (uint64_t)t.a + t.b + t.b;
+}
+__device__ inline QM31 qm31_mul_c(QM31 x, QM31 y)
+{
+    const CM31 t = cm31_mul_c(q_im(x), q_im(y));
+    uint64_t ra = m31_mac(m31_mac(0, x.a, y.a), x.b, M31_P - y.b);
+    uint64_t rb = m31_mac(m31_mac(0, x.a, y.b), x.b, y.a);
+    cm31_acc_r(ra, rb, t);
+    const uint64_t ia = m31_mac(m31_mac(m31_mac(m31_mac(0, x.a, y.c), x.b, M31_P - y.d), x.c, y.a), x.d, M31_P - y.b);
+    const uint64_t ib = m31_mac(m31_mac(m31_mac(m31_mac(0, x.a, y.d), x.b, y.c), x.c, y.b), x.d, y.a);
+    return {m31_red64(ra), m31_red64(rb), m31_red64(ia), m31_red64(ib)};
+}
+__device__ inline QM31 qm31_sqr_c(QM31 x)
+{
+    const CM31 t = {m31_red64(m31_mac(m31_mac(0, x.c, x.c), x.d, M31_P - x.d)), m31_red64(m31_mac(0, x.c + x.c, x.d))};
+    uint64_t ra = m31_mac(m31_mac(0, x.a, x.a), x.b, M31_P - x.b);
+    uint64_t rb = m31_mac(0, x.a + x.a, x.b);
+    cm31_acc_r(ra, rb, t);
+    const uint64_t ia = m31_mac(m31_mac(0, x.a + x.a, x.c), x.b + x.b, M31_P - x.d);
+    const uint64_t ib = m31_mac(m31_mac(0, x.a + x.a, x.d), x.b + x.b, x.c);
+    return {m31_red64(ra), m31_red64(rb), m31_red64(ia), m31_red64(ib)};
+}
+// x * (0 + y u): the product with an element whose real half is zero (DEEP a0 / b0)
+__device__ inline QM31 qm31_mul_im_c(QM31 x, CM31 y)
+{
+    const CM31 t = cm31_mul_c(q_im(x), y);
+    uint64_t ra = 0, rb = 0;
+    cm31_acc_r(ra, rb, t);
+    const CM31 im = cm31_mul_c(q_re(x), y);
+    return {m31_red64(ra), m31_red64(rb), im.a, im.b};
+}
+__device__ __forceinline__ QM31 qm31_red(QM31 x) { return {m31_red(x.a), m31_red(x.b), m31_red(x.c), m31_red(x.d)}; }
+
 // ------------------------------------------------------ groups/m31_point.simf:33-97
 __device__ __forceinline__ M31Point m31_point_add(M31Point l, M31Point r)
 {

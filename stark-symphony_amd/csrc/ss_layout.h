@@ -47,8 +47,9 @@ struct StwoLayout {
     uint64_t off_fri_path[kMaxList + 1];
     uint64_t total_words;
     // workspace word offsets (u32 words)
-    uint32_t c_queries, c_p, c_p2, c_b, c_a1, c_c1, c_a2, c_c2, c_m1, c_fold, ctx_words;
-    uint64_t ws_ctx, ws_leaf, ws_total_words;
+    uint32_t c_queries, c_p, c_p2, c_b01, c_b02, c_a1, c_c1, c_a2, c_c2, c_m1, c_fold, ctx_words;
+    uint32_t n_pow;  // DEEP alpha powers kept per proof
+    uint64_t ws_ctx, ws_alpha, ws_leaf, ws_total_words;
 };
 
 SS_HD inline bool stwo_cfg_ok(uint32_t N, uint32_t TL, uint32_t L, uint32_t Q, uint32_t K, uint32_t mode)
@@ -90,7 +91,8 @@ SS_HD inline StwoLayout stwo_layout(uint32_t N, uint32_t TL, uint32_t L, uint32_
     y.c_queries = c; c += Q;
     y.c_p = c;       c += 8;            // OODS point P  (x.a..x.d, y.a..y.d)
     y.c_p2 = c;      c += 8;            // 2P
-    y.c_b = c;       c += 4 * (N + kCp);
+    y.c_b01 = c;     c += 4;            // DEEP b0 = (0, -2 im(P.y)) of the batch sampled at P
+    y.c_b02 = c;     c += 4;            // ... at 2P
     y.c_a1 = c;      c += 4;
     y.c_c1 = c;      c += 4;
     y.c_a2 = c;      c += 4;
@@ -100,6 +102,9 @@ SS_HD inline StwoLayout stwo_layout(uint32_t N, uint32_t TL, uint32_t L, uint32_
     y.ctx_words = c;
     uint64_t w = 0;
     y.ws_ctx = w;   w += (uint64_t)y.ctx_words * y.np;
+    // alpha[proof][k][4] = deep_alpha^(k+1): one 16-byte load per column in the query kernel
+    y.n_pow = N + kCp;
+    y.ws_alpha = w; w += (uint64_t)y.n_pow * 4 * y.np;
     y.ws_leaf = w;  w += (uint64_t)(K + 1) * 8 * y.nip;
     y.ws_total_words = w;
     return y;

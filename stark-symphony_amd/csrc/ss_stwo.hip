@@ -89,21 +89,6 @@ struct Channel {
     }
 };
 
-// deep_quotient_interpolant_coefficients (deep/quotients.simf:25-36)
-__device__ inline void interpolant_coefficients(const QM31Point &sp, QM31 value, QM31 alpha_i,
-                                                QM31 &a, QM31 &b, QM31 &c)
-{
-    CM31 im_v = q_im(value), im_py = q_im(sp.y);
-    QM31 a0 = q_make(CM31{0, 0}, cm31_neg(cm31_add(im_v, im_v)));
-    QM31 b0 = q_make(CM31{0, 0}, cm31_neg(cm31_add(im_py, im_py)));
-    QM31 a_py = qm31_mul(a0, sp.y);
-    QM31 b_val = qm31_mul(b0, value);
-    QM31 c0 = qm31_sub(b_val, a_py);
-    a = qm31_mul(alpha_i, a0);
-    b = qm31_mul(alpha_i, b0);
-    c = qm31_mul(alpha_i, c0);
-}
-
 // ========================================================================== transcript
 template <int HF>
 __device__ __forceinline__ void stwo_transcript_body(const StwoLayout &lay, const uint32_t *__restrict__ batch,
@@ -160,19 +145,21 @@ __device__ __forceinline__ void stwo_transcript_body(const StwoLayout &lay, cons
             ch.ctr = 0;
         }
 
-        // eval_composition_poly (constraints/wide_fibonacci.simf:24-62)
-        QM31 acc = qm31_zero(), a = qm31_zero(), b = qm31_zero();
+        // eval_composition_poly (constraints/wide_fibonacci.simf:24-62).  A column value reaches
+        // the squares through multiplications only, so it is reduced first and squared once
+        // (the reference squares it as `b` and again as `a`); it reaches the subtraction raw.
+        QM31 acc = qm31_zero(), sq_a = qm31_zero(), sq_b = qm31_zero();
         uint32_t skip = 0;
         for (uint32_t k = 0; k < lay.N; k++) {
-            QM31 c = HQ(lay.h_oods_trace + 4 * k);
+            const QM31 c = HQ(lay.h_oods_trace + 4 * k);
             if (skip == 2) {
-                QM31 constraint = qm31_sub(c, qm31_add(qm31_mul(b, b), qm31_mul(a, a)));
-                acc = qm31_add(qm31_mul(acc, cp_alpha), constraint);
+                const QM31 constraint = qm31_sub(c, qm31_add(sq_b, sq_a));
+                acc = qm31_add(qm31_mul_c(acc, cp_alpha), constraint);
             } else {
                 skip++;
             }
-            a = b;
-            b = c;
+            sq_a = sq_b;
+            sq_b = qm31_sqr_c(qm31_red(c));
         }
         // vanishing_poly_eval (evals/composition_poly.simf:27-35,66-71): u8 loop counter
         QM31 van = P.x;
@@ -241,44 +228,55 @@ __device__ __forceinline__ void stwo_transcript_body(const StwoLayout &lay, cons
     }
 
     // ---- stage VI, query-independent part (fri/answers.simf:44-64,97-130)
+    // deep_quotient_interpolant_coefficients (deep/quotients.simf:25-36) gives, for column k with
+    // sample `value` at point sp and alpha_k = deep_alpha^(k+1):
+    //     a_k = alpha_k a0_k,  b_k = alpha_k b0,  c_k = alpha_k (b0 value - a0_k sp.y)
+    // with a0_k = (0, -2 im(value)) and b0 = (0, -2 im(sp.y)) the same for every column.  The
+    // query kernel needs sum_k b_k v_k - y sum_k a_k - sum_k c_k, so this kernel keeps
+    //     alpha_k (table),  b0,  A = sum alpha_k a0_k,  C = b0 V - A sp.y,  V = sum alpha_k value_k
+    // and the query kernel computes b0 (sum_k alpha_k v_k).  Every operand is a field element in
+    // [0, P] except the raw `value`, which the reference doubles with wrapping adds (kept) and
+    // otherwise only multiplies (reduced first), so the sums are the reference's words.
     {
         QM31Point P2 = qm31_point_add(P, P);
         CQ(lay.c_p, P.x);  CQ(lay.c_p + 4, P.y);
         CQ(lay.c_p2, P2.x); CQ(lay.c_p2 + 4, P2.y);
-        QM31 A = qm31_zero(), C = qm31_zero(), alpha_i = deep_alpha;
-        for (uint32_t k = 0; k < lay.N; k++) {
-            QM31 a, b, c;
-            interpolant_coefficients(P, HQ(lay.h_oods_trace + 4 * k), alpha_i, a, b, c);
-            CQ(lay.c_b + 4 * k, b);
-            A = qm31_add(A, a);
-            C = qm31_add(C, c);
-            alpha_i = qm31_mul(alpha_i, deep_alpha);
-        }
-        if (lay.mode == 1) {  // FIXTURE: second batch at 2P, alpha restarts
-            CQ(lay.c_a1, A); CQ(lay.c_c1, C);
-            A = qm31_zero(); C = qm31_zero(); alpha_i = deep_alpha;
-            QM31 alpha_pow = qm31_one();
-            for (uint32_t k = 0; k < kCp; k++) {
-                QM31 a, b, c;
-                interpolant_coefficients(P2, HQ(lay.h_oods_cp + 4 * k), alpha_i, a, b, c);
-                CQ(lay.c_b + 4 * (lay.N + k), b);
-                A = qm31_add(A, a);
-                C = qm31_add(C, c);
-                alpha_i = qm31_mul(alpha_i, deep_alpha);
-                alpha_pow = qm31_mul(alpha_pow, deep_alpha);
+        uint4 *alpha_tab = reinterpret_cast<uint4 *>(ws + lay.ws_alpha) + (size_t)p * lay.n_pow;
+        auto b0_of = [](const QM31Point &sp) {
+            const CM31 im_py = q_im(sp.y);
+            return cm31_neg(cm31_add(im_py, im_py));
+        };
+        QM31 alpha_i = deep_alpha, alpha_last = deep_alpha;
+        auto batch = [&](const QM31Point &sp, CM31 b0, uint32_t h_base, uint32_t count, uint32_t tab0, QM31 &A,
+                         QM31 &C) {
+            QM31 V = qm31_zero();
+            A = qm31_zero();
+            for (uint32_t k = 0; k < count; k++) {
+                const QM31 value = HQ(h_base + 4 * k);
+                const CM31 im_v = q_im(value);
+                const CM31 a0 = cm31_neg(cm31_add(im_v, im_v));
+                alpha_tab[tab0 + k] = make_uint4(alpha_i.a, alpha_i.b, alpha_i.c, alpha_i.d);
+                A = qm31_add(A, qm31_mul_im_c(alpha_i, a0));
+                V = qm31_add(V, qm31_mul_c(alpha_i, qm31_red(value)));
+                alpha_last = alpha_i;
+                alpha_i = qm31_mul_c(alpha_i, deep_alpha);
             }
-            CQ(lay.c_a2, A); CQ(lay.c_c2, C);
-            CQ(lay.c_m1, alpha_pow);
+            C = qm31_sub(qm31_mul_im_c(V, b0), qm31_mul_c(A, sp.y));
+        };
+        const CM31 b01 = b0_of(P), b02 = b0_of(P2);
+        CQ(lay.c_b01, q_make(CM31{0, 0}, b01));
+        CQ(lay.c_b02, q_make(CM31{0, 0}, b02));
+        QM31 A1, C1, A2, C2;
+        batch(P, b01, lay.h_oods_trace, lay.N, 0, A1, C1);
+        if (lay.mode == 1) {  // FIXTURE: second batch at 2P, alpha restarts (same powers, rewritten)
+            alpha_i = deep_alpha;
+            batch(P2, b02, lay.h_oods_cp, kCp, 0, A2, C2);
+            CQ(lay.c_a1, A1); CQ(lay.c_c1, C1);
+            CQ(lay.c_a2, A2); CQ(lay.c_c2, C2);
+            CQ(lay.c_m1, alpha_last);  // alpha^16
         } else {  // LITERAL: one batch over all N + 16 columns at P
-            for (uint32_t k = 0; k < kCp; k++) {
-                QM31 a, b, c;
-                interpolant_coefficients(P, HQ(lay.h_oods_cp + 4 * k), alpha_i, a, b, c);
-                CQ(lay.c_b + 4 * (lay.N + k), b);
-                A = qm31_add(A, a);
-                C = qm31_add(C, c);
-                alpha_i = qm31_mul(alpha_i, deep_alpha);
-            }
-            CQ(lay.c_a1, A); CQ(lay.c_c1, C);
+            batch(P, b01, lay.h_oods_cp, kCp, lay.N, A2, C2);
+            CQ(lay.c_a1, qm31_add(A1, A2)); CQ(lay.c_c1, qm31_add(C1, C2));
             CQ(lay.c_a2, qm31_zero()); CQ(lay.c_c2, qm31_zero());
             CQ(lay.c_m1, alpha_i);  // alpha^(N+17), fri/answers.simf:126
         }
@@ -383,20 +381,37 @@ stwo_query_kernel(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *
         const CM31 di1 = cm31_mul_m31(CM31{d1.a, m31_neg(d1.b)}, sh_p[K + 1][lane]);
         const CM31 di2 = cm31_mul_m31(CM31{d2.a, m31_neg(d2.b)}, sh_p[K + 2][lane]);
         const uint32_t *tv = batch + lay.off_trace_vals, *cv = batch + lay.off_cp_vals;
-        QM31 s = qm31_zero();
-        for (uint32_t k = 0; k < lay.N; k++)
-            s = qm31_add(s, qm31_mul_m31(CGQ(lay.c_b + 4 * k), tv[(size_t)k * nip + inst]));
-        QM31 s2 = qm31_zero();
-        for (uint32_t k = 0; k < kCp; k++)
-            s2 = qm31_add(s2, qm31_mul_m31(CGQ(lay.c_b + 4 * (lay.N + k)), cv[(size_t)k * nip + inst]));
+        const uint4 *alpha_tab = reinterpret_cast<const uint4 *>(ws + lay.ws_alpha) + (size_t)p * lay.n_pow;
+        // sum_k alpha_k v_k with the four words kept as open 64-bit sums (three products per fold);
+        // a queried value only meets multiplications, so it is reduced on load
+        auto dot = [&](const uint32_t *vals, uint32_t count, uint32_t tab0) {
+            uint64_t sa = 0, sb = 0, sc = 0, sd = 0;
+            uint32_t open = 0;
+            for (uint32_t k = 0; k < count; k++) {
+                const uint4 al = alpha_tab[tab0 + k];
+                const uint32_t v = m31_red(vals[(size_t)k * nip + inst]);
+                sa = m31_mac(sa, al.x, v); sb = m31_mac(sb, al.y, v);
+                sc = m31_mac(sc, al.z, v); sd = m31_mac(sd, al.w, v);
+                if (++open == 3) {
+                    sa = m31_fold62(sa); sb = m31_fold62(sb); sc = m31_fold62(sc); sd = m31_fold62(sd);
+                    open = 0;
+                }
+            }
+            return QM31{m31_red64(sa), m31_red64(sb), m31_red64(sc), m31_red64(sd)};
+        };
+        const QM31 S1 = dot(tv, lay.N, 0);
+        const QM31 S2 = dot(cv, kCp, two ? 0 : lay.N);
+        const CM31 b01 = q_im(CGQ(lay.c_b01));
         if (two) {
+            const QM31 s = qm31_mul_im_c(S1, b01), s2 = qm31_mul_im_c(S2, q_im(CGQ(lay.c_b02)));
             QM31 n1 = qm31_sub(s, qm31_add(qm31_mul_m31(CGQ(lay.c_a1), dp.y), CGQ(lay.c_c1)));
             QM31 n2 = qm31_sub(s2, qm31_add(qm31_mul_m31(CGQ(lay.c_a2), dp.y), CGQ(lay.c_c2)));
             QM31 b1 = qm31_mul_cm31(n1, di1), b2 = qm31_mul_cm31(n2, di2);
-            eval = qm31_add(qm31_mul(b1, CGQ(lay.c_m1)), b2);
+            eval = qm31_add(qm31_mul_c(b1, CGQ(lay.c_m1)), b2);
         } else {
-            QM31 nn = qm31_sub(qm31_add(s, s2), qm31_add(qm31_mul_m31(CGQ(lay.c_a1), dp.y), CGQ(lay.c_c1)));
-            eval = qm31_mul(qm31_mul_cm31(nn, di1), CGQ(lay.c_m1));
+            const QM31 s = qm31_mul_im_c(qm31_add(S1, S2), b01);
+            QM31 nn = qm31_sub(s, qm31_add(qm31_mul_m31(CGQ(lay.c_a1), dp.y), CGQ(lay.c_c1)));
+            eval = qm31_mul_c(qm31_mul_cm31(nn, di1), CGQ(lay.c_m1));
         }
     }
 
@@ -418,7 +433,7 @@ stwo_query_kernel(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *
         if (l > 0 && ((query >> l) & 1)) cinv = m31_sub(0, cinv);
         QM31 f0 = qm31_add(e0, e1);
         QM31 f1 = qm31_mul_m31(qm31_sub(e0, e1), cinv);
-        eval = qm31_add(f0, qm31_mul(CGQ(lay.c_fold + 4 * l), f1));
+        eval = qm31_add(f0, qm31_mul_c(CGQ(lay.c_fold + 4 * l), f1));
         cur = position >> 1;
     }
 
