@@ -33,6 +33,7 @@ class Pipeline:
         # one head stream per slot: HEAD halves are latency bound (a few waves per CU), so
         # several of them also overlap each other; TAIL halves share one stream.
         self.head_streams = [torch.cuda.Stream(device=dev) for _ in self.slots]
+        # (a high-priority tail stream was tried: no measurable effect on MI355X)
         self.tail_stream = torch.cuda.Stream(device=dev)
         self.comm_stream = torch.cuda.Stream(device=dev)  # accept-reduce, off the kernels' path
         self.head_done = [torch.cuda.Event() for _ in self.slots]
