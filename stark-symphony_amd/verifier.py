@@ -51,6 +51,9 @@ class Pipeline:
         if self.tail_done[k] is not None:  # the slot's workspace is free again
             hs.wait_event(self.tail_done[k])
         slot.run(hs, PHASE_HEAD)
+        # a fresh event per pass: re-recording one event inside a stream capture crashes
+        # hipStreamEndCapture on ROCm 7.0 (tools/probes/graph_capture_probe.py)
+        self.head_done[k] = torch.cuda.Event()
         self.head_done[k].record(hs)
         self.tail_stream.wait_event(self.head_done[k])
         slot.run(self.tail_stream, PHASE_TAIL)
@@ -72,6 +75,55 @@ class Pipeline:
             s.synchronize()
         self.tail_stream.synchronize()
         self.comm_stream.synchronize()
+
+
+class GraphedPipeline:
+    """One pipelined pass over every slot captured ONCE into a hipGraph (the head streams and the
+    tail stream fork from and join the capture stream), then replayed with a single launch.
+
+    For small batches (stark101, a few thousand proofs) a pass costs less GPU time than the ~10
+    host-side launches and event operations that enqueue it; replaying a graph removes that bound.
+    Within a replay all HEAD halves run concurrently and the TAIL halves chain; replays on one
+    stream serialize, so keep two GraphedPipelines (own slots, own streams) in flight to overlap
+    the HEAD latency of one with the Merkle kernels of the other (tools/graph_bench.py).
+
+    Each slot is used once per graph: a head stream that waits again on a tail-stream event inside
+    the capture crashes hipStreamEndCapture on ROCm 7.0 (tools/probes/graph_capture_probe.py).
+    Per-kernel timing (`Verifier.set_timing`) must be off: timing events cannot be captured."""
+
+    def __init__(self, slots: Sequence["_DeviceBatch"]):
+        torch = _torch()
+        ver = slots[0].ver
+        if ver.timing:
+            raise RuntimeError("GraphedPipeline: switch Verifier.set_timing off before capturing")
+        self.slots = list(slots)
+        self.steps_per_replay = len(self.slots)
+        self.stream = torch.cuda.Stream(device=ver.device)
+        pipe = Pipeline(self.slots)
+        branches = pipe.head_streams + [pipe.tail_stream]
+        self.graph = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize(ver.device)
+        with torch.cuda.graph(self.graph, stream=self.stream):
+            fork = torch.cuda.Event()
+            fork.record(self.stream)
+            for s in branches:
+                s.wait_event(fork)
+            for _ in self.slots:
+                pipe.submit()
+            for s in branches:
+                join = torch.cuda.Event()
+                join.record(s)
+                self.stream.wait_event(join)
+        self._pipe = pipe  # keeps the captured streams and events alive
+
+    def replay(self) -> int:
+        """Enqueue one pass over every slot; returns the number of passes."""
+        with _torch().cuda.stream(self.stream):
+            self.graph.replay()
+        return self.steps_per_replay
+
+    def synchronize(self) -> None:
+        self.stream.synchronize()
 
 
 # ----------------------------------------------------------------------------- records
@@ -297,6 +349,7 @@ class Verifier:
         ctx = C.c_void_p()
         B.check(B.lib().ss_ctx_create(device, C.byref(ctx)))
         self.ctx = ctx
+        self.timing = False
         torch.cuda.set_device(self.device)
 
     def close(self) -> None:
@@ -313,6 +366,7 @@ class Verifier:
     # -- timing -----------------------------------------------------------------------
     def set_timing(self, on: bool) -> None:
         B.check(B.lib().ss_ctx_set_timing(self.ctx, 1 if on else 0))
+        self.timing = bool(on)
 
     def collect_timing(self) -> dict:
         """{kernel name: (total_ms, launches)} since the last collect (waits for the events)."""

@@ -323,3 +323,32 @@ def test_stwo_full_size_batch_2p20(ver):
     got = b.status()
     assert got.tolist() == [int(want_d[i]) for i in idx]
     assert b.accepted() == sum(1 for i in idx if want_d[i] == 0) >= n // 2
+
+
+def test_graphed_pipeline_matches_eager(ver, s101_proof, stwo_prod):
+    """hipGraph replay of the pipelined passes (fork / join of the head and tail streams captured
+    once) leaves the same status words and accept counts as eager submission."""
+    rng = np.random.default_rng(SEED + 17)
+    for family in ("stark101", "stwo"):
+        if family == "stark101":
+            distinct = [s101_proof] + [formats.stark101_corrupt(s101_proof, rng)[0] for _ in range(5)]
+            want_d = O.s101_verify_batch(distinct)
+            idx = [i % 6 if i % 2 else 0 for i in range(257)]
+            batch = ver.stark101_batch([distinct[i] for i in idx])
+        else:
+            distinct = [stwo_prod] + [formats.stwo_corrupt(stwo_prod, rng)[0] for _ in range(5)]
+            want_d = O.stwo_verify_batch(distinct)
+            idx = [i % 6 if i % 2 else 0 for i in range(130)]
+            batch = ver.stwo_batch([distinct[i] for i in idx])
+        want = [int(want_d[i]) for i in idx]
+        slots = [batch, batch.sibling(), batch.sibling()]
+        gp = verifier.GraphedPipeline(slots)
+        assert gp.steps_per_replay == 3
+        for _ in range(3):
+            for s in slots:
+                s.status_dev.fill_(0x55)
+            gp.replay()
+            gp.synchronize()
+            for s in slots:
+                assert s.status().tolist() == want
+                assert s.accepted() == sum(1 for w in want if w == 0)
