@@ -189,6 +189,24 @@ __device__ inline QM31 qm31_mul_im_c(QM31 x, CM31 y)
     const CM31 im = cm31_mul_c(q_re(x), y);
     return {m31_red64(ra), m31_red64(rb), im.a, im.b};
 }
+// Canonical-operand forms (a, b < P) for code that never sees a raw word (the provers): the
+// conditional subtraction is one v_min_u32 on the wrapped difference.
+__device__ __forceinline__ uint32_t m31_add_c(uint32_t a, uint32_t b)
+{
+    const uint32_t s = a + b;
+    return min(s, s - M31_P);
+}
+__device__ __forceinline__ uint32_t m31_sub_c(uint32_t a, uint32_t b)
+{
+    const uint32_t d = a - b;
+    return min(d, d + M31_P);
+}
+__device__ __forceinline__ uint32_t m31_mul_c(uint32_t a, uint32_t b)
+{
+    const uint32_t lo = a * b, hi = __umulhi(a, b);                       // a b < 2^62
+    const uint32_t s = (lo & M31_P) + __funnelshift_r(lo, hi, 31);        // x0 + (x >> 31) <= 2P
+    return min(s, s - M31_P);
+}
 __device__ __forceinline__ QM31 qm31_red(QM31 x) { return {m31_red(x.a), m31_red(x.b), m31_red(x.c), m31_red(x.d)}; }
 
 // ------------------------------------------------------ groups/m31_point.simf:33-97

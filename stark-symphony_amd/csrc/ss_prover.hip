@@ -103,6 +103,92 @@ __global__ void p_fft_layer_kernel(uint32_t m, uint32_t layer, uint32_t *__restr
     }
 }
 
+// Several consecutive butterfly layers [lo, lo + nb) in ONE pass over HBM: a block stages 2^nb rows
+// x 32 "lanes" of the layers' index space in LDS (rows = the 2^nb values of index bits
+// [lo, lo + nb)), runs the nb layers there and writes the tile back, so m layers cost ceil(m / 8)
+// read+write sweeps instead of m.
+//   strided pass (lo >= 5): lanes = 32 neighbours in the bits below lo of one column; the tile's
+//     2^nb - 1 twiddles do not depend on the lane and are staged in LDS.
+//   contiguous pass (lo = 0): lanes = G groups of 2^nb contiguous words x CPB columns (G CPB = 32).
+//     Here every butterfly of a column has its own twiddle (the table is as large as the column), so
+//     the columns of a block re-use each twiddle line from L1/L2 instead of fetching it per column.
+// Row stride 33 words keeps the row-wise (strided) and column-wise (contiguous) LDS accesses
+// conflict free.  Operands are canonical, so the butterflies use the min-based m31 forms.
+constexpr uint32_t kFftT = 32, kFftTp = 33, kFftMaxNb = 8;
+
+template <bool CONTIG>
+__global__ void __launch_bounds__(256)
+p_fft_pass_kernel(uint32_t m, uint32_t lo, uint32_t nb, uint32_t cpb_log, uint32_t *__restrict__ data,
+                  const uint32_t *__restrict__ tw, int inverse, uint32_t scale)
+{
+    __shared__ uint32_t tile[(1u << kFftMaxNb) * kFftTp];
+    __shared__ uint32_t twl[1u << kFftMaxNb];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t rows = 1u << nb, elems = rows * kFftT;
+    const uint32_t glog = 5 - cpb_log, gmask = (1u << glog) - 1;  // contiguous: lane = column * G + group
+    uint32_t hi;
+    uint32_t *col;
+    size_t base = 0;
+    if (CONTIG) {
+        hi = blockIdx.x << glog;
+        col = data + ((size_t)(blockIdx.y << cpb_log) << m);
+    } else {
+        const uint32_t chunks = (1u << lo) / kFftT;
+        hi = blockIdx.x / chunks;
+        col = data + ((size_t)blockIdx.y << m);
+        base = ((size_t)hi << (lo + nb)) + (size_t)(blockIdx.x % chunks) * kFftT;
+    }
+    auto gaddr = [&](uint32_t e) -> size_t {  // tile element e -> word offset from col
+        if (CONTIG) {
+            const uint32_t c = e >> nb;
+            return ((size_t)(c >> glog) << m) + ((size_t)(hi + (c & gmask)) << nb) + (e & (rows - 1));
+        }
+        return base + ((size_t)(e >> 5) << lo) + (e & 31);
+    };
+    auto laddr = [&](uint32_t e) -> uint32_t {
+        return CONTIG ? (e & (rows - 1)) * kFftTp + (e >> nb) : (e >> 5) * kFftTp + (e & 31);
+    };
+    for (uint32_t e = tid; e < elems; e += 256) tile[laddr(e)] = col[gaddr(e)];
+    if (!CONTIG) {  // layer ip of the tile at twl[rows - (rows >> ip) ..]
+        for (uint32_t ip = 0; ip < nb; ip++) {
+            const size_t goff = ((size_t)1 << m) - ((size_t)1 << (m - lo - ip));
+            const uint32_t cnt = rows >> (ip + 1);
+            for (uint32_t q = tid; q < cnt; q += 256)
+                twl[rows - (rows >> ip) + q] = tw[goff + ((size_t)hi << (nb - 1 - ip)) + q];
+        }
+    }
+    __syncthreads();
+    const uint32_t half = elems / 2;
+    for (uint32_t step = 0; step < nb; step++) {
+        const uint32_t ip = inverse ? step : nb - 1 - step;
+        const size_t goff = ((size_t)1 << m) - ((size_t)1 << (m - lo - ip));
+        const bool last = inverse && lo + ip + 1 == m && scale != 1;
+        for (uint32_t b = tid; b < half; b += 256) {
+            uint32_t c, pr;
+            if (CONTIG) { pr = b & (rows / 2 - 1); c = b >> (nb - 1); }
+            else { c = b & 31; pr = b >> 5; }
+            const uint32_t hl = pr >> ip;
+            const uint32_t j0 = (hl << (ip + 1)) | (pr & ((1u << ip) - 1));
+            const uint32_t w = CONTIG ? tw[goff + ((size_t)(hi + (c & gmask)) << (nb - 1 - ip)) + hl]
+                                      : twl[rows - (rows >> ip) + hl];
+            uint32_t *p0 = &tile[j0 * kFftTp + c], *p1 = p0 + (kFftTp << ip);
+            const uint32_t v0 = *p0, v1 = *p1;
+            if (inverse) {
+                uint32_t sum = m31_add_c(v0, v1), d = m31_mul_c(m31_sub_c(v0, v1), w);
+                if (last) { sum = m31_mul_c(sum, scale); d = m31_mul_c(d, scale); }
+                *p0 = sum;
+                *p1 = d;
+            } else {
+                const uint32_t x = m31_mul_c(v1, w);
+                *p0 = m31_add_c(v0, x);
+                *p1 = m31_sub_c(v0, x);
+            }
+        }
+        __syncthreads();
+    }
+    for (uint32_t e = tid; e < elems; e += 256) col[gaddr(e)] = tile[laddr(e)];
+}
+
 // --------------------------------------------------------------------------------- hashing
 template <int HF>
 __global__ void p_hash_rows_kernel(size_t n, uint32_t w, const uint32_t *__restrict__ cols, size_t stride,
@@ -289,10 +375,30 @@ extern "C" int ss_p_fft(ss_ctx *, uint32_t m, uint32_t ncols, uint32_t *data, co
                         void *stream)
 {
     if (!data || !tw || m < 1 || m > 28 || !ncols) return ss_internal_set_err(SS_ERR_ARG, "ss_p_fft: bad argument");
+    // 2^-m mod P = 2^(31-m) because 2^31 == 1
+    const uint32_t scale = (1u << ((31 - (m % 31)) % 31)) % M31_P;
+    if (m >= 13) {
+        // ceil(m / 8) LDS-staged passes of 5..8 layers each; the lowest pass is the contiguous one
+        const uint32_t k = (m + 7) / 8, base = m / k, extra = m % k;
+        uint32_t lo[4], nb[4];
+        for (uint32_t i = 0, at = 0; i < k; i++) { lo[i] = at; nb[i] = base + (i < extra ? 1 : 0); at += nb[i]; }
+        uint32_t cpb_log = 0;  // columns per block of the contiguous pass: 8, 4, 2 or 1
+        while (cpb_log < 3 && ncols % (2u << cpb_log) == 0) cpb_log++;
+        for (uint32_t s = 0; s < k; s++) {
+            const uint32_t i = inverse ? s : k - 1 - s;
+            if (i == 0)
+                hipLaunchKernelGGL(p_fft_pass_kernel<true>, dim3((1u << (m - nb[i])) >> (5 - cpb_log), ncols >> cpb_log),
+                                   dim3(256), 0, (hipStream_t)stream, m, lo[i], nb[i], cpb_log, data, tw, inverse,
+                                   scale);
+            else
+                hipLaunchKernelGGL(p_fft_pass_kernel<false>, dim3((1u << (m - nb[i])) / kFftT, ncols), dim3(256), 0,
+                                   (hipStream_t)stream, m, lo[i], nb[i], 0u, data, tw, inverse, scale);
+        }
+        P_TRY(hipGetLastError());
+        return SS_OK;
+    }
     const dim3 grid(blocks_for(1u << (m - 1)), ncols);
     if (inverse) {
-        // 2^-m mod P = 2^(31-m) because 2^31 == 1
-        const uint32_t scale = (1u << ((31 - (m % 31)) % 31)) % M31_P;
         for (uint32_t i = 0; i < m; i++)
             hipLaunchKernelGGL(p_fft_layer_kernel, grid, dim3(256), 0, (hipStream_t)stream, m, i, data, tw, 1,
                                i + 1 == m ? scale : 1u);
