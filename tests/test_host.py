@@ -230,3 +230,23 @@ def test_group_by_config_keeps_input_order():
     b = ss.stwo_from_json(json.load(open(os.path.join(g, "stwo_proof_test.json"))))
     assert verifier.group_by_config([a, b, a, a, b]) == [[0, 2, 3], [1, 4]]
     assert verifier.group_by_config([]) == []
+
+
+def test_stark101_prover_channel_replays_the_reference_transcript():
+    """prover101._Channel (channel.py:41-96) driven with the roots of the reference's proof draws the
+    reference's betas and its query index (6160, stark101/src/verifier.simf:44-388)."""
+    from stark_symphony_amd import prover101
+    j = json.load(open(os.path.join(ROOT, "tests", "golden", "stark101_proof.json")))
+    ch = prover101._Channel()
+    ch.mix(int(j["p_mt_root"]).to_bytes(32, "big"))
+    alphas = [ch.field_element() for _ in range(3)]
+    assert alphas == [2843266690, 519917353, 1882164991]  # air.simf:103-137 known answers
+    layers = j["fri_layers"]
+    ch.mix(int(layers[0][0]).to_bytes(32, "big"))
+    for i, layer in enumerate(layers):
+        assert ch.field_element() == layer[1]
+        if i + 1 < len(layers):
+            ch.mix(int(layers[i + 1][0]).to_bytes(32, "big"))
+    ch.mix(int(j["fri_last_layer"]).to_bytes(4, "big"))
+    assert ch.random_int(0, 8191) == 6160
+    assert prover101.trace_reference()[1022] == prover101.REFERENCE_CLAIM
