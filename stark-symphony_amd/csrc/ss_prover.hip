@@ -158,31 +158,70 @@ p_fft_pass_kernel(uint32_t m, uint32_t lo, uint32_t nb, uint32_t cpb_log, uint32
         }
     }
     __syncthreads();
-    const uint32_t half = elems / 2;
-    for (uint32_t step = 0; step < nb; step++) {
-        const uint32_t ip = inverse ? step : nb - 1 - step;
-        const size_t goff = ((size_t)1 << m) - ((size_t)1 << (m - lo - ip));
-        const bool last = inverse && lo + ip + 1 == m && scale != 1;
-        for (uint32_t b = tid; b < half; b += 256) {
-            uint32_t c, pr;
-            if (CONTIG) { pr = b & (rows / 2 - 1); c = b >> (nb - 1); }
-            else { c = b & 31; pr = b >> 5; }
-            const uint32_t hl = pr >> ip;
-            const uint32_t j0 = (hl << (ip + 1)) | (pr & ((1u << ip) - 1));
-            const uint32_t w = CONTIG ? tw[goff + ((size_t)(hi + (c & gmask)) << (nb - 1 - ip)) + hl]
-                                      : twl[rows - (rows >> ip) + hl];
-            uint32_t *p0 = &tile[j0 * kFftTp + c], *p1 = p0 + (kFftTp << ip);
-            const uint32_t v0 = *p0, v1 = *p1;
-            if (inverse) {
-                uint32_t sum = m31_add_c(v0, v1), d = m31_mul_c(m31_sub_c(v0, v1), w);
-                if (last) { sum = m31_mul_c(sum, scale); d = m31_mul_c(d, scale); }
-                *p0 = sum;
-                *p1 = d;
-            } else {
-                const uint32_t x = m31_mul_c(v1, w);
-                *p0 = m31_add_c(v0, x);
-                *p1 = m31_sub_c(v0, x);
+    // twiddle of local layer ip, butterfly group hl (= row >> (ip + 1)), lane c
+    auto twid = [&](uint32_t ip, uint32_t hl, uint32_t c) -> uint32_t {
+        if (CONTIG) {
+            const size_t goff = ((size_t)1 << m) - ((size_t)1 << (m - ip));
+            return tw[goff + ((size_t)(hi + (c & gmask)) << (nb - 1 - ip)) + hl];
+        }
+        return twl[rows - (rows >> ip) + hl];
+    };
+    auto bfly = [&](uint32_t &v0, uint32_t &v1, uint32_t w) {
+        if (inverse) {
+            const uint32_t sum = m31_add_c(v0, v1);
+            v1 = m31_mul_c(m31_sub_c(v0, v1), w);
+            v0 = sum;
+        } else {
+            const uint32_t x = m31_mul_c(v1, w);
+            v1 = m31_sub_c(v0, x);
+            v0 = m31_add_c(v0, x);
+        }
+    };
+    // Two layers per LDS round trip (four rows per thread, three twiddles), one when nb is odd.
+    for (uint32_t done = 0; done < nb;) {
+        if (nb - done >= 2) {
+            const uint32_t a = inverse ? done : nb - 2 - done;  // local layers a and a + 1
+            const bool last = inverse && lo + a + 2 == m && scale != 1;
+            for (uint32_t q = tid; q < elems / 4; q += 256) {
+                uint32_t c, pq;
+                if (CONTIG) { pq = q & (rows / 4 - 1); c = q >> (nb - 2); }
+                else { c = q & 31; pq = q >> 5; }
+                const uint32_t hq = pq >> a;
+                const uint32_t j0 = (hq << (a + 2)) | (pq & ((1u << a) - 1));
+                uint32_t *p0 = &tile[j0 * kFftTp + c], *p1 = p0 + (kFftTp << a), *p2 = p0 + (kFftTp << (a + 1)),
+                         *p3 = p1 + (kFftTp << (a + 1));
+                uint32_t v0 = *p0, v1 = *p1, v2 = *p2, v3 = *p3;
+                const uint32_t wa0 = twid(a, 2 * hq, c), wa1 = twid(a, 2 * hq + 1, c), wb = twid(a + 1, hq, c);
+                if (inverse) {
+                    bfly(v0, v1, wa0); bfly(v2, v3, wa1);
+                    bfly(v0, v2, wb);  bfly(v1, v3, wb);
+                    if (last) {
+                        v0 = m31_mul_c(v0, scale); v1 = m31_mul_c(v1, scale);
+                        v2 = m31_mul_c(v2, scale); v3 = m31_mul_c(v3, scale);
+                    }
+                } else {
+                    bfly(v0, v2, wb);  bfly(v1, v3, wb);
+                    bfly(v0, v1, wa0); bfly(v2, v3, wa1);
+                }
+                *p0 = v0; *p1 = v1; *p2 = v2; *p3 = v3;
             }
+            done += 2;
+        } else {
+            const uint32_t ip = inverse ? done : 0;  // the odd layer: last (inverse) or lowest (forward)
+            const bool last = inverse && lo + ip + 1 == m && scale != 1;
+            for (uint32_t b = tid; b < elems / 2; b += 256) {
+                uint32_t c, pr;
+                if (CONTIG) { pr = b & (rows / 2 - 1); c = b >> (nb - 1); }
+                else { c = b & 31; pr = b >> 5; }
+                const uint32_t hl = pr >> ip;
+                const uint32_t j0 = (hl << (ip + 1)) | (pr & ((1u << ip) - 1));
+                uint32_t *p0 = &tile[j0 * kFftTp + c], *p1 = p0 + (kFftTp << ip);
+                uint32_t v0 = *p0, v1 = *p1;
+                bfly(v0, v1, twid(ip, hl, c));
+                if (last) { v0 = m31_mul_c(v0, scale); v1 = m31_mul_c(v1, scale); }
+                *p0 = v0; *p1 = v1;
+            }
+            done += 1;
         }
         __syncthreads();
     }
