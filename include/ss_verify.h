@@ -196,7 +196,10 @@ int ss_ctx_collect_timing(ss_ctx *ctx, int cap, const char **names, float *total
  *   op 1  m31: in (a, b) -> out (add, sub, mul, inv(a) or 0xffffffff when a == 0)
  *   op 2  qm31: in (a[4], b[4]) -> out (mul[4], inv(a)[4] or all-ones on abort)
  *   op 3  circle point of index: in idx -> out (x, y)
- *   op 4  stark101 field: in (a, b) -> out (add, sub, mul, div(a,b) or 0xffffffff on abort) */
+ *   op 4  stark101 field: in (a, b) -> out (add, sub, mul, div(a,b) or 0xffffffff on abort)
+ *   op 5  lazily reduced M31 forms on words in [0, P]: in (a[4], b[4]) -> out 16 words
+ *         (a*b [4], a*a [4], a*(0 + im(b) u) [4], then for x = a[0] mod P, y = b[0] mod P:
+ *         x+y, x-y, x*y, and (a[1] * 2^32 + b[1]) mod P)                                      */
 int ss_selftest(ss_ctx *ctx, int op, size_t n, const uint32_t *in_host, uint32_t *out_host);
 
 #ifdef __cplusplus

@@ -663,14 +663,27 @@ __global__ void selftest_kernel(int op, uint32_t n, const uint32_t *in, uint32_t
         out[4 * i + 3] = f101_div(a, b, d) ? d : 0xffffffffu;
         break;
     }
+    case 5: {  // lazily reduced forms on operands in [0, P]: mul, sqr, mul by (0 + y u), canonical add/sub/mul
+        QM31 a = {in[8 * i], in[8 * i + 1], in[8 * i + 2], in[8 * i + 3]};
+        QM31 b = {in[8 * i + 4], in[8 * i + 5], in[8 * i + 6], in[8 * i + 7]};
+        const QM31 m = qm31_mul_c(a, b), s = qm31_sqr_c(a), h = qm31_mul_im_c(a, q_im(b));
+        uint32_t *o = out + 16 * i;
+        o[0] = m.a; o[1] = m.b; o[2] = m.c; o[3] = m.d;
+        o[4] = s.a; o[5] = s.b; o[6] = s.c; o[7] = s.d;
+        o[8] = h.a; o[9] = h.b; o[10] = h.c; o[11] = h.d;
+        const uint32_t x = m31_red(a.a), y = m31_red(b.a);  // strictly canonical for the min-based forms
+        o[12] = m31_add_c(x, y); o[13] = m31_sub_c(x, y); o[14] = m31_mul_c(x, y);
+        o[15] = m31_red64(((uint64_t)a.b << 32) | b.b);
+        break;
+    }
     }
 }
 }  // namespace ss
 
 extern "C" int ss_selftest(ss_ctx *ctx, int op, size_t n, const uint32_t *in_host, uint32_t *out_host)
 {
-    static const int in_w[5] = {16, 2, 8, 1, 2}, out_w[5] = {8, 4, 8, 2, 4};
-    if (!ctx || !in_host || !out_host || op < 0 || op > 4 || !n) return set_err(SS_ERR_ARG, "bad argument");
+    static const int in_w[6] = {16, 2, 8, 1, 2, 8}, out_w[6] = {8, 4, 8, 2, 4, 16};
+    if (!ctx || !in_host || !out_host || op < 0 || op > 5 || !n) return set_err(SS_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(ctx->device));
     DevBuf a, b;
     HIP_TRY(hipMalloc(&a.p, n * in_w[op] * 4));

@@ -352,3 +352,23 @@ def test_graphed_pipeline_matches_eager(ver, s101_proof, stwo_prod):
             for s in slots:
                 assert s.status().tolist() == want
                 assert s.accepted() == sum(1 for w in want if w == 0)
+
+
+def test_lazily_reduced_field_forms(ver):
+    """qm31_mul_c / qm31_sqr_c / qm31_mul_im_c / m31_*_c / m31_red64 (ss_fields.h) against the
+    oracle's reference-order arithmetic, on words in [0, P] including 0, 1, P - 1 and P."""
+    P = 2147483647
+    rng = np.random.default_rng(SEED + 18)
+    v = rng.integers(0, P, size=(4096, 8), dtype=np.uint32)
+    edge = np.array([0, 1, 2, P - 2, P - 1, P], dtype=np.uint32)
+    v[:512] = rng.choice(edge, size=(512, 8))
+    v[512:1024, ::2] = rng.choice(edge, size=(512, 4))
+    got = ver.selftest(5, v)
+    L = O.lib()
+    for row, g in zip(v.tolist(), got.tolist()):
+        a, b = O.qm(row[:4]), O.qm(row[4:])
+        im_b = O.qm([0, 0, row[6], row[7]])
+        want = list(L.so_qm31_mul(a, b).t()) + list(L.so_qm31_mul(a, a).t()) + list(L.so_qm31_mul(a, im_b).t())
+        x, y = row[0] % P, row[4] % P
+        want += [(x + y) % P, (x - y) % P, (x * y) % P, ((row[1] << 32) | row[5]) % P]
+        assert g == want, (row, g, want)
