@@ -95,6 +95,15 @@ def parse_literal(text: str) -> Any:
             if pos >= n or text[pos] != "[":
                 raise MalformedProof("expected '[' after list!")
             return seq("]")
+        if text.startswith("qm31", pos):  # qm31(a, b, c, d) constructor of the .simf snippets
+            pos += 4
+            skip()
+            if pos >= n or text[pos] != "(":
+                raise MalformedProof("expected '(' after qm31")
+            w = seq(")")
+            if not isinstance(w, list) or len(w) != 4:
+                raise MalformedProof("qm31 takes four words")
+            return [[w[0], w[1]], [w[2], w[3]]]
         if ch == "(":
             return seq(")")
         if ch == "[":
@@ -247,6 +256,32 @@ def stark101_to_wit(p: Stark101Proof) -> str:
         "FRI_LAST_LAYER": {"value": str(j["fri_last_layer"]), "type": "u32"},
     }
     return json.dumps(res, indent=4)
+
+
+def stark101_to_simf(p: Stark101Proof) -> str:
+    """The ``let proof: FibSquareProof = (...);`` snippet stark101/scripts/generate_simf.py prints
+    (the literal embedded in stark101/src/verifier.simf:44-388), same text."""
+    j = stark101_to_json(p)
+
+    def nodes(path: List[int]) -> str:
+        return "list![\n                %s\n            ]" % ",\n                ".join(str(x) for x in path)
+
+    def ev(e: List[Any]) -> str:
+        return "        (\n            %d,\n            %s,\n        )," % (e[0], nodes(e[1]))
+
+    def layer(l: List[Any]) -> str:
+        return ("\n        (\n            %d,\n            %d,\n            %d,\n            %s,\n            %d,\n"
+                "            %s\n        )" % (l[0], l[1], l[2], nodes(l[3]), l[4], nodes(l[5])))
+    return ("\nlet proof: FibSquareProof = (\n    %d,\n    (\n%s\n    ),\n    list![\n        %s\n    ],\n    %d\n);\n"
+            % (j["p_mt_root"], "\n".join(ev(e) for e in j["evals"]),
+               ",\n             ".join(layer(l) for l in j["fri_layers"]), j["fri_last_layer"]))
+
+
+def stark101_from_simf(text: str) -> Stark101Proof:
+    v = _simf_body(text, "FibSquareProof")
+    if not isinstance(v, list) or len(v) != 4:
+        raise MalformedProof("FibSquareProof has four fields")
+    return _s101_from_parts(v[0], v[1], v[2], v[3])
 
 
 # ----------------------------------------------------------------------------- stwo
@@ -456,6 +491,12 @@ def stwo_from_wit(text: Any, trace_log: int, pow_bits: int = 5, hash: str = "sha
         nonce = parse_literal(obj["POW_NONCE"]["value"])
     except KeyError as e:
         raise MalformedProof("missing witness %s" % e) from e
+    return _stwo_from_parts(com, dec, oods, fric, frid, nonce, trace_log, pow_bits, hash)
+
+
+def _stwo_from_parts(com: Any, dec: Any, oods: Any, fric: Any, frid: Any, nonce: Any, trace_log: int,
+                     pow_bits: int, hash: str) -> StwoProof:
+    """The six fields of `StarkProof` (stwo-verifier/src/verifier.simf:22-33) as parsed literals."""
     try:
         roots = np.stack([np.frombuffer(u256_to_bytes(c), dtype=np.uint8) for c in com])
         Q = len(dec)
@@ -532,6 +573,65 @@ def stwo_to_wit(p: StwoProof) -> str:
         "POW_NONCE": {"value": str(int(p.pow_nonce)), "type": "u64"},
     }
     return json.dumps(wit, indent=4)
+
+
+def _simf_body(text: str, what: str) -> Any:
+    """``let proof: T = <literal>;`` -> the parsed literal."""
+    s = text.strip()
+    if not s.startswith("let ") or "=" not in s:
+        raise MalformedProof("expected `let proof: %s = (...);`" % what)
+    body = s[s.index("=") + 1:].strip()
+    if body.endswith(";"):
+        body = body[:-1]
+    return parse_literal(body)
+
+
+def stwo_to_simf(p: StwoProof) -> str:
+    """The ``let proof: Proof = (...);`` snippet stwo-verifier/scripts/generate_simf.py:160-228
+    prints for pasting into a ``.simf`` test (e.g. verifier.simf:63), same text."""
+    def hx(b: Any) -> str:
+        return "0x" + bytes(b).hex()
+
+    def q(v: Sequence[int]) -> str:
+        return "qm31(%d, %d, %d, %d)" % (int(v[0]), int(v[1]), int(v[2]), int(v[3]))
+
+    def lst(pth: np.ndarray) -> str:
+        return "list![" + ", ".join(hx(n) for n in pth) + "]"
+
+    def indent(text: str, spaces: int) -> str:
+        pad = " " * spaces
+        return "\n".join(pad + line if line else line for line in text.splitlines())
+
+    def layer(i: int) -> str:
+        items = ["(\n            %s,\n            %s\n        )" % (q(p.fri_witness[i, j]), lst(p.fri_paths[i][j]))
+                 for j in range(p.cfg.n_queries)]
+        return "[\n        " + ",\n        ".join(items) + "\n    ]"
+    Q, K = p.cfg.n_queries, p.cfg.n_layers
+    commitments = "(\n        %s,\n        %s,\n        %s,\n    )" % tuple(hx(r) for r in p.roots)
+    dec_items = []
+    for i in range(Q):
+        tv = "[" + ", ".join("[%d]" % int(x) for x in p.trace_vals[i]) + "]"
+        cv = "[" + ", ".join(str(int(x)) for x in p.cp_vals[i]) + "]"
+        dec_items.append("(\n            (%s, %s),\n            (%s, %s),\n        )"
+                         % (tv, lst(p.trace_paths[i]), cv, lst(p.cp_paths[i])))
+    decommitments = "[\n        " + ",\n        ".join(dec_items) + "\n    ]"
+    oods = "(\n        %s,\n        %s,\n    )" % (
+        "[" + ", ".join("[" + q(v) + "]" for v in p.oods_trace) + "]",
+        "[" + ", ".join(q(v) for v in p.oods_cp) + "]")
+    fri_commitments = "(\n        %s,\n        %s,\n        %s,\n    )" % (
+        hx(p.fri_roots[0]), "[" + ", ".join(hx(r) for r in p.fri_roots[1:]) + "]", q(p.last_layer))
+    inner = "[\n" + ",\n".join(indent(layer(i), 8) for i in range(1, K + 1)) + "\n    ]"
+    fri_decommitments = "(\n" + indent(layer(0), 8) + ",\n" + indent(inner, 4) + "\n    )"
+    return ("let proof: Proof = (\n    %s,\n    %s,\n    %s,\n    %s,\n    %s,\n    %d\n);"
+            % (commitments, decommitments, oods, fri_commitments, fri_decommitments, int(p.pow_nonce)))
+
+
+def stwo_from_simf(text: str, trace_log: int, pow_bits: int = 5, hash: str = "sha256") -> StwoProof:
+    """Reads the snippet back (it carries no config, like the ``.wit``)."""
+    v = _simf_body(text, "Proof")
+    if not isinstance(v, list) or len(v) != 6:
+        raise MalformedProof("Proof has six fields")
+    return _stwo_from_parts(v[0], v[1], v[2], v[3], v[4], v[5], trace_log, pow_bits, hash)
 
 
 # ------------------------------------------------------------- seeded corruption (tests / bench)

@@ -250,3 +250,48 @@ def test_stark101_prover_channel_replays_the_reference_transcript():
     ch.mix(int(j["fri_last_layer"]).to_bytes(4, "big"))
     assert ch.random_int(0, 8191) == 6160
     assert prover101.trace_reference()[1022] == prover101.REFERENCE_CLAIM
+
+
+FORMATS = os.path.join(ROOT, "tests", "golden", "formats")
+
+
+@pytest.mark.parametrize("name,trace_log", [("stwo_proof", 9), ("stwo_proof_test", 3)])
+def test_stwo_writers_equal_the_reference_adapters(name, trace_log):
+    """tests/golden/formats/* were printed by the reference's generate_wit.py / generate_simf.py
+    (tests/golden/make_format_golden.py): our writers give the same bytes, our readers the same proof."""
+    p = ss.stwo_from_json(json.load(open(os.path.join(ROOT, "tests", "golden", name + ".json"))))
+    wit = open(os.path.join(FORMATS, name + ".wit")).read()
+    simf = open(os.path.join(FORMATS, name + ".simf.txt")).read()
+    assert ss.stwo_to_wit(p) + "\n" == wit
+    assert ss.stwo_to_simf(p) + "\n" == simf
+    for back in (ss.stwo_from_wit(wit, trace_log, p.cfg.pow_bits), ss.stwo_from_simf(simf, trace_log, p.cfg.pow_bits)):
+        assert back.cfg == p.cfg and ss.stwo_to_json(back) == ss.stwo_to_json(p)
+
+
+def test_stark101_writers_equal_the_reference_adapters(s101_proof):
+    wit = open(os.path.join(FORMATS, "stark101_proof.wit")).read()
+    simf = open(os.path.join(FORMATS, "stark101_proof.simf.txt")).read()
+    assert ss.stark101_to_wit(s101_proof) + "\n" == wit
+    assert ss.stark101_to_simf(s101_proof) + "\n" == simf
+    want = ss.stark101_to_json(s101_proof)
+    assert ss.stark101_to_json(ss.stark101_from_wit(wit)) == want
+    assert ss.stark101_to_json(ss.stark101_from_simf(simf)) == want
+    with pytest.raises(ss.MalformedProof):
+        ss.stark101_from_simf("proof = 1")
+    with pytest.raises(ss.MalformedProof):
+        ss.stwo_from_simf("let proof: Proof = (1, 2, 3);", 9)
+
+
+def test_cli_convert_prints_what_the_reference_adapters_print():
+    from stark_symphony_amd import cli
+    import contextlib
+    import io
+    src = os.path.join(ROOT, "tests", "golden", "stwo_proof_test.json")
+    for to, fixture in (("wit", "stwo_proof_test.wit"), ("simf", "stwo_proof_test.simf.txt")):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            assert cli.main(["convert", "--family", "stwo", "--to", to, src]) == 0
+        assert buf.getvalue() == open(os.path.join(FORMATS, fixture)).read()
+    with contextlib.redirect_stderr(io.StringIO()):
+        assert cli.main(["convert", "--family", "stwo", "--to", "wit",
+                         os.path.join(FORMATS, "stwo_proof_test.wit")]) == 1  # needs --trace-log
