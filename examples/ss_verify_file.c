@@ -1,0 +1,98 @@
+/*
+ * ss_verify_file.c -- the C ABI of libss_verify.so from plain C (no Python, no torch).
+ *
+ * What a non-Python host (the reference's Rust CLI through FFI) does:
+ * read raw records, call ss_stwo_verify_records, map the status words to the exit status of
+ * `simfony run` (simfony-cli/src/main.rs:254-257: 0 = every proof accepted, 1 otherwise).
+ *
+ *   ss_verify_file stwo <n_cols> <trace_log> <lde_log> <n_queries> <n_layers> <pow_bits> <hash 0|1> \
+ *                  <mode 0|1> records.bin
+ *   ss_verify_file stark101 <max_layers> <max_path> records.bin
+ *
+ * records.bin = the records back to back, little-endian u32 words (include/ss_verify.h; written by
+ * stark_symphony_amd.records / verifier.stwo_record).  Build:
+ *   gcc -O2 -Iinclude examples/ss_verify_file.c -o build/ss_verify_file -Lstark-symphony_amd -lss_verify \
+ *       -Wl,-rpath,$PWD/stark-symphony_amd
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "ss_verify.h"
+
+static uint32_t *read_words(const char *path, size_t *n_words)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) { perror(path); return NULL; }
+    fseek(f, 0, SEEK_END);
+    long bytes = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (bytes <= 0 || bytes % 4) { fprintf(stderr, "%s: not a whole number of words\n", path); fclose(f); return NULL; }
+    uint32_t *w = (uint32_t *)malloc((size_t)bytes);
+    if (!w || fread(w, 1, (size_t)bytes, f) != (size_t)bytes) { fprintf(stderr, "%s: read failed\n", path); fclose(f); free(w); return NULL; }
+    fclose(f);
+    *n_words = (size_t)bytes / 4;
+    return w;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) { fprintf(stderr, "usage: see the header of examples/ss_verify_file.c\n"); return 2; }
+    const int stwo = strcmp(argv[1], "stwo") == 0;
+    if ((stwo && argc != 11) || (!stwo && (strcmp(argv[1], "stark101") != 0 || argc != 5))) {
+        fprintf(stderr, "usage: see the header of examples/ss_verify_file.c\n");
+        return 2;
+    }
+    ss_stwo_cfg cfg;
+    ss_s101_shape shape;
+    size_t rec_words;
+    const char *path;
+    memset(&cfg, 0, sizeof cfg);
+    if (stwo) {
+        cfg.n_cols = (uint32_t)atoi(argv[2]);
+        cfg.trace_log = (uint32_t)atoi(argv[3]);
+        cfg.lde_log = (uint32_t)atoi(argv[4]);
+        cfg.n_queries = (uint32_t)atoi(argv[5]);
+        cfg.n_layers = (uint32_t)atoi(argv[6]);
+        const int pow_bits = atoi(argv[7]);
+        /* POW_TARGET_64 = 2^(64 - bits) - 1, compared with lt_64 (config.simf:32, pow.simf:32) */
+        cfg.pow_target = pow_bits <= 0 ? UINT64_MAX : (pow_bits >= 64 ? 0 : ((uint64_t)1 << (64 - pow_bits)) - 1);
+        cfg.hash = (uint32_t)atoi(argv[8]);
+        cfg.mode = (uint32_t)atoi(argv[9]);
+        rec_words = ss_stwo_record_words(&cfg);
+        path = argv[10];
+    } else {
+        shape.max_layers = (uint32_t)atoi(argv[2]);
+        shape.max_path = (uint32_t)atoi(argv[3]);
+        rec_words = ss_s101_record_words(&shape);
+        path = argv[4];
+    }
+    if (!rec_words) { fprintf(stderr, "unsupported configuration\n"); return 2; }
+    size_t n_words = 0;
+    uint32_t *words = read_words(path, &n_words);
+    if (!words) return 2;
+    if (n_words % rec_words) { fprintf(stderr, "%s: %zu words is not a multiple of the %zu-word record\n", path, n_words, rec_words); return 2; }
+    const size_t n = n_words / rec_words;
+    const uint32_t **recs = (const uint32_t **)malloc(n * sizeof *recs);
+    uint32_t *status = (uint32_t *)malloc(n * sizeof *status);
+    for (size_t i = 0; i < n; i++) recs[i] = words + i * rec_words;
+
+    ss_ctx *ctx = NULL;
+    int rc = ss_ctx_create(0, &ctx);
+    if (rc == SS_OK)
+        rc = stwo ? ss_stwo_verify_records(ctx, &cfg, n, recs, NULL, status)
+                  : ss_s101_verify_records(ctx, &shape, n, recs, status);
+    if (rc != SS_OK) {  /* no CPU fallback: a missing GPU is an error, never a verdict */
+        fprintf(stderr, "libss_verify: %s (code %d)\n", ss_last_error(), rc);
+        return 2;
+    }
+    size_t rejected = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (status[i]) { rejected++; printf("proof %zu: REJECT (first failing assert 0x%08x)\n", i, status[i]); }
+        else printf("proof %zu: ACCEPT\n", i);
+    }
+    ss_ctx_destroy(ctx);
+    free(status); free(recs); free(words);
+    return rejected ? 1 : 0;
+}

@@ -372,3 +372,34 @@ def test_lazily_reduced_field_forms(ver):
         x, y = row[0] % P, row[4] % P
         want += [(x + y) % P, (x - y) % P, (x * y) % P, ((row[1] << 32) | row[5]) % P]
         assert g == want, (row, g, want)
+
+
+def test_c_abi_consumer_program(ver, tmp_path, s101_proof, stwo_prod):
+    """examples/ss_verify_file.c (plain C over include/ss_verify.h, no Python in the process):
+    verdicts and exit status equal the oracle's for a file of raw records."""
+    import subprocess
+    from test_host import _build_c_example
+    exe = _build_c_example(tmp_path)
+    rng = np.random.default_rng(SEED + 19)
+    proofs = [stwo_prod] + [formats.stwo_corrupt(stwo_prod, rng)[0] for _ in range(5)]
+    proofs = [p for p in proofs if verifier.stwo_record(p)[1] == 0]  # the file format carries no shape_status
+    want = O.stwo_verify_batch(proofs)
+    c = stwo_prod.cfg
+    path = tmp_path / "stwo.bin"
+    np.concatenate([verifier.stwo_record(p)[0] for p in proofs]).astype("<u4").tofile(path)
+    args = [exe, "stwo", str(c.n_cols), str(c.trace_log), str(c.lde_log), str(c.n_queries), str(c.n_layers),
+            str(c.pow_bits), "0", "1", str(path)]
+    r = subprocess.run(args, capture_output=True, text=True)
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == len(proofs), r.stderr
+    for i, w in enumerate(want.tolist()):
+        assert lines[i] == ("proof %d: ACCEPT" % i if w == 0 else
+                            "proof %d: REJECT (first failing assert 0x%08x)" % (i, w))
+    assert r.returncode == (1 if any(want) else 0)
+    ok = tmp_path / "one.bin"
+    verifier.stwo_record(stwo_prod)[0].astype("<u4").tofile(ok)
+    assert subprocess.run(args[:-1] + [str(ok)], capture_output=True).returncode == 0
+    ml, pm = verifier.s101_shape_of([s101_proof])
+    p101 = tmp_path / "s101.bin"
+    verifier.s101_record(s101_proof, ml, pm).astype("<u4").tofile(p101)
+    assert subprocess.run([exe, "stark101", str(ml), str(pm), str(p101)], capture_output=True).returncode == 0

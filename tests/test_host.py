@@ -295,3 +295,29 @@ def test_cli_convert_prints_what_the_reference_adapters_print():
     with contextlib.redirect_stderr(io.StringIO()):
         assert cli.main(["convert", "--family", "stwo", "--to", "wit",
                          os.path.join(FORMATS, "stwo_proof_test.wit")]) == 1  # needs --trace-log
+
+
+def _build_c_example(tmp_path):
+    exe = str(tmp_path / "ss_verify_file")
+    libdir = os.path.join(ROOT, "stark-symphony_amd")
+    subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "ss_verify_file.c"), "-o", exe, "-L" + libdir,
+                    "-lss_verify", "-Wl,-rpath," + libdir], check=True)
+    return exe
+
+
+def test_c_abi_consumer_builds_and_fails_loudly_without_a_gpu(tmp_path, s101_proof):
+    """examples/ss_verify_file.c: the header is plain C, the library links from gcc, and without
+    a GPU the program reports the library's error (exit 2) instead of producing a verdict."""
+    import torch
+    exe = _build_c_example(tmp_path)
+    ml, pm = verifier.s101_shape_of([s101_proof])
+    rec = verifier.s101_record(s101_proof, ml, pm)
+    path = tmp_path / "records.bin"
+    rec.astype("<u4").tofile(path)
+    r = subprocess.run([exe, "stark101", str(ml), str(pm), str(path)], capture_output=True, text=True)
+    if torch.cuda.is_available():
+        assert r.returncode == 0 and "proof 0: ACCEPT" in r.stdout
+    else:
+        assert r.returncode == 2 and "libss_verify" in r.stderr and "ACCEPT" not in r.stdout
+    assert subprocess.run([exe], capture_output=True).returncode == 2
