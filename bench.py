@@ -152,14 +152,22 @@ def main() -> None:
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
-    torch.cuda.set_device(local)
+    # Test hooks (1-GPU boxes): SS_BENCH_SHARE_GPU=1 puts every rank on GPU 0 and SS_BENCH_BACKEND=gloo
+    # replaces RCCL, which refuses two ranks on one device -- the multi-rank control flow of this
+    # file then runs end to end on a single GPU.  Never set by the driver.
+    dev_index = 0 if os.environ.get("SS_BENCH_SHARE_GPU") else local
+    backend = os.environ.get("SS_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     from stark_symphony_amd import verifier
     wname, family, proofs, note = load_workload(args.workload)
-    ver = verifier.Verifier(local)
+    ver = verifier.Verifier(dev_index)
 
     if family == "stwo" and args.distinct > len(proofs) and wname != "stwo_fixture":
         # More distinct valid proofs of the same configuration, made on this GPU by the prover

@@ -1,0 +1,52 @@
+"""bench.py end to end on the GPU box: the JSON contract at N=1 and the multi-rank control flow
+(two ranks sharing the one GPU over gloo -- RCCL refuses two ranks on one device, so the nccl backend
+itself is the only part of `--gpus N` this cannot cover)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+            "scaling", "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _last_json(stdout: str) -> dict:
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_json_contract():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "stwo_fixture",
+                        "--proofs-per-gpu", "2048", "--steps", "5", "--warmup", "1", "--cpu-seconds", "0.5"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert REQUIRED <= set(d) and d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 1
+    assert d["value"] > 0 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert abs(d["value"] - 2048 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["kernel_launches"] == 5
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+
+
+def test_bench_two_ranks_share_one_gpu():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SS_BENCH_SHARE_GPU="1", SS_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--workload", "stwo_fixture", "--proofs-per-gpu", "512", "--steps", "4",
+                        "--warmup", "1"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["proofs_per_gpu"] == 512 and "cpu_baseline" not in d
+    assert abs(d["value"] - 2 * 512 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
