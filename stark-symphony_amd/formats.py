@@ -113,12 +113,16 @@ def parse_literal(text: str) -> Any:
             pos += 2
             while pos < n and text[pos] in "0123456789abcdefABCDEF_":
                 pos += 1
-            return int(text[start:pos].replace("_", ""), 16)
-        while pos < n and (text[pos].isdigit() or text[pos] == "_"):
+            digits = text[start + 2:pos].replace("_", "")
+            if not digits:
+                raise MalformedProof("hex literal without digits at %d" % start)
+            return int(digits, 16)
+        while pos < n and (text[pos] in "0123456789_"):
             pos += 1
-        if start == pos:
-            raise MalformedProof("unexpected character %r at %d" % (ch, pos))
-        return int(text[start:pos].replace("_", ""))
+        digits = text[start:pos].replace("_", "")
+        if not digits:
+            raise MalformedProof("unexpected character %r at %d" % (ch, start))
+        return int(digits)
 
     def seq(close: str) -> Any:
         nonlocal pos
