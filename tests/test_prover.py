@@ -68,3 +68,31 @@ def test_committed_baseline_fixtures(name, cfg):
     for p in proofs:
         assert p.cfg == cfg
         assert O.stwo_verify(p, O.MODE_FIXTURE) == 0
+
+
+# ---------------------------------------------------------------- random shapes (hypothesis)
+from hypothesis import HealthCheck, given, settings  # noqa: E402
+from hypothesis import strategies as st  # noqa: E402
+
+_shapes = st.fixed_dictionaries(dict(
+    n_cols=st.integers(3, 9), trace_log=st.integers(2, 6), log_blowup=st.integers(1, 3),
+    n_queries=st.integers(1, 5), pow_bits=st.integers(0, 6), seed=st.integers(0, 1000),
+    hash=st.sampled_from(["sha256", "blake2s"])))
+
+
+@settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(_shapes, st.integers(0, 2 ** 31))
+def test_random_shapes_completeness_and_soundness_of_single_words(kw, mut_seed):
+    """Any shape the prover supports verifies in the oracle (FIXTURE mode), and changing one word of
+    a sampled value, queried value, FRI witness or the last layer makes it reject."""
+    import numpy as np
+    proof = ss.stwo_from_json(stwo_prover.prove(**kw))
+    assert O.stwo_verify(proof, O.MODE_FIXTURE) == 0
+    assert O.stwo_verify(proof, O.MODE_LITERAL) != 0  # SURVEY 0.1: the literal text rejects honest proofs
+    rng = np.random.default_rng(mut_seed)
+    bad = proof.copy()
+    arr = [bad.oods_trace, bad.oods_cp, bad.trace_vals, bad.cp_vals, bad.fri_witness, bad.last_layer][
+        int(rng.integers(6))].reshape(-1)
+    i = int(rng.integers(arr.size))
+    arr[i] = (int(arr[i]) + 1 + int(rng.integers(2 ** 31 - 2))) % (2 ** 31 - 1)
+    assert O.stwo_verify(bad, O.MODE_FIXTURE) != 0
