@@ -95,3 +95,24 @@ def test_stark101_gpu_prover_other_seed_is_rejected_at_the_boundary_constraint(g
         assert status == O.s101_verify(proof) != 0
         assert status == 0x400, hex(status)  # layer 0: cp_0(x) != the AIR's value (fri.simf:77)
     assert tried >= 3
+
+
+def test_random_shapes_prove_verify_and_match_the_oracle(gp):
+    """Thirty random shapes (odd column counts, query counts that do not divide 64, blow-ups 2..16,
+    both hashes): GPU prover -> GPU verifier accepts; with seeded corruptions mixed in, every status
+    word equals the oracle's, in both modes."""
+    import numpy as np
+    from stark_symphony_amd import formats, verifier
+    rng = np.random.default_rng(20261003)
+    for _ in range(30):
+        kw = dict(n_cols=int(rng.integers(3, 41)), trace_log=int(rng.integers(2, 11)),
+                  log_blowup=int(rng.integers(1, 5)), n_queries=int(rng.integers(1, 21)),
+                  pow_bits=int(rng.integers(0, 9)), seed=int(rng.integers(0, 1000)),
+                  hash=("sha256", "blake2s")[int(rng.integers(2))])
+        proof = ss.stwo_from_json(gp.prove(**kw))
+        batch = [proof] + [formats.stwo_corrupt(proof, rng)[0] for _ in range(6)]
+        for mode in (verifier.MODE_FIXTURE, verifier.MODE_LITERAL):
+            got = gp.ver.verify_stwo(batch, mode)
+            want = O.stwo_verify_batch(batch, mode)
+            assert got.tolist() == want.tolist(), (kw, mode)
+        assert gp.ver.verify_stwo(batch)[0] == 0, kw
