@@ -12,7 +12,9 @@ its own batch, total work grows with N.  Rank 0 prints ONE JSON line.
 Workloads (`--workload`):
   stwo_2p20      2^20-row wide-Fibonacci trace, blowup 2^4 (LDE 2^24), 16 queries, 19 inner FRI
                  layers, SHA-256 -- BASELINE.json configs[3], the configuration the metric is
-                 quoted on.  Proofs: tests/golden/stwo_trace20.npz (made by tools/stwo_prover.py).
+                 quoted on: a batch of 65 536 proofs (11.2 GB of records, fits one GPU) per step and
+                 per rank.  Proofs: tests/golden/stwo_trace20.npz (made by tools/stwo_prover.py) plus
+                 distinct ones made at start-up by the GPU prover (--distinct).
   stwo_fixture   the reference's own proof (tests/golden/stwo_proof.json: trace 2^9, LDE 2^13,
                  16 queries) replicated -- used when the 2^20 fixture is absent.
   stwo_2p16      BASELINE.json configs[2]: 2^16 trace, 32 queries.
@@ -193,7 +195,9 @@ def main() -> None:
         raise SystemExit("workload %s has no committed proof: needs --distinct >= 1" % wname)
     if family == "stwo":
         cfg = proofs[0].cfg
-        per_gpu = args.proofs_per_gpu or (8192 if cfg.lde_log >= 20 else 32768)
+        # BASELINE.json configs[3] is "batch of 65536 proofs": 11.2 GB of records, which fits one
+        # GPU, so that batch is the step at N=1 and (weak scaling) on every rank at N>1.
+        per_gpu = args.proofs_per_gpu or (65536 if cfg.lde_log >= 24 else 32768)
         reps = (per_gpu + len(proofs) - 1) // len(proofs)
         batch = ver.stwo_batch(proofs, verifier.MODE_FIXTURE, replicate=reps)
         bytes_per_proof, compr_per_proof = cfg.packed_bytes, cfg.compressions

@@ -308,7 +308,8 @@ def test_stwo_mixed_shapes_in_one_call(ver, stwo_small, stwo_prod):
 
 
 def test_stwo_full_size_batch_2p20(ver):
-    """BASELINE.json configs[3] at its per-GPU size: 8 192 proofs of the 2^20-trace shape (1.4 GB
+    """BASELINE.json configs[3], one GPU's share of the 65 536-proof batch split over 8 GPUs
+    (bench.py itself asserts that all 65 536 resident proofs accept): 8 192 proofs of the 2^20-trace shape (1.4 GB
     resident), half of them seeded corruptions.  Size-independent property: the
     status vector equals the oracle's verdicts of the distinct proofs, gathered through the
     replication map, and the device accept count equals the number of valid entries."""
