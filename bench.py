@@ -106,9 +106,11 @@ def pmc_traffic(wname: str, n_local: int):
 def cpu_baseline(family, proofs, seconds: float):
     """Oracle (CPU restatement of the reference path) on this box's host cores; bounded sample."""
     from oracle import oracle as O
-    threads = O.num_procs()
+    # cores this process may really use (cgroup quota, not the 256 logical CPUs a container sees:
+    # tools/probes/oracle_scaling.py -- 256 OpenMP threads on a 16-core quota run 35 % slower than 16)
+    threads = O.effective_cpus()
     if family == "stwo":
-        chunk = max(threads * 4, 32)
+        chunk = max(threads * 16, 64)
         batch = O.StwoBatch([proofs[i % len(proofs)] for i in range(chunk)])
         run = lambda: batch.verify(O.MODE_FIXTURE, threads)  # noqa: E731
     else:
@@ -126,8 +128,9 @@ def cpu_baseline(family, proofs, seconds: float):
             break
     return {"value": done / dt, "unit": "proofs/s", "cores": threads, "kind": "port",
             "sample": "%d proofs of the same workload in %.1f s, C oracle (restatement of the "
-                      "SimplicityHL verifier; `simfony run` is not buildable here), OpenMP over proofs"
-                      % (done, dt)}
+                      "SimplicityHL verifier; `simfony run` is not buildable here), OpenMP over proofs, "
+                      "%d threads = the cores this process is allowed (%d logical CPUs visible)"
+                      % (done, dt, threads, O.num_procs())}
 
 
 def main() -> None:

@@ -343,3 +343,25 @@ def stwo_verify_batch(proofs: Sequence, mode: int = MODE_FIXTURE, threads: int =
 
 def num_procs() -> int:
     return int(lib().so_num_procs())
+
+
+def effective_cpus() -> int:
+    """Host cores this process may actually use: the scheduler affinity capped by the cgroup CPU
+    quota (a container can see 256 logical CPUs and be allowed 16 cores' worth of time; OpenMP over
+    all 256 then runs slower than over 16)."""
+    import math
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # cgroup v2
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, math.ceil(quota / period)))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, num_procs()))
