@@ -31,8 +31,64 @@ void so_sha256_blocks_reset(void) { g_blocks = 0; }
 
 static inline uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
 
+/* The CPU baseline of bench.py times this file, so the compression uses the x86 SHA extensions when
+ * the host has them (same function, FIPS 180-4; pinned by the same known-answer tests; set
+ * SS_ORACLE_NO_SHANI=1 to force the portable code below). */
+#if defined(__x86_64__)
+#include <cpuid.h>
+#include <immintrin.h>
+#include <stdlib.h>
+static int g_shani = -1;
+static int shani_available(void)
+{
+    if (g_shani < 0) {
+        unsigned a, b, c, d;
+        int ok = __get_cpuid_count(7, 0, &a, &b, &c, &d) && (b & (1u << 29));      /* SHA */
+        ok = ok && __get_cpuid(1, &a, &b, &c, &d) && (c & (1u << 19)) && (c & (1u << 9)); /* SSE4.1, SSSE3 */
+        const char *off = getenv("SS_ORACLE_NO_SHANI");
+        g_shani = ok && !(off && off[0] == '1');
+    }
+    return g_shani;
+}
+__attribute__((target("sha,sse4.1,ssse3"))) static void sha256_block_ni(uint32_t h[8], const uint8_t blk[64])
+{
+    const __m128i bswap = _mm_set_epi64x(0x0c0d0e0f08090a0bULL, 0x0405060700010203ULL);
+    __m128i tmp = _mm_shuffle_epi32(_mm_loadu_si128((const __m128i *)&h[0]), 0xB1);  /* CDAB */
+    __m128i s1 = _mm_shuffle_epi32(_mm_loadu_si128((const __m128i *)&h[4]), 0x1B);   /* EFGH */
+    __m128i s0 = _mm_alignr_epi8(tmp, s1, 8);                                        /* ABEF */
+    s1 = _mm_blend_epi16(s1, tmp, 0xF0);                                             /* CDGH */
+    const __m128i save0 = s0, save1 = s1;
+    __m128i w[4];
+    for (int i = 0; i < 4; i++)
+        w[i] = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i *)(blk + 16 * i)), bswap);
+    for (int i = 0; i < 16; i++) { /* four rounds per step */
+        __m128i t = _mm_add_epi32(w[i & 3], _mm_loadu_si128((const __m128i *)&K256[4 * i]));
+        s1 = _mm_sha256rnds2_epu32(s1, s0, t);
+        s0 = _mm_sha256rnds2_epu32(s0, s1, _mm_shuffle_epi32(t, 0x0E));
+        if (i < 12) { /* W[4(i+4) .. 4(i+4)+3] replaces W[4i ..] */
+            const __m128i w1 = w[(i + 1) & 3], w2 = w[(i + 2) & 3], w3 = w[(i + 3) & 3];
+            __m128i x = _mm_add_epi32(_mm_sha256msg1_epu32(w[i & 3], w1), _mm_alignr_epi8(w3, w2, 4));
+            w[i & 3] = _mm_sha256msg2_epu32(x, w3);
+        }
+    }
+    s0 = _mm_add_epi32(s0, save0);
+    s1 = _mm_add_epi32(s1, save1);
+    tmp = _mm_shuffle_epi32(s0, 0x1B);                 /* FEBA */
+    s1 = _mm_shuffle_epi32(s1, 0xB1);                  /* DCHG */
+    _mm_storeu_si128((__m128i *)&h[0], _mm_blend_epi16(tmp, s1, 0xF0)); /* DCBA */
+    _mm_storeu_si128((__m128i *)&h[4], _mm_alignr_epi8(s1, tmp, 8));    /* HGFE */
+}
+#endif
+
 static void sha256_block(uint32_t h[8], const uint8_t blk[64])
 {
+#if defined(__x86_64__)
+    if (shani_available()) {
+        sha256_block_ni(h, blk);
+        g_blocks++;
+        return;
+    }
+#endif
     uint32_t w[64];
     for (int i = 0; i < 16; i++)
         w[i] = ((uint32_t)blk[4 * i] << 24) | ((uint32_t)blk[4 * i + 1] << 16) |

@@ -5,6 +5,7 @@ import json
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -321,3 +322,27 @@ def test_c_abi_consumer_builds_and_fails_loudly_without_a_gpu(tmp_path, s101_pro
     else:
         assert r.returncode == 2 and "libss_verify" in r.stderr and "ACCEPT" not in r.stdout
     assert subprocess.run([exe], capture_output=True).returncode == 2
+
+
+def test_oracle_sha256_portable_and_sha_extension_paths_agree():
+    """oracle/ss_oracle.c uses the x86 SHA extensions when present (the CPU baseline times it);
+    SS_ORACLE_NO_SHANI=1 forces the portable rounds.  Same digests, same verdicts."""
+    import hashlib
+    from oracle import oracle as O
+    code = ("import sys, json; sys.path.insert(0, %r)\n"
+            "from oracle import oracle as O\n"
+            "import stark_symphony_amd as ss\n"
+            "msgs = [bytes((i * 7 + j) & 255 for j in range(n)) for i, n in enumerate((0, 1, 55, 56, 64, 65, 120, 777))]\n"
+            "p = ss.stwo_from_json(json.load(open(%r)))\n"
+            "print(json.dumps([O.sha256(m).hex() for m in msgs] + [O.stwo_verify(p, O.MODE_FIXTURE), O.stwo_verify(p, O.MODE_LITERAL)]))\n"
+            % (ROOT, os.path.join(ROOT, "tests", "golden", "stwo_proof.json")))
+    outs = []
+    for flag in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                           env=dict(os.environ, SS_ORACLE_NO_SHANI=flag), check=True)
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1]
+    msgs = [bytes((i * 7 + j) & 255 for j in range(n)) for i, n in enumerate((0, 1, 55, 56, 64, 65, 120, 777))]
+    assert outs[0][:8] == [hashlib.sha256(m).hexdigest() for m in msgs]
+    assert outs[0][8] == 0 and outs[0][9] == (7 << 24) | 1
+    assert O.sha256(b"abc") == hashlib.sha256(b"abc").digest()
