@@ -266,18 +266,20 @@ def _to_dev(a: np.ndarray, device):
 class _DeviceBatch:
     """A batch resident in HBM plus its workspace / status buffers."""
 
-    def __init__(self, ver: "Verifier", n: int, batch_host: np.ndarray, ws_bytes: int,
+    def __init__(self, ver: "Verifier", n: int, batch_host, ws_bytes: int,
                  shape_status: Optional[np.ndarray]):
+        """`batch_host`: the packed batch as a numpy array (uploaded here) or as an int32 device
+        tensor that is already resident."""
         torch = _torch()
         self.ver, self.n = ver, n
-        self.batch = _to_dev(batch_host, ver.device)
+        self.batch = batch_host if torch.is_tensor(batch_host) else _to_dev(batch_host, ver.device)
         self.ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.int32, device=ver.device)
         self.status_dev = torch.empty(n, dtype=torch.int32, device=ver.device)
         self.accept_dev = torch.zeros(1, dtype=torch.int32, device=ver.device)
         self.shape_dev = None
         if shape_status is not None and np.any(shape_status):
             self.shape_dev = _to_dev(np.ascontiguousarray(shape_status, dtype=np.uint32), ver.device)
-        self.batch_bytes = batch_host.nbytes
+        self.batch_bytes = self.batch.numel() * 4
 
     def _stream(self, stream) -> int:
         torch = _torch()
@@ -306,13 +308,28 @@ class _DeviceBatch:
 
 class StwoDeviceBatch(_DeviceBatch):
     def __init__(self, ver: "Verifier", cfg: StwoConfig, mode: int, records: Sequence[np.ndarray],
-                 shape_status: Optional[np.ndarray] = None):
+                 shape_status: Optional[np.ndarray] = None, index: Optional[Sequence[int]] = None):
+        """`index` (optional): proof i of the batch is records[index[i]].  The distinct records are
+        then uploaded once, replicated by a device gather and re-tiled by ss_stwo_pack_dev, so a
+        65 536-proof batch made of a few distinct proofs costs no 11 GB host pack and upload."""
         L = B.lib()
         self.cfg, self.mode = cfg, mode
         self.cs = stwo_cfg_struct(cfg, mode)
-        host = pack_stwo(cfg, mode, records)
-        super().__init__(ver, len(records), host, L.ss_stwo_workspace_bytes(C.byref(self.cs), len(records)),
-                         shape_status)
+        if index is None:
+            n = len(records)
+            packed = pack_stwo(cfg, mode, records)
+        else:
+            torch = _torch()
+            n = len(index)
+            distinct = _to_dev(np.ascontiguousarray(np.stack(records), dtype=np.uint32), ver.device)
+            idx = torch.as_tensor(np.asarray(index, dtype=np.int64), device=ver.device)
+            full = distinct[idx].contiguous()
+            packed = torch.empty(L.ss_stwo_batch_words(C.byref(self.cs), n), dtype=torch.int32, device=ver.device)
+            B.check(L.ss_stwo_pack_dev(ver.ctx, C.byref(self.cs), n, full.data_ptr(), packed.data_ptr(),
+                                       int(torch.cuda.current_stream(ver.device).cuda_stream)))
+            torch.cuda.synchronize(ver.device)
+            del full, distinct
+        super().__init__(ver, n, packed, L.ss_stwo_workspace_bytes(C.byref(self.cs), n), shape_status)
 
     def run(self, stream=None, phases: int = PHASE_ALL) -> None:
         """Asynchronous: enqueue the verification of the whole batch (or one half of it, see
@@ -394,8 +411,11 @@ class Verifier:
         if any(p.cfg != cfg for p in proofs):
             raise ValueError("all proofs of a batch must share one StwoConfig")
         recs, shapes = zip(*[stwo_record(p) for p in proofs])
-        return StwoDeviceBatch(self, cfg, mode, list(recs) * replicate,
-                               np.array(list(shapes) * replicate, dtype=np.uint32))
+        if replicate > 1:  # the proofs repeated `replicate` times, replicated on the device
+            index = list(range(len(recs))) * replicate
+            return StwoDeviceBatch(self, cfg, mode, list(recs), np.array(list(shapes) * replicate, dtype=np.uint32),
+                                   index=index)
+        return StwoDeviceBatch(self, cfg, mode, list(recs), np.array(shapes, dtype=np.uint32))
 
     def verify_stwo(self, proofs: Sequence[StwoProof], mode: int = MODE_FIXTURE) -> np.ndarray:
         """Status word per proof.  Proofs of different shapes (StwoConfig) may be mixed: each

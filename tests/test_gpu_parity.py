@@ -404,3 +404,17 @@ def test_c_abi_consumer_program(ver, tmp_path, s101_proof, stwo_prod):
     p101 = tmp_path / "s101.bin"
     verifier.s101_record(s101_proof, ml, pm).astype("<u4").tofile(p101)
     assert subprocess.run([exe, "stark101", str(ml), str(pm), str(p101)], capture_output=True).returncode == 0
+
+
+def test_replicated_batch_built_on_the_device_equals_the_host_pack(ver, stwo_prod):
+    """Verifier.stwo_batch(replicate=k): distinct records uploaded once, gathered and re-tiled on
+    the GPU -- the same words as packing the replicated list on the host, and the same verdicts."""
+    rng = np.random.default_rng(SEED + 20)
+    distinct = [stwo_prod] + [formats.stwo_corrupt(stwo_prod, rng)[0] for _ in range(4)]
+    b = ver.stwo_batch(distinct, verifier.MODE_FIXTURE, replicate=27)
+    recs = [verifier.stwo_record(p)[0] for p in distinct]
+    host = verifier.pack_stwo(stwo_prod.cfg, verifier.MODE_FIXTURE, recs * 27)
+    assert b.n == 135 and np.array_equal(b.batch.cpu().numpy().view(np.uint32), host)
+    b.run()
+    want = O.stwo_verify_batch(distinct).tolist()
+    assert b.status().tolist() == want * 27
