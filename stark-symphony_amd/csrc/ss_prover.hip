@@ -183,9 +183,9 @@ p_fft_pass_kernel(uint32_t m, uint32_t lo, uint32_t nb, uint32_t cpb_log, uint32
             const uint32_t a = inverse ? done : nb - 2 - done;  // local layers a and a + 1
             const bool last = inverse && lo + a + 2 == m && scale != 1;
             for (uint32_t q = tid; q < elems / 4; q += 256) {
-                uint32_t c, pq;
-                if (CONTIG) { pq = q & (rows / 4 - 1); c = q >> (nb - 2); }
-                else { c = q & 31; pq = q >> 5; }
+                // lanes of a wave differ in c: consecutive LDS words (no bank conflicts) and, in the
+                // contiguous pass, only 32 / CPB distinct twiddle addresses per 32 lanes
+                const uint32_t c = q & 31, pq = q >> 5;
                 const uint32_t hq = pq >> a;
                 const uint32_t j0 = (hq << (a + 2)) | (pq & ((1u << a) - 1));
                 uint32_t *p0 = &tile[j0 * kFftTp + c], *p1 = p0 + (kFftTp << a), *p2 = p0 + (kFftTp << (a + 1)),
@@ -210,9 +210,7 @@ p_fft_pass_kernel(uint32_t m, uint32_t lo, uint32_t nb, uint32_t cpb_log, uint32
             const uint32_t ip = inverse ? done : 0;  // the odd layer: last (inverse) or lowest (forward)
             const bool last = inverse && lo + ip + 1 == m && scale != 1;
             for (uint32_t b = tid; b < elems / 2; b += 256) {
-                uint32_t c, pr;
-                if (CONTIG) { pr = b & (rows / 2 - 1); c = b >> (nb - 1); }
-                else { c = b & 31; pr = b >> 5; }
+                const uint32_t c = b & 31, pr = b >> 5;
                 const uint32_t hl = pr >> ip;
                 const uint32_t j0 = (hl << (ip + 1)) | (pr & ((1u << ip) - 1));
                 uint32_t *p0 = &tile[j0 * kFftTp + c], *p1 = p0 + (kFftTp << ip);
