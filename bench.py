@@ -92,45 +92,125 @@ def pmc_traffic(wname: str, n_local: int):
     """HBM bytes per launch of the dominant kernel from the PMC counters.  Counters cannot be
     read from inside this process: they come from the separate rocprofv3 `--pmc FETCH_SIZE` /
     `--pmc WRITE_SIZE` passes over this same command, summarised (with the guide's gfx950
-    correction) in profiles/r01_hbm_traffic.json.  Traffic is linear in the proofs per launch."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    try:
-        d = json.load(open(path))
-    except OSError:
-        return None
-    if d.get("workload") != wname:
-        return None
-    return d["hbm_bytes_per_proof"] * n_local
+    correction) in profiles/*_hbm_traffic.json together with the commit they were measured at.
+    Traffic is linear in the proofs per launch.  -> (bytes or None, provenance string)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if d.get("workload") == wname:
+            src = "%s (rocprofv3 --pmc passes at commit %s; kernels changed since = stale)" % (
+                os.path.relpath(path, ROOT), d.get("commit", "unrecorded"))
+            return d["hbm_bytes_per_proof"] * n_local, src
+    return None, "no PMC profile of this workload under profiles/"
 
 
 def cpu_baseline(family, proofs, seconds: float):
-    """Oracle (CPU restatement of the reference path) on this box's host cores; bounded sample."""
+    """Oracle (CPU restatement of the reference path) on this box's host cores; bounded sample.
+    SURVEY.md 8d: (i) one thread, (ii) all granted cores, (iii) `simfony run` itself when the box
+    has it (it cannot be built here: SimplicityHL + Rust git forks, no cargo, no network)."""
+    import shutil
     from oracle import oracle as O
     # cores this process may really use (cgroup quota, not the 256 logical CPUs a container sees:
     # tools/probes/oracle_scaling.py -- 256 OpenMP threads on a 16-core quota run 35 % slower than 16)
     threads = O.effective_cpus()
-    if family == "stwo":
-        chunk = max(threads * 16, 64)
-        batch = O.StwoBatch([proofs[i % len(proofs)] for i in range(chunk)])
-        run = lambda: batch.verify(O.MODE_FIXTURE, threads)  # noqa: E731
-    else:
-        chunk = max(threads * 64, 512)
-        arr = O.s101_array([proofs[i % len(proofs)] for i in range(chunk)])
-        run = lambda: O.s101_verify_batch(arr, threads)  # noqa: E731
-    st = run()
-    assert (st == 0).all(), "oracle rejects the benchmark proofs"
-    done, t0 = 0, time.perf_counter()
-    while True:
-        run()
-        done += chunk
-        dt = time.perf_counter() - t0
-        if dt >= seconds:
-            break
-    return {"value": done / dt, "unit": "proofs/s", "cores": threads, "kind": "port",
-            "sample": "%d proofs of the same workload in %.1f s, C oracle (restatement of the "
-                      "SimplicityHL verifier; `simfony run` is not buildable here), OpenMP over proofs, "
-                      "%d threads = the cores this process is allowed (%d logical CPUs visible)"
-                      % (done, dt, threads, O.num_procs())}
+
+    def timed(nthreads: int, budget: float):
+        if family == "stwo":
+            chunk = max(nthreads * 16, 16)
+            batch = O.StwoBatch([proofs[i % len(proofs)] for i in range(chunk)])
+            run = lambda: batch.verify(O.MODE_FIXTURE, nthreads)  # noqa: E731
+        else:
+            chunk = max(nthreads * 64, 64)
+            arr = O.s101_array([proofs[i % len(proofs)] for i in range(chunk)])
+            run = lambda: O.s101_verify_batch(arr, nthreads)  # noqa: E731
+        st = run()
+        assert (st == 0).all(), "oracle rejects the benchmark proofs"
+        done, t0 = 0, time.perf_counter()
+        while True:
+            run()
+            done += chunk
+            dt = time.perf_counter() - t0
+            if dt >= budget:
+                return done, dt
+
+    done1, dt1 = timed(1, seconds * 0.25)
+    done, dt = timed(threads, seconds * 0.75)
+    simfony = shutil.which("simfony")
+    out = {"value": done / dt, "unit": "proofs/s", "cores": threads, "kind": "port",
+           "sample": "%d proofs of the same workload in %.1f s, C oracle (restatement of the "
+                     "SimplicityHL verifier), OpenMP over proofs, %d threads = the cores this process is "
+                     "allowed (%d logical CPUs visible)" % (done, dt, threads, O.num_procs()),
+           "single_thread": {"value": done1 / dt1, "unit": "proofs/s", "cores": 1,
+                             "sample": "%d proofs in %.1f s" % (done1, dt1)},
+           "simfony": "absent: `command -v simfony` finds nothing and it cannot be built here "
+                      "(no cargo / network); the reference path is timed through its C restatement"}
+    if simfony:  # reference CLI present: time the real thing on its own one-proof case (config 1)
+        out["simfony"] = time_simfony(simfony)
+    return out
+
+
+def time_simfony(exe: str):
+    """`simfony run main.simf --witness proof.wit` (stark101/Makefile:8-9), one process per proof."""
+    import subprocess
+    import tempfile
+    src = os.environ.get("SS_SIMFONY_PROGRAM")  # the mcpp-expanded stark101 program, if the box has one
+    if not src or not os.path.exists(src):
+        return "present at %s, but no compiled stark101 program given (SS_SIMFONY_PROGRAM)" % exe
+    wit = os.path.join(GOLDEN, "formats", "stark101_proof.wit")
+    with tempfile.TemporaryDirectory() as d:
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 5.0:
+            r = subprocess.run([exe, "run", src, "--witness", wit], cwd=d, capture_output=True)
+            if r.returncode != 0:
+                return "present at %s, `simfony run` exit %d: %s" % (exe, r.returncode, r.stderr[-200:].decode("replace"))
+            n += 1
+        return {"value": n / (time.perf_counter() - t0), "unit": "proofs/s", "cores": 1,
+                "sample": "%d x `simfony run` of the stark101 proof" % n}
+
+
+def spawn_ranks(n: int) -> int:
+    """One child process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment,
+    the same contract torch.distributed.run provides), same command line.  Rank 0's stdout -- the
+    single JSON line -- is relayed; the exit status is non-zero if any rank's is."""
+    import socket
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in env:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            env["MASTER_PORT"] = str(s.getsockname()[1])
+    env["WORLD_SIZE"] = env["LOCAL_WORLD_SIZE"] = str(n)
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    kids = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        kids.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    import threading
+    out = []
+    reader = threading.Thread(target=lambda: out.append(kids[0].stdout.read()), daemon=True)
+    reader.start()
+    bad = []
+    while not bad and any(k.poll() is None for k in kids):
+        time.sleep(0.2)
+        bad = [(r, k.returncode) for r, k in enumerate(kids) if k.poll() not in (None, 0)]
+    if bad:  # a dead rank leaves the others waiting in a collective: stop exactly the children started here
+        time.sleep(2.0)
+        for k in kids:
+            if k.poll() is None:
+                k.kill()
+    for k in kids:
+        k.wait()
+    reader.join(timeout=10)
+    if bad:
+        print("bench.py: ranks failed (rank, exit status): %s" % bad, file=sys.stderr)
+        return 1
+    sys.stdout.write(b"".join(out).decode())
+    sys.stdout.flush()
+    return 0
 
 
 def main() -> None:
@@ -148,6 +228,11 @@ def main() -> None:
                     help="batch passes in flight (one HIP stream each)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` typed as is: this process becomes the launcher.  It has not
+        # imported torch or touched HIP, so starting children is safe; it never verifies anything.
+        raise SystemExit(spawn_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
 
@@ -155,8 +240,7 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d disagrees with WORLD_SIZE=%d" % (args.gpus, world))
     # Test hooks (1-GPU boxes): SS_BENCH_SHARE_GPU=1 puts every rank on GPU 0 and SS_BENCH_BACKEND=gloo
     # replaces RCCL, which refuses two ranks on one device -- the multi-rank control flow of this
     # file then runs end to end on a single GPU.  Never set by the driver.
@@ -267,6 +351,7 @@ def main() -> None:
         k_ms, k_n = timing.get(dominant, (0.0, 0))
         k_avg_s = (k_ms / max(k_n, 1)) * 1e-3
         launch_bytes = bytes_per_proof * n_local
+        traffic, traffic_src = pmc_traffic(wname, n_local)
         achieved = launch_bytes / k_avg_s / 1e9 if k_avg_s else 0.0
         compr_s = compr_per_proof * n_local / k_avg_s if k_avg_s else 0.0
         out = {
@@ -284,7 +369,7 @@ def main() -> None:
             "hbm_gb_s": value * bytes_per_proof / 1e9,
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(wname, n_local),
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_avg_ms": k_avg_s * 1e3, "kernel_launches": k_n,
                          "algorithmic_bytes_per_launch": launch_bytes,
                          "note": "integer-ALU bound by construction (2 SHA-256 / 1 Blake2s compression "

@@ -81,7 +81,7 @@ int main(int argc, char **argv)
     ss_ctx *ctx = NULL;
     int rc = ss_ctx_create(0, &ctx);
     if (rc == SS_OK)
-        rc = stwo ? ss_stwo_verify_records(ctx, &cfg, n, recs, NULL, status)
+        rc = stwo ? ss_stwo_verify_records(ctx, &cfg, n, recs, status)
                   : ss_s101_verify_records(ctx, &shape, n, recs, status);
     if (rc != SS_OK) {  /* no CPU fallback: a missing GPU is an error, never a verdict */
         fprintf(stderr, "libss_verify: %s (code %d)\n", ss_last_error(), rc);

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define SS_VERSION 0x00010000
+#define SS_VERSION 0x00020000 /* 2.0: stwo records carry their Merkle path lengths; shape_status is gone */
 
 /* return codes (all < 0 are errors; verdicts live in the status array) */
 #define SS_OK 0
@@ -54,6 +54,10 @@ extern "C" {
 int ss_version(void);
 const char *ss_last_error(void); /* thread-local text of the last error */
 int ss_device_count(void);       /* number of visible HIP devices, <0 on error */
+/* sizeof(ss_stwo_cfg) == 40 and sizeof(ss_s101_shape) == 8 as this library was compiled: a
+ * binding written in another language checks its own struct against these once at start-up. */
+size_t ss_abi_sizeof_cfg(void);
+size_t ss_abi_sizeof_shape(void);
 
 /* ======================================================================== stark101
  * Record (ss_s101_record_words(max_layers, max_path) words, zero padded):
@@ -91,6 +95,7 @@ typedef struct ss_stwo_cfg {
     uint32_t mode;       /* SS_MODE_*                                      */
     uint64_t pow_target; /* POW_TARGET_64: digest value must be < target   */
     uint32_t hash;       /* SS_HASH_*                                      */
+    uint32_t reserved;   /* 0; explicit tail padding: sizeof == 40         */
 } ss_stwo_cfg;
 
 /* SS_HASH_SHA256 is the reference (hasher.simf:13-104, channel.simf:36-172).  SS_HASH_BLAKE2S is
@@ -113,10 +118,14 @@ typedef struct ss_stwo_cfg {
  *   last_layer[4]  pow_nonce_hi  pow_nonce_lo
  *   n_queries x { trace_vals[n_cols], cp_vals[16], trace_path[lde_log][8], cp_path[lde_log][8] }
  *   (1+n_layers) x n_queries x { witness[4], path[lde_log-1-layer][8] }
- * A Merkle path whose length differs from the shape above cannot verify in the reference
- * (`path == 1`, merkle.simf:42): the caller reports it in shape_status (code of that
- * assert, or 0) and stores zeros; the verdict is min(first device failure, shape_status).
+ *   path_len[3+n_layers][n_queries]      kind 0 trace, 1 cp, 2+l FRI layer l
+ * The reference types every Merkle path List<u256, 32> (scripts/generate_wit.py:70-103): its
+ * length is data.  path_len carries the length the proof really has; the fixed slots above hold
+ * the first min(length, slot) siblings, zero padded.  A path whose length differs from the slot
+ * cannot verify in the reference whatever it contains (`path == 1`, merkle.simf:42) and the
+ * library reports the code of exactly that assert -- the caller computes no part of the verdict.
  * Status codes: (stage << 24) | (layer << 16) | (query << 4) | sub
+ *   0/1 the proof does not have the shape of the expected config (host side, before any kernel) |
  *   1 channel draw exhausted | 2 OODS (sub 1 point inverse, 2 vanishing inverse, 3 CP mismatch
  *   deep/oods.simf:58) | 4 proof of work (pow.simf:33) | 5 decommit (sub 0 trace path, 1 trace
  *   root, 2 cp path, 3 cp root) | 6 DEEP denominator abort (sub = batch) | 7 FRI layer (sub 0
@@ -143,7 +152,7 @@ int ss_stwo_pack_dev(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const uint32
 
 /* Device-resident entry points: every pointer is device memory on ctx's GPU, `stream` is a
  * hipStream_t (NULL = default stream).  Asynchronous; status_dev is valid once the stream
- * has drained.  shape_status_dev may be NULL.  accept_count_dev (may be NULL) receives the
+ * has drained.  accept_count_dev (may be NULL) receives the
  * number of accepted proofs (one uint32_t) -- the value a multi-GPU caller all-reduces.
  * No allocation and no synchronisation happen inside, so the call is hipGraph-capturable.  */
 int ss_s101_verify_batch_dev(ss_ctx *ctx, const ss_s101_shape *shape, size_t n,
@@ -151,9 +160,8 @@ int ss_s101_verify_batch_dev(ss_ctx *ctx, const ss_s101_shape *shape, size_t n,
                              size_t workspace_bytes, uint32_t *status_dev,
                              uint32_t *accept_count_dev, void *stream);
 int ss_stwo_verify_batch_dev(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n,
-                             const uint32_t *batch_dev, const uint32_t *shape_status_dev,
-                             void *workspace_dev, size_t workspace_bytes, uint32_t *status_dev,
-                             uint32_t *accept_count_dev, void *stream);
+                             const uint32_t *batch_dev, void *workspace_dev, size_t workspace_bytes,
+                             uint32_t *status_dev, uint32_t *accept_count_dev, void *stream);
 
 /* The same work in two separately enqueueable halves, for callers that pipeline batches:
  *   SS_PHASE_HEAD  reset status, transcript kernel (Fiat-Shamir chain, latency bound) and
@@ -170,17 +178,37 @@ int ss_s101_verify_phase_dev(ss_ctx *ctx, const ss_s101_shape *shape, size_t n,
                              size_t workspace_bytes, uint32_t *status_dev,
                              uint32_t *accept_count_dev, int phases, void *stream);
 int ss_stwo_verify_phase_dev(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n,
-                             const uint32_t *batch_dev, const uint32_t *shape_status_dev,
-                             void *workspace_dev, size_t workspace_bytes, uint32_t *status_dev,
-                             uint32_t *accept_count_dev, int phases, void *stream);
+                             const uint32_t *batch_dev, void *workspace_dev, size_t workspace_bytes,
+                             uint32_t *status_dev, uint32_t *accept_count_dev, int phases, void *stream);
 
-/* Host-buffer convenience: pack + H2D + verify + D2H, synchronous.  Allocates scratch
- * device memory for the call.  PCIe-inclusive; not what bench.py times.                 */
+/* Host-buffer convenience: pack + H2D + verify + D2H, synchronous.  Scratch (pinned staging and
+ * device buffers) belongs to the context and only grows.  PCIe-inclusive; not what bench.py times. */
 int ss_s101_verify_records(ss_ctx *ctx, const ss_s101_shape *shape, size_t n,
                            const uint32_t *const *records, uint32_t *status_host);
 int ss_stwo_verify_records(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n,
-                           const uint32_t *const *records, const uint32_t *shape_status_host,
-                           uint32_t *status_host);
+                           const uint32_t *const *records, uint32_t *status_host);
+
+/* Per-stage intermediates of one proof after a verify call (the reference's counterpart is the
+ * debug tracker of `simfony run`, simfony-cli/src/tracker.rs:48-80, which prints the values a
+ * program passes to dbg!).  ss_stwo_ws_layout_of gives the word offsets inside the workspace for
+ * callers that read it themselves; ss_stwo_read_intermediates copies the usual ones to the host
+ * (synchronises `stream` first; any out pointer may be NULL):
+ *   queries[n_queries]         fri_generate_queries (fri/queries.simf:29-43)
+ *   oods_point[8]              x.a..x.d, y.a..y.d (channel_draw_qm31_point, channel.simf:143-151)
+ *   deep_alpha[4]              the DEEP random coefficient (deep/oods.simf:62)
+ *   fold_alphas[4*(1+n_layers)]  fri_commit (fri/commit.simf:70-85)
+ *   fri_answers[4*n_queries]   fri_answer of every query (fri/answers.simf:97-130)                */
+typedef struct ss_stwo_ws_layout {
+    uint64_t np, nip;                 /* proofs / instances padded to 64                        */
+    uint64_t ctx, alpha, leaf;        /* section word offsets: ctx[w][np], alpha[proof][n_pow][4],
+                                         leaf[layer][8][nip] (even, odd member of the leaf pair) */
+    uint64_t total_words;
+    uint32_t c_queries, c_p, c_p2, c_fold, c_m1, n_pow;   /* ctx word indices */
+} ss_stwo_ws_layout;
+int ss_stwo_ws_layout_of(const ss_stwo_cfg *cfg, size_t n, ss_stwo_ws_layout *out);
+int ss_stwo_read_intermediates(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const void *workspace_dev,
+                               size_t proof, void *stream, uint32_t *queries, uint32_t *oods_point,
+                               uint32_t *deep_alpha, uint32_t *fold_alphas, uint32_t *fri_answers);
 
 /* Kernel timing.  With timing enabled every *_verify_batch_dev call records a HIP event pair
  * around each kernel ON THE CALLER'S STREAM (no synchronisation; not graph-capturable, so off

@@ -276,6 +276,16 @@ class StwoHolder:
     def __init__(self, p):
         cfg = p.cfg
         Q, K = cfg.n_queries, cfg.n_layers
+        # the C side indexes every array by the config: check before handing pointers over
+        shapes_ok = (np.shape(p.roots) == (3, 32) and np.shape(p.oods_trace) == (cfg.n_cols, 4)
+                     and np.shape(p.oods_cp) == (16, 4) and np.shape(p.trace_vals) == (Q, cfg.n_cols)
+                     and np.shape(p.cp_vals) == (Q, 16) and np.shape(p.fri_roots) == (K + 1, 32)
+                     and np.shape(p.fri_witness) == (K + 1, Q, 4) and len(p.trace_paths) == Q
+                     and len(p.cp_paths) == Q and len(p.fri_paths) == K + 1
+                     and all(len(l) == Q for l in p.fri_paths))
+        paths = list(p.trace_paths) + list(p.cp_paths) + [x for l in p.fri_paths for x in l]
+        if not shapes_ok or any(len(x) > 31 or (len(x) and np.shape(x)[1:] != (32,)) for x in paths):
+            raise ValueError("proof arrays do not have the shape of its StwoConfig %r" % (cfg,))
         self.cfg = StwoCfg(cfg.n_cols, cfg.trace_log, cfg.lde_log, Q, K, cfg.pow_target,
                            1 if getattr(cfg, "hash", "sha256") == "blake2s" else 0)
         self.keep: List[np.ndarray] = []
@@ -322,6 +332,9 @@ class StwoBatch:
     """A prepared array of so_stwo_proof for the timed CPU baseline."""
 
     def __init__(self, proofs: Sequence):
+        if not proofs or any(p.cfg != proofs[0].cfg for p in proofs):
+            raise ValueError("StwoBatch needs a non-empty list of proofs of ONE StwoConfig "
+                             "(stwo_verify_batch groups mixed lists)")
         self.holders = [StwoHolder(p) for p in proofs]
         self.arr = (StwoProofC * len(proofs))()
         for i, h in enumerate(self.holders):
@@ -337,8 +350,21 @@ class StwoBatch:
         return st
 
 
-def stwo_verify_batch(proofs: Sequence, mode: int = MODE_FIXTURE, threads: int = 0) -> np.ndarray:
-    return StwoBatch(proofs).verify(mode, threads)
+def stwo_verify_batch(proofs: Sequence, mode: int = MODE_FIXTURE, threads: int = 0, cfg=None) -> np.ndarray:
+    """Status word per proof, each verified under its OWN config (grouped, input order kept).  With
+    `cfg` (a StwoConfig or a list of them) proofs of any other config get status 1, the checker's
+    counterpart of Verifier.verify_stwo's STATUS_CONFIG_MISMATCH."""
+    allowed = None if cfg is None else ([cfg] if not isinstance(cfg, (list, tuple)) else list(cfg))
+    out = np.zeros(len(proofs), dtype=np.uint32)
+    groups: dict = {}
+    for i, p in enumerate(proofs):
+        if allowed is not None and p.cfg not in allowed:
+            out[i] = 1
+        else:
+            groups.setdefault(p.cfg, []).append(i)
+    for idx in groups.values():
+        out[idx] = StwoBatch([proofs[i] for i in idx]).verify(mode, threads)
+    return out
 
 
 def num_procs() -> int:

@@ -26,7 +26,7 @@ class StwoCfg(C.Structure):
     """ss_stwo_cfg"""
     _fields_ = [("n_cols", C.c_uint32), ("trace_log", C.c_uint32), ("lde_log", C.c_uint32),
                 ("n_queries", C.c_uint32), ("n_layers", C.c_uint32), ("mode", C.c_uint32),
-                ("pow_target", C.c_uint64), ("hash", C.c_uint32)]
+                ("pow_target", C.c_uint64), ("hash", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class S101Shape(C.Structure):
@@ -34,8 +34,17 @@ class S101Shape(C.Structure):
     _fields_ = [("max_layers", C.c_uint32), ("max_path", C.c_uint32)]
 
 
+class StwoWsLayout(C.Structure):
+    """ss_stwo_ws_layout"""
+    _fields_ = [("np", C.c_uint64), ("nip", C.c_uint64), ("ctx", C.c_uint64), ("alpha", C.c_uint64),
+                ("leaf", C.c_uint64), ("total_words", C.c_uint64), ("c_queries", C.c_uint32),
+                ("c_p", C.c_uint32), ("c_p2", C.c_uint32), ("c_fold", C.c_uint32), ("c_m1", C.c_uint32),
+                ("n_pow", C.c_uint32)]
+
+
 EXPORTS = [
-    "ss_version", "ss_last_error", "ss_device_count",
+    "ss_version", "ss_last_error", "ss_device_count", "ss_abi_sizeof_cfg", "ss_abi_sizeof_shape",
+    "ss_stwo_ws_layout_of", "ss_stwo_read_intermediates",
     "ss_s101_record_words", "ss_s101_batch_words", "ss_s101_workspace_bytes", "ss_s101_pack",
     "ss_stwo_record_words", "ss_stwo_batch_words", "ss_stwo_workspace_bytes", "ss_stwo_pack",
     "ss_ctx_create", "ss_ctx_destroy", "ss_s101_verify_batch_dev", "ss_stwo_verify_batch_dev",
@@ -67,6 +76,13 @@ def lib() -> C.CDLL:
     sig("ss_version", C.c_int)
     sig("ss_last_error", C.c_char_p)
     sig("ss_device_count", C.c_int)
+    sig("ss_abi_sizeof_cfg", sz)
+    sig("ss_abi_sizeof_shape", sz)
+    if L.ss_abi_sizeof_cfg() != C.sizeof(StwoCfg) or L.ss_abi_sizeof_shape() != C.sizeof(S101Shape):
+        raise ImportError("%s: struct sizes differ from this binding (ss_stwo_cfg %d vs %d)"
+                          % (LIB_PATH, L.ss_abi_sizeof_cfg(), C.sizeof(StwoCfg)))
+    if (L.ss_version() >> 16) != 2:
+        raise ImportError("%s is ABI version 0x%08x; this binding needs 2.x: rebuild" % (LIB_PATH, L.ss_version()))
     sp = C.POINTER(S101Shape)
     sig("ss_s101_record_words", sz, sp)
     sig("ss_s101_batch_words", sz, sp, sz)
@@ -80,14 +96,16 @@ def lib() -> C.CDLL:
     sig("ss_ctx_create", C.c_int, C.c_int, pp)
     sig("ss_ctx_destroy", None, vp)
     sig("ss_s101_verify_batch_dev", C.c_int, vp, sp, sz, vp, vp, sz, vp, vp, vp)
-    sig("ss_stwo_verify_batch_dev", C.c_int, vp, cp, sz, vp, vp, vp, sz, vp, vp, vp)
+    sig("ss_stwo_verify_batch_dev", C.c_int, vp, cp, sz, vp, vp, sz, vp, vp, vp)
     sig("ss_s101_verify_phase_dev", C.c_int, vp, sp, sz, vp, vp, sz, vp, vp, C.c_int, vp)
-    sig("ss_stwo_verify_phase_dev", C.c_int, vp, cp, sz, vp, vp, vp, sz, vp, vp, C.c_int, vp)
+    sig("ss_stwo_verify_phase_dev", C.c_int, vp, cp, sz, vp, vp, sz, vp, vp, C.c_int, vp)
     sig("ss_stwo_pack_dev", C.c_int, vp, cp, sz, vp, vp, vp)
     sig("ss_s101_verify_records", C.c_int, vp, sp, sz, pp, vp)
-    sig("ss_stwo_verify_records", C.c_int, vp, cp, sz, pp, vp, vp)
+    sig("ss_stwo_verify_records", C.c_int, vp, cp, sz, pp, vp)
     sig("ss_ctx_set_timing", C.c_int, vp, C.c_int)
-    sig("ss_ctx_collect_timing", C.c_int, vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float))
+    sig("ss_ctx_collect_timing", C.c_int, vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float), u32p)
+    sig("ss_stwo_ws_layout_of", C.c_int, cp, sz, C.POINTER(StwoWsLayout))
+    sig("ss_stwo_read_intermediates", C.c_int, vp, cp, sz, vp, sz, vp, vp, vp, vp, vp, vp)
     sig("ss_selftest", C.c_int, vp, C.c_int, sz, vp, vp)
     _lib = L
     return L

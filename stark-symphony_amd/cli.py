@@ -2,12 +2,19 @@
 
     python -m stark_symphony_amd.cli verify --family stark101 --witness target/proof.wit
     python -m stark_symphony_amd.cli verify --family stwo --proof tests/data/proof.json
-    python -m stark_symphony_amd.cli verify --family stwo --witness a.wit b.wit --trace-log 9
+    python -m stark_symphony_amd.cli verify --family stwo --witness a.wit b.wit            # config.simf, production
+    python -m stark_symphony_amd.cli verify --family stwo --config testing --witness t.wit  # config.simf -DTESTING
+    python -m stark_symphony_amd.cli verify --family stwo --trace-log 20 --lde-log 24 --n-layers 19 --proof p.json
     python -m stark_symphony_amd.cli convert --family stwo --to wit tests/data/proof.json     # generate_wit.py
     python -m stark_symphony_amd.cli convert --family stwo --to simf tests/data/proof.json    # generate_simf.py
 
 Exit 0 when every input is ACCEPTed, 1 otherwise (REJECT or malformed witness, like the
 reference, whose type errors also end in exit 1: main.rs:77-81,187-190).  Runs on GPU 0.
+
+The stwo parameters (columns, sizes, queries, FRI layers, PoW bits, hash) are the VERIFIER's: the
+reference compiles them in (stwo-verifier/src/config.simf:10-51), this command takes them from
+`--config production|testing` plus explicit overrides -- never from the proof.  A proof that
+declares or has any other shape is rejected like a witness that fails typing.
 """
 from __future__ import annotations
 
@@ -53,9 +60,16 @@ def main(argv=None) -> int:
     v.add_argument("--family", choices=["stark101", "stwo"], required=True)
     v.add_argument("--witness", nargs="*", default=[], help=".wit files (formats B / D)")
     v.add_argument("--proof", nargs="*", default=[], help="proof.json files (formats A / C)")
-    v.add_argument("--trace-log", type=int, default=None,
-                   help="TRACE_LOG_SIZE for stwo .wit files (config.simf:17,35)")
-    v.add_argument("--pow-bits", type=int, default=5)
+    v.add_argument("--config", choices=["production", "testing"], default="production",
+                   help="stwo: the config.simf profile the verifier enforces (default: production, "
+                        "i.e. the reference built without -DTESTING)")
+    v.add_argument("--n-cols", type=int, default=None, help="override NUM_COLUMNS")
+    v.add_argument("--trace-log", type=int, default=None, help="override TRACE_LOG_SIZE")
+    v.add_argument("--lde-log", type=int, default=None, help="override LDE_LOG_SIZE")
+    v.add_argument("--n-queries", type=int, default=None, help="override NUM_FRI_QUERIES")
+    v.add_argument("--n-layers", type=int, default=None, help="override NUM_FRI_LAYERS")
+    v.add_argument("--pow-bits", type=int, default=None, help="override the PoW bits of POW_TARGET_64")
+    v.add_argument("--hash", choices=["sha256", "blake2s"], default=None, help="override the hash family")
     v.add_argument("--mode", choices=["fixture", "literal"], default="fixture")
     v.add_argument("--device", type=int, default=0)
     c = sub.add_parser("convert", help="proof.json -> .wit / .simf snippet (the reference's "
@@ -69,21 +83,24 @@ def main(argv=None) -> int:
     if args.cmd == "convert":
         return convert(args)
 
+    import dataclasses
+    expected = formats.PRODUCTION_CONFIG if args.config == "production" else formats.TESTING_CONFIG
+    over = {k: getattr(args, k) for k in ("n_cols", "trace_log", "lde_log", "n_queries", "n_layers",
+                                          "pow_bits", "hash") if getattr(args, k) is not None}
+    expected = dataclasses.replace(expected, **over)
     proofs, names = [], []
     try:
         for path in args.witness:
             text = open(path).read()
             if args.family == "stark101":
                 proofs.append(formats.stark101_from_wit(text))
-            else:
-                if args.trace_log is None:
-                    raise formats.MalformedProof("--trace-log is required for stwo .wit files")
-                proofs.append(formats.stwo_from_wit(text, args.trace_log, args.pow_bits))
+            else:  # a .wit declares nothing: what cannot be read off its shape is the verifier's
+                proofs.append(formats.stwo_from_wit(text, expected.trace_log, expected.pow_bits, expected.hash))
             names.append(path)
         for path in args.proof:
             obj = json.load(open(path))
             proofs.append(formats.stark101_from_json(obj) if args.family == "stark101"
-                          else formats.stwo_from_json(obj, args.trace_log))
+                          else formats.stwo_from_json(obj, expect=expected))
             names.append(path)
     except (formats.MalformedProof, OSError, ValueError) as e:
         print("Error: %s" % e, file=sys.stderr)
@@ -96,15 +113,16 @@ def main(argv=None) -> int:
         status = ver.verify_stark101(proofs)
     else:
         mode = verifier.MODE_FIXTURE if args.mode == "fixture" else verifier.MODE_LITERAL
-        status = ver.verify_stwo(proofs, mode)
+        status = ver.verify_stwo(proofs, mode, cfg=expected)
     bad = 0
     for name, st in zip(names, status.tolist()):
         if st == 0:
             print("%s: ACCEPT" % name)
         else:
             bad += 1
-            print("Error: Failed to run program: %s: REJECT (first failing assert 0x%08x)" % (name, st),
-                  file=sys.stderr)
+            why = ("witness does not have the shape of the expected config" if st == verifier.STATUS_CONFIG_MISMATCH
+                   else "first failing assert 0x%08x" % st)
+            print("Error: Failed to run program: %s: REJECT (%s)" % (name, why), file=sys.stderr)
     return 1 if bad else 0
 
 

@@ -64,8 +64,8 @@ struct HostPath {
     void *pinned[2] = {nullptr, nullptr};
     size_t pinned_bytes = 0;
     hipEvent_t pinned_free[2] = {nullptr, nullptr};
-    void *dev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // records, batch, ws, status, shape
-    size_t dev_bytes[5] = {0, 0, 0, 0, 0};
+    void *dev[4] = {nullptr, nullptr, nullptr, nullptr};  // records, batch, ws, status
+    size_t dev_bytes[4] = {0, 0, 0, 0};
     hipStream_t stream = nullptr;
 };
 
@@ -120,11 +120,13 @@ extern "C" int ss_ctx_set_timing(ss_ctx *ctx, int enabled)
     return SS_OK;
 }
 
+// nullptr when the runtime cannot create another event: the span is then skipped, never recorded
+// with a null handle.
 static hipEvent_t take_event(ss_ctx *c)
 {
     if (!c->pool.empty()) { hipEvent_t e = c->pool.back(); c->pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
 }
 
@@ -162,24 +164,29 @@ struct Timer {
     {
         if (!c->timing || c->spans.size() >= kMaxSpans) return;
         cur = take_event(c);
-        (void)hipEventRecord(cur, s);
+        if (cur && hipEventRecord(cur, s) != hipSuccess) { c->pool.push_back(cur); cur = nullptr; }
     }
     void end(const char *name)
     {
         if (!cur) return;
         hipEvent_t stop = take_event(c);
-        (void)hipEventRecord(stop, s);
-        c->spans.push_back({name, cur, stop});
+        if (!stop || hipEventRecord(stop, s) != hipSuccess) {
+            if (stop) c->pool.push_back(stop);
+            c->pool.push_back(cur);
+        } else {
+            c->spans.push_back({name, cur, stop});
+        }
         cur = nullptr;
     }
 };
 
 // ------------------------------------------------------------------------ host threads
+// `max_threads` bounds the fan-out: a thread is only worth starting for a few MiB of copying.
 template <class F>
-static void parallel_for(size_t n, F f)
+static void parallel_for(size_t n, F f, size_t max_threads = 16)
 {
     unsigned hw = std::thread::hardware_concurrency();
-    size_t nt = std::max<size_t>(1, std::min<size_t>(hw ? hw : 1, std::min<size_t>(n, 32)));
+    size_t nt = std::max<size_t>(1, std::min<size_t>(hw ? hw : 1, std::min<size_t>(n, max_threads)));
     if (nt == 1) { for (size_t i = 0; i < n; i++) f(i); return; }
     std::vector<std::thread> th;
     for (size_t t = 0; t < nt; t++)
@@ -210,6 +217,52 @@ extern "C" size_t ss_stwo_batch_words(const ss_stwo_cfg *c, size_t n)
 extern "C" size_t ss_stwo_workspace_bytes(const ss_stwo_cfg *c, size_t n)
 {
     return cfg_ok(c) && n ? (size_t)lay_of(c, n).ws_total_words * 4 : 0;
+}
+
+static_assert(sizeof(ss_stwo_cfg) == 40, "ss_stwo_cfg is 9 words + tail padding to the u64's alignment");
+static_assert(sizeof(ss_s101_shape) == 8, "ss_s101_shape is 2 words");
+extern "C" size_t ss_abi_sizeof_cfg(void) { return sizeof(ss_stwo_cfg); }
+extern "C" size_t ss_abi_sizeof_shape(void) { return sizeof(ss_s101_shape); }
+
+extern "C" int ss_stwo_ws_layout_of(const ss_stwo_cfg *c, size_t n, ss_stwo_ws_layout *out)
+{
+    if (!cfg_ok(c) || !n || !out) return set_err(SS_ERR_ARG, "bad argument");
+    const StwoLayout y = lay_of(c, n);
+    out->np = y.np; out->nip = y.nip;
+    out->ctx = y.ws_ctx; out->alpha = y.ws_alpha; out->leaf = y.ws_leaf; out->total_words = y.ws_total_words;
+    out->c_queries = y.c_queries; out->c_p = y.c_p; out->c_p2 = y.c_p2; out->c_fold = y.c_fold;
+    out->c_m1 = y.c_m1; out->n_pow = y.n_pow;
+    return SS_OK;
+}
+
+extern "C" int ss_stwo_read_intermediates(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const void *workspace,
+                                          size_t proof, void *stream_, uint32_t *queries, uint32_t *oods_point,
+                                          uint32_t *deep_alpha, uint32_t *fold_alphas, uint32_t *fri_answers)
+{
+    if (!ctx || !workspace) return set_err(SS_ERR_ARG, "null argument");
+    if (!cfg_ok(c) || !n || proof >= n) return set_err(SS_ERR_ARG, "bad config or proof index");
+    const StwoLayout y = lay_of(c, n);
+    const uint32_t *ws = (const uint32_t *)workspace;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream_));
+    // ctx[w][proof]: `rows` consecutive w of one proof are a column of a (rows x np) matrix
+    auto column = [&](uint32_t *dst, const uint32_t *src, size_t pitch_words, size_t rows) {
+        return hipMemcpy2D(dst, 4, src, pitch_words * 4, 4, rows, hipMemcpyDeviceToHost);
+    };
+    const uint32_t *cx = ws + y.ws_ctx + proof;
+    std::vector<uint32_t> qs(y.Q);
+    HIP_TRY(column(qs.data(), cx + (size_t)y.c_queries * y.np, y.np, y.Q));
+    if (queries) memcpy(queries, qs.data(), y.Q * 4);
+    if (oods_point) HIP_TRY(column(oods_point, cx + (size_t)y.c_p * y.np, y.np, 8));
+    if (fold_alphas) HIP_TRY(column(fold_alphas, cx + (size_t)y.c_fold * y.np, y.np, 4 * (y.K + 1)));
+    if (deep_alpha)
+        HIP_TRY(hipMemcpy(deep_alpha, ws + y.ws_alpha + proof * y.n_pow * 4, 16, hipMemcpyDeviceToHost));
+    if (fri_answers)
+        for (uint32_t q = 0; q < y.Q; q++) {  // the query's own member of the layer-0 leaf pair
+            const size_t inst = proof * y.Q + q, half = (qs[q] & 1) ? 4 : 0;
+            HIP_TRY(column(fri_answers + 4 * q, ws + y.ws_leaf + half * y.nip + inst, y.nip, 4));
+        }
+    return SS_OK;
 }
 
 extern "C" int ss_stwo_pack(const ss_stwo_cfg *c, size_t n, const uint32_t *const *records,
@@ -244,14 +297,16 @@ extern "C" int ss_stwo_pack(const ss_stwo_cfg *c, size_t n, const uint32_t *cons
                     for (uint32_t w = 0; w < 8; w++) out[tile_word(y.off_fri_path[l], len, inst, lv, w)] = *r++;
             }
         }
+        for (uint32_t kind = 0; kind < K + 3; kind++)  // trailer: path lengths
+            for (uint32_t q = 0; q < Q; q++) out[y.off_plen + (uint64_t)kind * y.nip + (uint64_t)p * Q + q] = *r++;
     });
     return SS_OK;
 }
 
 extern "C" int ss_stwo_verify_phase_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n,
-                                        const uint32_t *batch, const uint32_t *shape_status,
-                                        void *workspace, size_t workspace_bytes, uint32_t *status,
-                                        uint32_t *accept_count, int phases, void *stream_)
+                                        const uint32_t *batch, void *workspace, size_t workspace_bytes,
+                                        uint32_t *status, uint32_t *accept_count, int phases,
+                                        void *stream_)
 {
     if (!ctx) return set_err(SS_ERR_ARG, "ctx is null");
     if (!cfg_ok(c)) return set_err(SS_ERR_ARG, "unsupported stwo config");
@@ -284,7 +339,7 @@ extern "C" int ss_stwo_verify_phase_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_
         t.end("stwo_merkle");
         t.begin();
         hipLaunchKernelGGL(stwo_finalize_kernel, dim3((y.n + 255) / 256), dim3(256), 0, s, y.n, status,
-                           shape_status, accept_count);
+                           accept_count);
         t.end("stwo_finalize");
     }
     HIP_TRY(hipGetLastError());
@@ -292,12 +347,11 @@ extern "C" int ss_stwo_verify_phase_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_
 }
 
 extern "C" int ss_stwo_verify_batch_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n,
-                                        const uint32_t *batch, const uint32_t *shape_status,
-                                        void *workspace, size_t workspace_bytes, uint32_t *status,
-                                        uint32_t *accept_count, void *stream_)
+                                        const uint32_t *batch, void *workspace, size_t workspace_bytes,
+                                        uint32_t *status, uint32_t *accept_count, void *stream_)
 {
-    return ss_stwo_verify_phase_dev(ctx, c, n, batch, shape_status, workspace, workspace_bytes, status,
-                                    accept_count, SS_PHASE_ALL, stream_);
+    return ss_stwo_verify_phase_dev(ctx, c, n, batch, workspace, workspace_bytes, status, accept_count,
+                                    SS_PHASE_ALL, stream_);
 }
 
 // ============================================================================ stark101
@@ -378,7 +432,7 @@ extern "C" int ss_s101_verify_phase_dev(ss_ctx *ctx, const ss_s101_shape *sh, si
         t.end("s101_merkle");
         t.begin();
         hipLaunchKernelGGL(stwo_finalize_kernel, dim3((y.n + 255) / 256), dim3(256), 0, s, y.n, status,
-                           (const uint32_t *)nullptr, accept_count);
+                           accept_count);
         t.end("s101_finalize");
     }
     HIP_TRY(hipGetLastError());
@@ -408,6 +462,7 @@ struct StwoRecordMap {
     uint64_t W;        // record words
     uint32_t qstride;  // words per query in the decommitment section
     uint32_t fbase;    // first word of the FRI section
+    uint32_t tbase;    // first word of the path-length trailer
     uint32_t foff[kMaxList + 1];  // FRI layer l starts at fbase + foff[l]
 };
 
@@ -432,12 +487,15 @@ __global__ void stwo_pack_words_kernel(StwoLayout y, StwoRecordMap m, const uint
         uint32_t row, off0;
         if (d < y.off_cp_vals) { e = d - y.off_trace_vals; row = (uint32_t)(e / y.nip); off0 = row; }
         else if (d < y.off_fri_wit) { e = d - y.off_cp_vals; row = (uint32_t)(e / y.nip); off0 = y.N + row; }
-        else { e = d - y.off_fri_wit; row = (uint32_t)(e / y.nip); off0 = 0; }
+        else if (d < y.off_plen) { e = d - y.off_fri_wit; row = (uint32_t)(e / y.nip); off0 = 0; }
+        else { e = d - y.off_plen; row = (uint32_t)(e / y.nip); off0 = 0; }
         const uint32_t inst = (uint32_t)(e - (uint64_t)row * y.nip);
         if (inst < y.ni) {
             const uint32_t p = inst / y.Q, q = inst - p * y.Q;
             if (d < y.off_fri_wit) {
                 v = rec_word(rec, m, p, y.head_words + q * m.qstride + off0);
+            } else if (d >= y.off_plen) {
+                v = rec_word(rec, m, p, m.tbase + row * y.Q + q);
             } else {
                 const uint32_t l = row >> 2, w = row & 3, len = y.L - 1 - l;
                 v = rec_word(rec, m, p, m.fbase + m.foff[l] + q * (4 + 8 * len) + w);
@@ -497,6 +555,7 @@ static StwoRecordMap record_map(const StwoLayout &y)
         m.foff[l] = o;
         o += y.Q * (4 + 8 * (y.L - 1 - l));
     }
+    m.tbase = m.fbase + o;
     return m;
 }
 
@@ -551,8 +610,7 @@ static int hp_pinned(ss_ctx *ctx, size_t bytes)
 // uploaded asynchronously (two buffers in flight), re-tiled ON THE GPU (ss_stwo_pack_dev) and
 // verified.  PCIe-bound.
 extern "C" int ss_stwo_verify_records(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n,
-                                      const uint32_t *const *records, const uint32_t *shape_status_host,
-                                      uint32_t *status_host)
+                                      const uint32_t *const *records, uint32_t *status_host)
 {
     if (!ctx || !status_host || !records) return set_err(SS_ERR_ARG, "null argument");
     if (!cfg_ok(c)) return set_err(SS_ERR_ARG, "unsupported stwo config");
@@ -566,7 +624,6 @@ extern "C" int ss_stwo_verify_records(ss_ctx *ctx, const ss_stwo_cfg *c, size_t 
     if ((rc = hp_reserve(ctx, 1, words * 4))) return rc;
     if ((rc = hp_reserve(ctx, 2, wsb))) return rc;
     if ((rc = hp_reserve(ctx, 3, n * 4))) return rc;
-    if (shape_status_host && (rc = hp_reserve(ctx, 4, n * 4))) return rc;
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, (64u << 20) / (W * 4)));
     if ((rc = hp_pinned(ctx, chunk * W * 4))) return rc;
     HostPath &hp = ctx->hp;
@@ -577,15 +634,13 @@ extern "C" int ss_stwo_verify_records(ss_ctx *ctx, const ss_stwo_cfg *c, size_t 
         const size_t cnt = std::min(chunk, n - lo);
         HIP_TRY(hipEventSynchronize(hp.pinned_free[buf]));  // previous upload from this buffer done
         uint32_t *stage = (uint32_t *)hp.pinned[buf];
-        parallel_for(cnt, [&](size_t i) { memcpy(stage + i * W, records[lo + i], W * 4); });
+        parallel_for(cnt, [&](size_t i) { memcpy(stage + i * W, records[lo + i], W * 4); },
+                     std::max<size_t>(1, cnt * W * 4 / (4u << 20)));
         HIP_TRY(hipMemcpyAsync(rec_dev + lo * W, stage, cnt * W * 4, hipMemcpyHostToDevice, s));
         HIP_TRY(hipEventRecord(hp.pinned_free[buf], s));
     }
-    if (shape_status_host)
-        HIP_TRY(hipMemcpyAsync(hp.dev[4], shape_status_host, n * 4, hipMemcpyHostToDevice, s));
     if ((rc = ss_stwo_pack_dev(ctx, c, n, rec_dev, (uint32_t *)hp.dev[1], s))) return rc;
-    rc = ss_stwo_verify_batch_dev(ctx, c, n, (const uint32_t *)hp.dev[1],
-                                  shape_status_host ? (const uint32_t *)hp.dev[4] : nullptr, hp.dev[2], wsb,
+    rc = ss_stwo_verify_batch_dev(ctx, c, n, (const uint32_t *)hp.dev[1], hp.dev[2], wsb,
                                   (uint32_t *)hp.dev[3], nullptr, s);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(status_host, hp.dev[3], n * 4, hipMemcpyDeviceToHost, s));
@@ -593,27 +648,33 @@ extern "C" int ss_stwo_verify_records(ss_ctx *ctx, const ss_stwo_cfg *c, size_t 
     return SS_OK;
 }
 
+// Host records -> verdicts (stark101): host pack into pinned staging, one upload, verify, download.
+// Scratch (pinned + device) is the context's grow-only HostPath, as for the stwo twin.
 extern "C" int ss_s101_verify_records(ss_ctx *ctx, const ss_s101_shape *sh, size_t n,
                                       const uint32_t *const *records, uint32_t *status_host)
 {
-    if (!ctx || !status_host) return set_err(SS_ERR_ARG, "null argument");
+    if (!ctx || !status_host || !records) return set_err(SS_ERR_ARG, "null argument");
     if (!shape_ok(sh)) return set_err(SS_ERR_ARG, "unsupported stark101 shape");
     if (!n) return set_err(SS_ERR_ARG, "empty batch");
+    if (n > 0x7fffffffu) return set_err(SS_ERR_ARG, "batch too large");
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t words = ss_s101_batch_words(sh, n), wsb = ss_s101_workspace_bytes(sh, n);
-    std::vector<uint32_t> host(words);
-    int rc = ss_s101_pack(sh, n, records, host.data());
+    int rc;
+    if ((rc = hp_reserve(ctx, 1, words * 4))) return rc;
+    if ((rc = hp_reserve(ctx, 2, wsb))) return rc;
+    if ((rc = hp_reserve(ctx, 3, n * 4))) return rc;
+    if ((rc = hp_pinned(ctx, words * 4))) return rc;
+    HostPath &hp = ctx->hp;
+    hipStream_t s = hp.stream;
+    HIP_TRY(hipEventSynchronize(hp.pinned_free[0]));
+    if ((rc = ss_s101_pack(sh, n, records, (uint32_t *)hp.pinned[0]))) return rc;
+    HIP_TRY(hipMemcpyAsync(hp.dev[1], hp.pinned[0], words * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(hp.pinned_free[0], s));
+    rc = ss_s101_verify_batch_dev(ctx, sh, n, (const uint32_t *)hp.dev[1], hp.dev[2], wsb, (uint32_t *)hp.dev[3],
+                                  nullptr, s);
     if (rc) return rc;
-    DevBuf b, w, st;
-    HIP_TRY(hipMalloc(&b.p, words * 4));
-    HIP_TRY(hipMalloc(&w.p, wsb));
-    HIP_TRY(hipMalloc(&st.p, n * 4));
-    HIP_TRY(hipMemcpy(b.p, host.data(), words * 4, hipMemcpyHostToDevice));
-    rc = ss_s101_verify_batch_dev(ctx, sh, n, (const uint32_t *)b.p, w.p, wsb, (uint32_t *)st.p, nullptr,
-                                  nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(status_host, st.p, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(status_host, hp.dev[3], n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     return SS_OK;
 }
 

@@ -4,6 +4,7 @@
 // Everything is an array of little-endian u32 words in ONE buffer.
 //   per-proof "head" words      head[w][proof]              (SoA, proofs padded to 64)
 //   per-instance values         vals[column][instance]      (instance = proof * Q + query)
+//   Merkle path lengths         plen[kind][instance]        (kind 0 trace, 1 cp, 2 + l FRI layer l)
 //   Merkle paths, per chain type: 64-chain tiles
 //          tile[g][level][half][lane][4 words],   g = instance / 64, lane = instance % 64
 //     so a wavefront fetches one sibling level of its 64 chains as two contiguous 1 KiB reads.
@@ -43,7 +44,7 @@ struct StwoLayout {
     // head word indices
     uint32_t h_roots, h_oods_trace, h_oods_cp, h_fri_roots, h_last, h_nonce, head_words;
     // section word offsets inside the batch buffer
-    uint64_t off_head, off_trace_vals, off_cp_vals, off_fri_wit, off_trace_path, off_cp_path;
+    uint64_t off_head, off_trace_vals, off_cp_vals, off_fri_wit, off_plen, off_trace_path, off_cp_path;
     uint64_t off_fri_path[kMaxList + 1];
     uint64_t total_words;
     // workspace word offsets (u32 words)
@@ -79,6 +80,7 @@ SS_HD inline StwoLayout stwo_layout(uint32_t N, uint32_t TL, uint32_t L, uint32_
     y.off_trace_vals = o;  o += (uint64_t)N * y.nip;
     y.off_cp_vals = o;     o += (uint64_t)kCp * y.nip;
     y.off_fri_wit = o;     o += (uint64_t)(K + 1) * 4 * y.nip;
+    y.off_plen = o;        o += (uint64_t)(K + 3) * y.nip;  // path length per chain: plen[kind][inst]
     y.off_trace_path = o;  o += (uint64_t)L * 8 * y.nip;
     y.off_cp_path = o;     o += (uint64_t)L * 8 * y.nip;
     for (uint32_t l = 0; l <= K; l++) {
@@ -115,6 +117,7 @@ SS_HD inline uint64_t stwo_record_words(uint32_t N, uint32_t L, uint32_t Q, uint
     uint64_t w = 24 + 4 * (uint64_t)N + 64 + 8 * (uint64_t)(K + 1) + 4 + 2;
     w += (uint64_t)Q * (N + kCp + 16 * (uint64_t)L);
     for (uint32_t l = 0; l <= K; l++) w += (uint64_t)Q * (4 + 8 * (uint64_t)(L - 1 - l));
+    w += (uint64_t)(K + 3) * Q;  // trailer: path_len[kind][query], kind 0 trace, 1 cp, 2 + l FRI layer l
     return w;
 }
 

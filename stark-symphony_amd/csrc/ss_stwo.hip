@@ -535,7 +535,10 @@ __device__ __forceinline__ void stwo_merkle_body(const StwoLayout &lay, const ui
 #pragma unroll
     for (int j = 0; j < 8; j++) same &= node[j] == Hasher<HF>::native(head[(size_t)(root_w + j) * np + p]);
     if (!same) fail = code_base + 1;   // assert!(eq_256(computed_root, root))  merkle.simf:43
-    if (auth != 1) fail = code_base;   // assert!(eq_32(path, 1))              merkle.simf:42
+    // assert!(eq_32(path, 1)), merkle.simf:42, evaluated first by the reference.  The index starts
+    // in [2^len, 2^(len+1)) and loses one bit per sibling of the List<u256, 32>, so it ends at 1 iff
+    // the proof's path holds exactly `len` siblings -- whatever they contain.
+    if (auth != 1 || batch[lay.off_plen + (size_t)type * nip + inst] != len) fail = code_base;
     if (fail != 0xffffffffu) atomicMin(&status[p], fail);
 }
 
@@ -554,16 +557,11 @@ stwo_merkle_kernel_b2s(StwoLayout lay, const uint32_t *__restrict__ batch, const
 
 // ============================================================================ finalize
 __global__ void stwo_finalize_kernel(uint32_t n, uint32_t *__restrict__ status,
-                                     const uint32_t *__restrict__ shape_status,
                                      uint32_t *__restrict__ accept_count)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     uint32_t s = status[p];
-    if (shape_status) {
-        uint32_t h = shape_status[p];
-        if (h != 0 && h < s) s = h;
-    }
     s = s == 0xffffffffu ? 0u : s;
     status[p] = s;
     if (accept_count && s == 0) atomicAdd(accept_count, 1u);

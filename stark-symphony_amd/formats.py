@@ -387,15 +387,29 @@ def _split(lst: Sequence[Any], n: int) -> List[Sequence[Any]]:
     return [lst[i * k:(i + 1) * k] for i in range(n)]
 
 
-def stwo_from_json(data: Any, trace_log: int | None = None, hash: str | None = None) -> StwoProof:
+def stwo_from_json(data: Any, trace_log: int | None = None, hash: str | None = None,
+                   expect: "StwoConfig | None" = None) -> StwoProof:
     """Format C.  The JSON carries pow_bits / log_blowup / n_queries; the LDE size is
-    implied by the Merkle path length (the reference hard-codes it: config.simf:21,39)."""
+    implied by the Merkle path length (the reference hard-codes it: config.simf:21,39).
+
+    The returned proof's `cfg` is what the proof DECLARES (its `config` object and its array
+    shapes) -- untrusted input.  The verifier compares it with the config its caller expects
+    (Verifier.verify_stwo(..., cfg=...)) and never verifies against a self-declared one.  A
+    parameter the JSON does not declare is taken from `expect`; without `expect` it is an error
+    (in particular a missing `pow_bits` never means "no proof of work")."""
     if isinstance(data, (str, bytes)):
         data = json.loads(data)
     try:
         conf = data.get("config", {})
         fri_conf = conf.get("fri_config", {})
-        Q = int(fri_conf.get("n_queries", 1))
+
+        def declared(d: dict, key: str, fallback: Any) -> int:
+            if key in d:
+                return int(d[key])
+            if fallback is None:
+                raise MalformedProof("config has no %r and no expected config was given" % key)
+            return int(fallback)
+        Q = declared(fri_conf, "n_queries", expect and expect.n_queries)
         roots = np.stack([np.frombuffer(bytes(c), dtype=np.uint8) for c in data["commitments"]])
         if roots.shape != (3, 32):
             raise MalformedProof("expected three 32-byte commitments")
@@ -432,12 +446,14 @@ def stwo_from_json(data: Any, trace_log: int | None = None, hash: str | None = N
             raise MalformedProof("expected a degree-0 last layer")
         last = np.array(_qm31(coeffs[0]), dtype=np.uint32)
         lde_log = len(trace_paths[0]) if Q else 0
-        log_blowup = int(fri_conf.get("log_blowup_factor", 0))
-        tl = trace_log if trace_log is not None else lde_log - log_blowup
-        hname = hash or conf.get("hash", "sha256")
+        if trace_log is not None:
+            tl = trace_log
+        else:
+            tl = lde_log - declared(fri_conf, "log_blowup_factor", expect and expect.log_blowup)
+        hname = hash or conf.get("hash") or (expect.hash if expect else "sha256")  # the reference: SHA-256 only
         if hname not in ("sha256", "blake2s"):
             raise MalformedProof("unknown hash %r" % (hname,))
-        cfg = StwoConfig(N, tl, lde_log, Q, K, int(conf.get("pow_bits", 0)), hname)
+        cfg = StwoConfig(N, tl, lde_log, Q, K, declared(conf, "pow_bits", expect and expect.pow_bits), hname)
         nonce = int(data.get("proof_of_work", 0))
         if not (0 <= nonce < 1 << 64):
             raise MalformedProof("u64 out of range")

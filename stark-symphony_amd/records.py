@@ -51,7 +51,14 @@ def stwo_from_record(cfg: StwoConfig, rec: np.ndarray) -> StwoProof:
             fri_witness[l, q] = take(4)
             row.append(_path_bytes(take(8 * (L - 1 - l))))
         fri_paths.append(row)
-    if pos != rec.size:
+    if pos + (K + 3) * Q == rec.size:  # ABI 2.x: path_len trailer
+        lens = take((K + 3) * Q).reshape(K + 3, Q)
+        for q in range(Q):
+            trace_paths[q] = trace_paths[q][:lens[0, q]]
+            cp_paths[q] = cp_paths[q][:lens[1, q]]
+            for l in range(K + 1):
+                fri_paths[l][q] = fri_paths[l][q][:lens[2 + l, q]]
+    if pos != rec.size:  # (fixtures written before the trailer existed end here: full-length paths)
         raise ValueError("record has %d words, config needs %d" % (rec.size, pos))
     return StwoProof(cfg, roots, oods_trace, oods_cp, trace_vals, cp_vals, trace_paths, cp_paths,
                      fri_roots, last, fri_witness, fri_paths, (int(hi) << 32) | int(lo))
@@ -63,10 +70,11 @@ def save_stwo_npz(path: str, proofs: Sequence[StwoProof]) -> None:
     for p in proofs:
         if p.cfg != cfg:
             raise ValueError("mixed configs")
-        rec, shape = stwo_record(p)
-        if shape:
-            raise ValueError("non-uniform proof cannot be stored as a record")
-        recs.append(rec)
+        uniform = all(len(x) == cfg.lde_log for x in p.trace_paths + p.cp_paths) and all(
+            len(x) == cfg.fri_path_len(l) for l in range(cfg.n_layers + 1) for x in p.fri_paths[l])
+        if not uniform:  # an over-long path does not survive the fixed slots
+            raise ValueError("only proofs with full-length Merkle paths are stored as records")
+        recs.append(stwo_record(p))
     np.savez_compressed(path, cfg=np.array([cfg.n_cols, cfg.trace_log, cfg.lde_log, cfg.n_queries,
                                             cfg.n_layers, cfg.pow_bits,
                                             1 if cfg.hash == "blake2s" else 0], dtype=np.uint32),

@@ -145,38 +145,58 @@ def stwo_code(stage: int, layer: int, query: int, sub: int) -> int:
     return (stage << 24) | (layer << 16) | (query << 4) | sub
 
 
-def stwo_record(p: StwoProof) -> Tuple[np.ndarray, int]:
-    """Proof -> (record, shape_status); layout in include/ss_verify.h.  shape_status is the
-    code of the first `path == 1` assert (merkle.simf:42) that a wrong-length Merkle path
-    trips, or 0."""
+def stwo_record(p: StwoProof) -> np.ndarray:
+    """Proof -> record (layout in include/ss_verify.h).  Merkle paths go into fixed slots (first
+    min(len, slot) siblings, zero padded) and their real lengths into the path_len trailer; what a
+    wrong length means for the verdict is decided by the library (merkle.simf:42), not here."""
     c = p.cfg
     N, L, Q, K = c.n_cols, c.lde_log, c.n_queries, c.n_layers
-    shape = 0
-
-    def note(code: int) -> None:
-        nonlocal shape
-        if shape == 0 or code < shape:
-            shape = code
     parts: List[np.ndarray] = [
         _hash_words(p.roots.tobytes()), p.oods_trace.astype(np.uint32).reshape(-1),
         p.oods_cp.astype(np.uint32).reshape(-1), _hash_words(p.fri_roots.tobytes()),
         p.last_layer.astype(np.uint32).reshape(-1),
         np.array([p.pow_nonce >> 32, p.pow_nonce & 0xFFFFFFFF], dtype=np.uint32)]
     for q in range(Q):
-        if len(p.trace_paths[q]) != L:
-            note(stwo_code(5, 0, q, 0))
-        if len(p.cp_paths[q]) != L:
-            note(stwo_code(5, 0, q, 2))
         parts += [p.trace_vals[q].astype(np.uint32), p.cp_vals[q].astype(np.uint32),
                   _fixed_path(p.trace_paths[q], L), _fixed_path(p.cp_paths[q], L)]
     for l in range(K + 1):
         n = L - 1 - l
         for q in range(Q):
-            if len(p.fri_paths[l][q]) != n:
-                note(stwo_code(7, l, q, 0))
             parts += [p.fri_witness[l, q].astype(np.uint32), _fixed_path(p.fri_paths[l][q], n)]
-    rec = np.ascontiguousarray(np.concatenate(parts), dtype=np.uint32)
-    return rec, shape
+    lens = [[len(x) for x in p.trace_paths], [len(x) for x in p.cp_paths]]
+    lens += [[len(x) for x in p.fri_paths[l]] for l in range(K + 1)]
+    parts.append(np.array(lens, dtype=np.uint32).reshape(-1))
+    return np.ascontiguousarray(np.concatenate(parts), dtype=np.uint32)
+
+
+STATUS_CONFIG_MISMATCH = 1
+"""Status of a proof whose shape / declared parameters are not the config the caller expects.  The
+reference fixes NUM_COLUMNS, LDE_LOG_SIZE, NUM_FRI_QUERIES, NUM_FRI_LAYERS and POW_TARGET_64 at
+compile time (stwo-verifier/src/config.simf:10-51); a witness of any other shape fails typing and
+`simfony run` exits 1 before executing anything (simfony-cli/src/main.rs:77-81,187-190).  Stage 0
+precedes every assert of verify_proof, so this is the smallest status code."""
+
+
+def apply_config_policy(proofs: Sequence[StwoProof], cfg) -> Tuple[np.ndarray, List[List[int]]]:
+    """-> (status, groups): status[i] = STATUS_CONFIG_MISMATCH for every proof whose config is not
+    the expected one (or on the allow-list) and 0xFFFFFFFF (not yet verified = REJECT) for the
+    others; groups = indices of the admissible proofs, one list per config."""
+    allowed = _allowed_configs(cfg)
+    status = np.full(len(proofs), 0xFFFFFFFF, dtype=np.uint32)
+    ok = [i for i, p in enumerate(proofs) if p.cfg in allowed]
+    for i, p in enumerate(proofs):
+        if p.cfg not in allowed:
+            status[i] = STATUS_CONFIG_MISMATCH
+    return status, [[ok[j] for j in g] for g in group_by_config([proofs[i] for i in ok])]
+
+
+def _allowed_configs(cfg) -> List[StwoConfig]:
+    if isinstance(cfg, StwoConfig):
+        return [cfg]
+    allowed = list(cfg)
+    if not allowed or not all(isinstance(c, StwoConfig) for c in allowed):
+        raise TypeError("cfg must be the expected StwoConfig or a non-empty allow-list of them")
+    return allowed
 
 
 def group_by_config(proofs: Sequence[StwoProof]) -> List[List[int]]:
@@ -266,8 +286,7 @@ def _to_dev(a: np.ndarray, device):
 class _DeviceBatch:
     """A batch resident in HBM plus its workspace / status buffers."""
 
-    def __init__(self, ver: "Verifier", n: int, batch_host, ws_bytes: int,
-                 shape_status: Optional[np.ndarray]):
+    def __init__(self, ver: "Verifier", n: int, batch_host, ws_bytes: int):
         """`batch_host`: the packed batch as a numpy array (uploaded here) or as an int32 device
         tensor that is already resident."""
         torch = _torch()
@@ -276,9 +295,6 @@ class _DeviceBatch:
         self.ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.int32, device=ver.device)
         self.status_dev = torch.empty(n, dtype=torch.int32, device=ver.device)
         self.accept_dev = torch.zeros(1, dtype=torch.int32, device=ver.device)
-        self.shape_dev = None
-        if shape_status is not None and np.any(shape_status):
-            self.shape_dev = _to_dev(np.ascontiguousarray(shape_status, dtype=np.uint32), ver.device)
         self.batch_bytes = self.batch.numel() * 4
 
     def _stream(self, stream) -> int:
@@ -308,7 +324,7 @@ class _DeviceBatch:
 
 class StwoDeviceBatch(_DeviceBatch):
     def __init__(self, ver: "Verifier", cfg: StwoConfig, mode: int, records: Sequence[np.ndarray],
-                 shape_status: Optional[np.ndarray] = None, index: Optional[Sequence[int]] = None):
+                 index: Optional[Sequence[int]] = None):
         """`index` (optional): proof i of the batch is records[index[i]].  The distinct records are
         then uploaded once, replicated by a device gather and re-tiled by ss_stwo_pack_dev, so a
         65 536-proof batch made of a few distinct proofs costs no 11 GB host pack and upload."""
@@ -329,16 +345,28 @@ class StwoDeviceBatch(_DeviceBatch):
                                        int(torch.cuda.current_stream(ver.device).cuda_stream)))
             torch.cuda.synchronize(ver.device)
             del full, distinct
-        super().__init__(ver, n, packed, L.ss_stwo_workspace_bytes(C.byref(self.cs), n), shape_status)
+        super().__init__(ver, n, packed, L.ss_stwo_workspace_bytes(C.byref(self.cs), n))
 
     def run(self, stream=None, phases: int = PHASE_ALL) -> None:
         """Asynchronous: enqueue the verification of the whole batch (or one half of it, see
         SS_PHASE_* in include/ss_verify.h) on `stream`."""
         B.check(B.lib().ss_stwo_verify_phase_dev(
             self.ver.ctx, C.byref(self.cs), self.n, self.batch.data_ptr(),
-            self.shape_dev.data_ptr() if self.shape_dev is not None else None,
             self.ws.data_ptr(), self.ws.numel() * 4, self.status_dev.data_ptr(),
             self.accept_dev.data_ptr(), phases, self._stream(stream)))
+
+    def intermediates(self, proof: int, stream=None) -> dict:
+        """Per-stage values of proof `proof` left by the last run (ss_stwo_read_intermediates; the
+        reference's counterpart is the dbg! tracker, simfony-cli/src/tracker.rs:48-80)."""
+        Q, K = self.cfg.n_queries, self.cfg.n_layers
+        out = {"queries": np.zeros(Q, np.uint32), "oods_point": np.zeros(8, np.uint32),
+               "deep_alpha": np.zeros(4, np.uint32), "fold_alphas": np.zeros((K + 1, 4), np.uint32),
+               "fri_answers": np.zeros((Q, 4), np.uint32)}
+        B.check(B.lib().ss_stwo_read_intermediates(
+            self.ver.ctx, C.byref(self.cs), self.n, self.ws.data_ptr(), proof, self._stream(stream),
+            out["queries"].ctypes.data, out["oods_point"].ctypes.data, out["deep_alpha"].ctypes.data,
+            out["fold_alphas"].ctypes.data, out["fri_answers"].ctypes.data))
+        return out
 
 
 class S101DeviceBatch(_DeviceBatch):
@@ -346,8 +374,7 @@ class S101DeviceBatch(_DeviceBatch):
         L = B.lib()
         self.sh = B.S101Shape(max_layers, max_path)
         host = pack_s101(max_layers, max_path, records)
-        super().__init__(ver, len(records), host, L.ss_s101_workspace_bytes(C.byref(self.sh), len(records)),
-                         None)
+        super().__init__(ver, len(records), host, L.ss_s101_workspace_bytes(C.byref(self.sh), len(records)))
 
     def run(self, stream=None, phases: int = PHASE_ALL) -> None:
         B.check(B.lib().ss_s101_verify_phase_dev(
@@ -387,10 +414,11 @@ class Verifier:
 
     def collect_timing(self) -> dict:
         """{kernel name: (total_ms, launches)} since the last collect (waits for the events)."""
-        names = (C.c_char_p * 16)()
-        ms = (C.c_float * 16)()
-        cnt = (C.c_uint32 * 16)()
-        k = B.check(B.lib().ss_ctx_collect_timing(self.ctx, 16, names, ms, cnt))
+        cap = 64  # more kernel names than the library has
+        names = (C.c_char_p * cap)()
+        ms = (C.c_float * cap)()
+        cnt = (C.c_uint32 * cap)()
+        k = B.check(B.lib().ss_ctx_collect_timing(self.ctx, cap, names, ms, cnt))
         return {names[i].decode(): (float(ms[i]), int(cnt[i])) for i in range(k)}
 
     # -- stark101 ---------------------------------------------------------------------
@@ -407,38 +435,42 @@ class Verifier:
     # -- stwo -------------------------------------------------------------------------
     def stwo_batch(self, proofs: Sequence[StwoProof], mode: int = MODE_FIXTURE,
                    replicate: int = 1) -> StwoDeviceBatch:
+        """A resident batch of proofs that all have the config of proofs[0] (no policy here: the
+        caller has already decided that this config is the one it accepts, see verify_stwo)."""
         cfg = proofs[0].cfg
         if any(p.cfg != cfg for p in proofs):
             raise ValueError("all proofs of a batch must share one StwoConfig")
-        recs, shapes = zip(*[stwo_record(p) for p in proofs])
+        recs = [stwo_record(p) for p in proofs]
         if replicate > 1:  # the proofs repeated `replicate` times, replicated on the device
-            index = list(range(len(recs))) * replicate
-            return StwoDeviceBatch(self, cfg, mode, list(recs), np.array(list(shapes) * replicate, dtype=np.uint32),
-                                   index=index)
-        return StwoDeviceBatch(self, cfg, mode, list(recs), np.array(shapes, dtype=np.uint32))
+            return StwoDeviceBatch(self, cfg, mode, recs, index=list(range(len(recs))) * replicate)
+        return StwoDeviceBatch(self, cfg, mode, recs)
 
-    def verify_stwo(self, proofs: Sequence[StwoProof], mode: int = MODE_FIXTURE) -> np.ndarray:
-        """Status word per proof.  Proofs of different shapes (StwoConfig) may be mixed: each
-        shape is verified as its own device batch and the statuses return in input order."""
-        out = np.zeros(len(proofs), dtype=np.uint32)
-        for idx in group_by_config(proofs):
+    def verify_stwo(self, proofs: Sequence[StwoProof], mode: int = MODE_FIXTURE, *, cfg) -> np.ndarray:
+        """Status word per proof.  `cfg` is the StwoConfig the CALLER expects (or an explicit
+        allow-list of them): security parameters -- queries, blow-up, PoW bits, hash family, column
+        count -- are the verifier's, never the proof's.  A proof whose parsed shape or declared
+        config is not in `cfg` gets STATUS_CONFIG_MISMATCH without reaching the GPU; the others are
+        verified per config as their own device batch and the statuses return in input order."""
+        out, groups = apply_config_policy(proofs, cfg)
+        for idx in groups:
             b = self.stwo_batch([proofs[i] for i in idx], mode)
             b.run()
             out[idx] = b.status()
         return out
 
     def verify_stwo_records(self, cfg: StwoConfig, records: Sequence[np.ndarray],
-                            mode: int = MODE_FIXTURE,
-                            shape_status: Optional[np.ndarray] = None) -> np.ndarray:
+                            mode: int = MODE_FIXTURE) -> np.ndarray:
         """Host-buffer path (ss_stwo_verify_records): raw records are uploaded in pinned
         chunks, re-tiled on the GPU and verified.  PCIe-bound; synchronous."""
         cs = stwo_cfg_struct(cfg, mode)
-        status = np.zeros(len(records), dtype=np.uint32)
-        sh = None
-        if shape_status is not None and np.any(shape_status):
-            sh = np.ascontiguousarray(shape_status, dtype=np.uint32)
+        want = B.lib().ss_stwo_record_words(C.byref(cs))
+        if want == 0:
+            raise B.SsError(B.SS_ERR_ARG, "unsupported stwo config %r" % (cfg,))
+        for r in records:  # the library memcpy's `want` words from every pointer
+            if r.dtype != np.uint32 or r.size != want or not r.flags["C_CONTIGUOUS"]:
+                raise ValueError("record must be %d contiguous uint32 words" % want)
+        status = np.full(len(records), 0xFFFFFFFF, dtype=np.uint32)  # unwritten = REJECT
         B.check(B.lib().ss_stwo_verify_records(self.ctx, C.byref(cs), len(records), _ptr_array(records),
-                                               sh.ctypes.data if sh is not None else None,
                                                status.ctypes.data))
         return status
 
@@ -480,6 +512,8 @@ def verify_stark101(proof: Stark101Proof) -> bool:
     return int(default_verifier().verify_stark101([proof])[0]) == 0
 
 
-def verify_stwo(proof: StwoProof, mode: int = MODE_FIXTURE) -> bool:
-    """Drop-in for `simfony run stwo-verifier/main.simf --witness proof.wit`."""
-    return int(default_verifier().verify_stwo([proof], mode)[0]) == 0
+def verify_stwo(proof: StwoProof, mode: int = MODE_FIXTURE, cfg=None) -> bool:
+    """Drop-in for `simfony run stwo-verifier/main.simf --witness proof.wit`.  The expected config
+    defaults to what the reference compiles in without -DTESTING (config.simf:34-52)."""
+    from .formats import PRODUCTION_CONFIG
+    return int(default_verifier().verify_stwo([proof], mode, cfg=cfg or PRODUCTION_CONFIG)[0]) == 0

@@ -66,10 +66,12 @@ def test_blake2s_gpu_parity():
     for base in _proofs():
         batch = [base] + [formats.stwo_corrupt(base, rng)[0] for _ in range(79)]
         for mode in (verifier.MODE_FIXTURE, verifier.MODE_LITERAL):
-            got = ver.verify_stwo(batch, mode)
+            got = ver.verify_stwo(batch, mode, cfg=base.cfg)
             want = O.stwo_verify_batch(batch, mode)
             assert got.tolist() == want.tolist()
-        assert ver.verify_stwo([base]).tolist() == [0]
+        assert ver.verify_stwo([base], cfg=base.cfg).tolist() == [0]
     # the same bytes under the other hash family are rejected by the GPU too
     sha = ss.stwo_from_json(ss.stwo_to_json(_proofs()[1]), hash="sha256")
-    assert ver.verify_stwo([sha]).tolist() == [O.stwo_verify(sha, O.MODE_FIXTURE)] != [0]
+    assert ver.verify_stwo([sha], cfg=sha.cfg).tolist() == [O.stwo_verify(sha, O.MODE_FIXTURE)] != [0]
+    # ... and when the verifier expects Blake2s, a proof that declares SHA-256 never reaches the GPU
+    assert ver.verify_stwo([sha], cfg=_proofs()[1].cfg).tolist() == [verifier.STATUS_CONFIG_MISMATCH]

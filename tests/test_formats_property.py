@@ -9,7 +9,7 @@ from hypothesis import HealthCheck, given, settings
 from hypothesis import strategies as st
 
 import stark_symphony_amd as ss
-from stark_symphony_amd import binding, formats, verifier
+from stark_symphony_amd import binding, formats, records, verifier
 
 U32 = 1 << 32
 
@@ -43,10 +43,12 @@ def test_stwo_every_format_is_the_identity(t):
     assert ss.stwo_to_json(ss.stwo_from_json(json.dumps(want), c.trace_log)) == want
     assert ss.stwo_to_json(ss.stwo_from_wit(ss.stwo_to_wit(p), c.trace_log, c.pow_bits)) == want
     assert ss.stwo_to_json(ss.stwo_from_simf(ss.stwo_to_simf(p), c.trace_log, c.pow_bits)) == want
-    rec, shape = verifier.stwo_record(p)
+    rec = verifier.stwo_record(p)
     cs = verifier.stwo_cfg_struct(c, verifier.MODE_FIXTURE)
     import ctypes as C
-    assert shape == 0 and rec.size == binding.lib().ss_stwo_record_words(C.byref(cs)) == c.packed_bytes // 4
+    trailer = (c.n_layers + 3) * c.n_queries  # path_len words
+    assert rec.size == binding.lib().ss_stwo_record_words(C.byref(cs)) == c.packed_bytes // 4 + trailer
+    assert records.stwo_from_record(c, rec).trace_paths[0].shape == (c.lde_log, 32)
 
 
 @settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.too_slow])
@@ -59,10 +61,11 @@ def test_stwo_ragged_paths_survive_the_text_formats_and_are_reported(t):
     same_len = all(len(a) == len(b) for a, b in zip(p.trace_paths + p.cp_paths, back.trace_paths + back.cp_paths))
     assert same_len and all(len(a) == len(b) for la, lb in zip(p.fri_paths, back.fri_paths) for a, b in zip(la, lb))
     if len(p.trace_paths[0]) == c.lde_log:  # the .wit has no config: the first trace path fixes LDE_LOG_SIZE
-        rec, shape = verifier.stwo_record(back)
-        wrong = any(len(x) != c.lde_log for x in p.trace_paths + p.cp_paths) or any(
-            len(x) != c.lde_log - 1 - l for l, layer in enumerate(p.fri_paths) for x in layer)
-        assert (shape != 0) == wrong and rec.size == c.packed_bytes // 4
+        rec = verifier.stwo_record(back)
+        lens = rec[c.packed_bytes // 4:].reshape(c.n_layers + 3, c.n_queries)
+        assert lens[0].tolist() == [len(x) for x in p.trace_paths] and lens[1].tolist() == [len(x) for x in p.cp_paths]
+        for l, layer in enumerate(p.fri_paths):
+            assert lens[2 + l].tolist() == [len(x) for x in layer]
 
 
 def _rand_s101(seed: int, n_layers: int) -> ss.Stark101Proof:

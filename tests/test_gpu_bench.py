@@ -50,3 +50,34 @@ def test_bench_two_ranks_share_one_gpu():
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["proofs_per_gpu"] == 512 and "cpu_baseline" not in d
     assert abs(d["value"] - 2 * 512 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_spawns_its_own_ranks(n):
+    """`python bench.py --gpus N` exactly as the scaling driver may type it (no torchrun, no WORLD_SIZE):
+    the process turns into a launcher before touching torch / HIP, starts N ranks, relays rank 0's
+    single JSON line and returns non-zero if any rank does.  Here all ranks share GPU 0 over gloo."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SS_BENCH_SHARE_GPU="1", SS_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--workload",
+                        "stwo_fixture", "--proofs-per-gpu", "256", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=1200, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == n and d["steps"] == 3 and d["config"]["proofs_per_gpu"] == 256
+    assert abs(d["value"] - n * 256 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+def test_bench_launcher_reports_a_failing_rank():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SS_BENCH_SHARE_GPU="1", SS_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "no_such"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--workload", "stwo_fixture"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and "disagrees" in r.stderr

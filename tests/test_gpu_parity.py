@@ -156,8 +156,8 @@ def test_stark101_batch_4096(ver, s101_proof):
 @pytest.mark.parametrize("which", ["small", "prod"])
 def test_stwo_fixtures(ver, stwo_small, stwo_prod, which):
     p = stwo_small if which == "small" else stwo_prod
-    assert ver.verify_stwo([p], verifier.MODE_FIXTURE).tolist() == [0]
-    lit = ver.verify_stwo([p], verifier.MODE_LITERAL).tolist()
+    assert ver.verify_stwo([p], verifier.MODE_FIXTURE, cfg=p.cfg).tolist() == [0]
+    lit = ver.verify_stwo([p], verifier.MODE_LITERAL, cfg=p.cfg).tolist()
     assert lit == [O.stwo_verify(p, O.MODE_LITERAL)] and lit[0] == (7 << 24) | 1
 
 
@@ -170,7 +170,7 @@ def test_stwo_corruptions(ver, stwo_small, stwo_prod, mode):
             p, why = formats.stwo_corrupt(base, rng)
             batch.append(p)
             notes.append(why)
-        got = ver.verify_stwo(batch, mode)
+        got = ver.verify_stwo(batch, mode, cfg=base.cfg)
         want = O.stwo_verify_batch(batch, mode)
         bad = [(i, notes[i], hex(got[i]), hex(want[i])) for i in range(n) if got[i] != want[i]]
         assert not bad, bad[:5]
@@ -186,9 +186,10 @@ def test_stwo_wrong_path_lengths(ver, stwo_prod):
     batch.append(p)
     p = stwo_prod.copy(); p.fri_paths[4][7] = p.fri_paths[4][7][:2]; batch.append(p)
     p = stwo_prod.copy(); p.fri_paths[0][0] = p.fri_paths[0][0][:0]; p.pow_nonce += 1; batch.append(p)
-    got = ver.verify_stwo(batch)
+    got = ver.verify_stwo(batch, cfg=stwo_prod.cfg)
     want = O.stwo_verify_batch(batch)
     assert got.tolist() == want.tolist()
+    assert [hex(w) for w in want[1:]] == ['0x5000030', '0x5000002', '0x7040070', '0x4000000']
 
 
 def test_stwo_unreduced_words(ver, stwo_prod):
@@ -206,7 +207,7 @@ def test_stwo_unreduced_words(ver, stwo_prod):
         if mut == 7: p.oods_trace[0, 0] = 0x80000001
         batch.append(p)
     for mode in (verifier.MODE_FIXTURE, verifier.MODE_LITERAL):
-        got = ver.verify_stwo(batch, mode)
+        got = ver.verify_stwo(batch, mode, cfg=stwo_prod.cfg)
         assert got.tolist() == O.stwo_verify_batch(batch, mode).tolist()
 
 
@@ -215,7 +216,7 @@ def test_stwo_batch_replicated(ver, stwo_prod):
     rng = np.random.default_rng(SEED + 5)
     distinct = [stwo_prod] + [formats.stwo_corrupt(stwo_prod, rng)[0] for _ in range(9)]
     idx = [0 if i % 3 else 1 + (i // 3) % 9 for i in range(1000)]
-    got = ver.verify_stwo([distinct[i] for i in idx])
+    got = ver.verify_stwo([distinct[i] for i in idx], cfg=stwo_prod.cfg)
     want_d = O.stwo_verify_batch(distinct)
     assert got.tolist() == [int(want_d[i]) for i in idx]
     b = ver.stwo_batch([distinct[i] for i in idx])
@@ -234,21 +235,23 @@ def _load_npz(name):
     return records.load_stwo_npz(path)
 
 
-@pytest.mark.parametrize("name", ["stwo_trace16.npz", "stwo_wide256.npz", "stwo_trace20.npz"])
+@pytest.mark.parametrize("name", ["stwo_trace16.npz", "stwo_trace16_blake2s.npz", "stwo_wide256.npz",
+                                  "stwo_trace20.npz", "stwo_trace20_blake2s.npz"])
 def test_stwo_baseline_configs(ver, name):
-    """configs[2] (2^16 trace, 32 queries), configs[4] (256 columns, LDE 2^18) and configs[3]
-    (2^20 trace): valid proofs accept, seeded corruptions match the oracle word for word."""
+    """configs[2] (2^16 trace, 32 queries; SHA-256 = the pinned hash, and Blake2s = the config as
+    BASELINE.json names it), configs[4] (256 columns, LDE 2^18) and configs[3] (2^20 trace, both
+    hashes): valid proofs accept, seeded corruptions match the oracle word for word, both modes."""
     proofs = _load_npz(name)
     rng = np.random.default_rng(SEED + 11)
     batch = list(proofs)
     for _ in range(40):
         batch.append(formats.stwo_corrupt(proofs[0], rng)[0])
-    got = ver.verify_stwo(batch)
+    got = ver.verify_stwo(batch, cfg=proofs[0].cfg)
     want = O.stwo_verify_batch(batch)
     assert got.tolist() == want.tolist()
     assert (want[:len(proofs)] == 0).all() and (want[len(proofs):] != 0).any()
-    lit = ver.verify_stwo(batch[:4], verifier.MODE_LITERAL)
-    assert lit.tolist() == O.stwo_verify_batch(batch[:4], O.MODE_LITERAL).tolist()
+    lit = ver.verify_stwo(batch, verifier.MODE_LITERAL, cfg=proofs[0].cfg)
+    assert lit.tolist() == O.stwo_verify_batch(batch, O.MODE_LITERAL).tolist()
 
 
 def test_pipeline_matches_single_stream(ver, stwo_prod):
@@ -256,7 +259,7 @@ def test_pipeline_matches_single_stream(ver, stwo_prod):
     rng = np.random.default_rng(SEED + 12)
     distinct = [stwo_prod] + [formats.stwo_corrupt(stwo_prod, rng)[0] for _ in range(7)]
     batch = [distinct[i % 8] for i in range(256)]
-    ref = ver.verify_stwo(batch)
+    ref = ver.verify_stwo(batch, cfg=stwo_prod.cfg)
     a = ver.stwo_batch(batch)
     pipe = verifier.Pipeline([a, a.sibling()])
     used = [pipe.submit() for _ in range(5)]
@@ -273,7 +276,7 @@ def test_device_pack_equals_host_pack(ver, stwo_small, stwo_prod, which, n):
     base = {"small": stwo_small, "prod": stwo_prod}.get(which) or _load_npz("stwo_wide256.npz")[0]
     rng = np.random.default_rng(SEED + 13)
     proofs = [base] + [formats.stwo_corrupt(base, rng)[0] for _ in range(n - 1)]
-    recs = [verifier.stwo_record(p)[0] for p in proofs]
+    recs = [verifier.stwo_record(p) for p in proofs]
     host = verifier.pack_stwo(base.cfg, verifier.MODE_FIXTURE, recs)
     dev = ver.pack_stwo_on_device(base.cfg, verifier.MODE_FIXTURE, recs)
     assert np.array_equal(dev.cpu().numpy().view(np.uint32), host)
@@ -284,12 +287,11 @@ def test_host_buffer_entry_point(ver, stwo_prod):
     (1300 proofs of 54 KB > one 64 MiB staging buffer), called twice to reuse its scratch."""
     rng = np.random.default_rng(SEED + 14)
     distinct = [stwo_prod] + [formats.stwo_corrupt(stwo_prod, rng)[0] for _ in range(6)]
-    recs, shapes = zip(*[verifier.stwo_record(p) for p in distinct])
+    recs = [verifier.stwo_record(p) for p in distinct]
     want_d = O.stwo_verify_batch(list(distinct))
     for n in (1300, 17):
         idx = [i % 7 for i in range(n)]
-        got = ver.verify_stwo_records(stwo_prod.cfg, [recs[i] for i in idx],
-                                      shape_status=np.array([shapes[i] for i in idx]))
+        got = ver.verify_stwo_records(stwo_prod.cfg, [recs[i] for i in idx])
         assert got.tolist() == [int(want_d[i]) for i in idx]
 
 
@@ -302,7 +304,7 @@ def test_stwo_mixed_shapes_in_one_call(ver, stwo_small, stwo_prod):
         base = (stwo_small, stwo_prod, wide)[int(rng.integers(3))]
         proofs.append(base if rng.integers(2) else formats.stwo_corrupt(base, rng)[0])
     assert len(verifier.group_by_config(proofs)) == 3
-    got = ver.verify_stwo(proofs)
+    got = ver.verify_stwo(proofs, cfg=[stwo_small.cfg, stwo_prod.cfg, wide.cfg])
     want = [O.stwo_verify(p, O.MODE_FIXTURE) for p in proofs]
     assert got.tolist() == want and 0 in want and any(want)
 
@@ -383,11 +385,13 @@ def test_c_abi_consumer_program(ver, tmp_path, s101_proof, stwo_prod):
     exe = _build_c_example(tmp_path)
     rng = np.random.default_rng(SEED + 19)
     proofs = [stwo_prod] + [formats.stwo_corrupt(stwo_prod, rng)[0] for _ in range(5)]
-    proofs = [p for p in proofs if verifier.stwo_record(p)[1] == 0]  # the file format carries no shape_status
+    short = stwo_prod.copy(); short.fri_paths[2][5] = short.fri_paths[2][5][:-1]
+    long_ = stwo_prod.copy(); long_.cp_paths[1] = np.concatenate([long_.cp_paths[1], long_.cp_paths[1][:2]])
+    proofs += [short, long_]  # wrong path lengths: the record's path_len trailer carries them
     want = O.stwo_verify_batch(proofs)
     c = stwo_prod.cfg
     path = tmp_path / "stwo.bin"
-    np.concatenate([verifier.stwo_record(p)[0] for p in proofs]).astype("<u4").tofile(path)
+    np.concatenate([verifier.stwo_record(p) for p in proofs]).astype("<u4").tofile(path)
     args = [exe, "stwo", str(c.n_cols), str(c.trace_log), str(c.lde_log), str(c.n_queries), str(c.n_layers),
             str(c.pow_bits), "0", "1", str(path)]
     r = subprocess.run(args, capture_output=True, text=True)
@@ -398,7 +402,7 @@ def test_c_abi_consumer_program(ver, tmp_path, s101_proof, stwo_prod):
                             "proof %d: REJECT (first failing assert 0x%08x)" % (i, w))
     assert r.returncode == (1 if any(want) else 0)
     ok = tmp_path / "one.bin"
-    verifier.stwo_record(stwo_prod)[0].astype("<u4").tofile(ok)
+    verifier.stwo_record(stwo_prod).astype("<u4").tofile(ok)
     assert subprocess.run(args[:-1] + [str(ok)], capture_output=True).returncode == 0
     ml, pm = verifier.s101_shape_of([s101_proof])
     p101 = tmp_path / "s101.bin"
@@ -412,9 +416,98 @@ def test_replicated_batch_built_on_the_device_equals_the_host_pack(ver, stwo_pro
     rng = np.random.default_rng(SEED + 20)
     distinct = [stwo_prod] + [formats.stwo_corrupt(stwo_prod, rng)[0] for _ in range(4)]
     b = ver.stwo_batch(distinct, verifier.MODE_FIXTURE, replicate=27)
-    recs = [verifier.stwo_record(p)[0] for p in distinct]
+    recs = [verifier.stwo_record(p) for p in distinct]
     host = verifier.pack_stwo(stwo_prod.cfg, verifier.MODE_FIXTURE, recs * 27)
     assert b.n == 135 and np.array_equal(b.batch.cpu().numpy().view(np.uint32), host)
     b.run()
     want = O.stwo_verify_batch(distinct).tolist()
     assert b.status().tolist() == want * 27
+
+
+# ---------------------------------------------------------- `simfony run` shim
+def _cli(*args):
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    return subprocess.run([sys.executable, "-m", "stark_symphony_amd.cli", "verify", *args], cwd=ROOT,
+                          capture_output=True, text=True, timeout=600, env=dict(os.environ, PYTHONPATH=ROOT))
+
+
+def test_cli_verify_exit_status_contract(tmp_path):
+    """The reference's process contract (simfony-cli/src/main.rs:205-206,254-257,273): exit 0 for a
+    satisfied program; `Error: Failed to run program ...` on stderr and exit 1 for a failed assert;
+    a witness that does not type-check is exit 1 as well (main.rs:77-81,187-190)."""
+    import json
+    import os
+    from conftest import GOLDEN
+    F = os.path.join(GOLDEN, "formats")
+    r = _cli("--family", "stark101", "--witness", os.path.join(F, "stark101_proof.wit"))
+    assert r.returncode == 0 and "ACCEPT" in r.stdout and r.stderr == "", r.stderr
+    r = _cli("--family", "stwo", "--witness", os.path.join(F, "stwo_proof.wit"))  # production = default
+    assert r.returncode == 0 and "ACCEPT" in r.stdout, r.stderr
+    r = _cli("--family", "stwo", "--config", "testing", "--witness", os.path.join(F, "stwo_proof_test.wit"))
+    assert r.returncode == 0, r.stderr
+    r = _cli("--family", "stwo", "--proof", os.path.join(GOLDEN, "stwo_proof.json"),
+             os.path.join(GOLDEN, "stwo_proof.json"))
+    assert r.returncode == 0 and r.stdout.count("ACCEPT") == 2
+    # the test-config proof where production is enforced: shape mismatch = typing failure = exit 1
+    r = _cli("--family", "stwo", "--witness", os.path.join(F, "stwo_proof_test.wit"))
+    assert r.returncode == 1 and r.stderr.startswith("Error: Failed to run program") and "ACCEPT" not in r.stdout
+    # one flipped bit in a committed root of the stark101 witness
+    wit = json.load(open(os.path.join(F, "stark101_proof.wit")))
+    v = wit["P_MT_ROOT"]["value"]
+    wit["P_MT_ROOT"]["value"] = v[:-1] + ("0" if v[-1] != "0" else "1")
+    bad = tmp_path / "bad.wit"
+    bad.write_text(json.dumps(wit))
+    r = _cli("--family", "stark101", "--witness", str(bad))
+    assert r.returncode == 1 and r.stderr.startswith("Error: Failed to run program"), (r.stdout, r.stderr)
+    # accepted and rejected inputs together: every verdict is printed, exit 1
+    r = _cli("--family", "stark101", "--witness", os.path.join(F, "stark101_proof.wit"), str(bad))
+    assert r.returncode == 1 and r.stdout.count("ACCEPT") == 1 and "REJECT" in r.stderr
+    # literal mode = the .simf text, which rejects the repo's own proof at the first FRI decommitment
+    r = _cli("--family", "stwo", "--mode", "literal", "--witness", os.path.join(F, "stwo_proof.wit"))
+    assert r.returncode == 1 and "0x07000001" in r.stderr
+    # malformed witness / missing file: exit 1, nothing verified
+    junk = tmp_path / "junk.wit"
+    junk.write_text("{\"P_MT_ROOT\": {\"value\": \"(1, 2\", \"type\": \"u256\"}}")
+    assert _cli("--family", "stark101", "--witness", str(junk)).returncode == 1
+    assert _cli("--family", "stwo", "--witness", str(tmp_path / "absent.wit")).returncode == 1
+
+
+def test_stwo_config_policy_on_the_gpu(ver, stwo_small, stwo_prod):
+    """verify_stwo enforces the caller's config: the one-query test proof is status 1 where the
+    production config is expected, and verifies where it is allowed."""
+    got = ver.verify_stwo([stwo_prod, stwo_small], cfg=stwo_prod.cfg)
+    assert got.tolist() == [0, verifier.STATUS_CONFIG_MISMATCH]
+    assert got.tolist() == O.stwo_verify_batch([stwo_prod, stwo_small], cfg=stwo_prod.cfg).tolist()
+    assert ver.verify_stwo([stwo_prod, stwo_small], cfg=[stwo_prod.cfg, stwo_small.cfg]).tolist() == [0, 0]
+    assert verifier.verify_stwo(stwo_prod) is True and verifier.verify_stwo(stwo_small) is False
+    with pytest.raises(TypeError):
+        ver.verify_stwo([stwo_prod])  # no expected config, no verdict
+
+
+# ----------------------------------------------------------------------- seeded fuzz slice
+def test_fuzz_slice_matches_the_oracle(ver, s101_proof, stwo_small, stwo_prod):
+    """A seeded 2 000-mutant slice of tools/fuzz_parity.py (the long runs are summarised in
+    profiles/*_fuzz_parity.txt): bit flips, words replaced by 0 / P / P+v / 2^32-1, siblings swapped,
+    values copied between queries, ragged path lengths, double mutations; both stwo modes."""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_parity as fz
+    rng = np.random.default_rng(SEED + 23)
+    muts = [s101_proof] + [fz.mutate_s101(s101_proof, rng) for _ in range(400)]
+    assert ver.verify_stark101(muts).tolist() == O.s101_verify_batch(muts).tolist()
+    wide = _load_npz("stwo_wide256.npz")[0]
+    t16 = _load_npz("stwo_trace16.npz")[0]
+    seen = set()
+    for base, n in ((stwo_prod, 500), (stwo_small, 300), (wide, 200), (t16, 200)):
+        muts = [base] + [fz.mutate_stwo(base, rng) for _ in range(n)]
+        for mode in (verifier.MODE_FIXTURE, verifier.MODE_LITERAL):
+            got, want = ver.verify_stwo(muts, mode, cfg=base.cfg), O.stwo_verify_batch(muts, mode)
+            bad = np.nonzero(got != want)[0]
+            assert bad.size == 0, (mode, int(bad[0]), hex(got[bad[0]]), hex(want[bad[0]]))
+            seen |= set(want.tolist())
+    assert len(seen) > 12

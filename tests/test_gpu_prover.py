@@ -54,7 +54,7 @@ def test_gpu_prove_then_gpu_verify_roundtrip(gp):
     proofs = [ss.stwo_from_json(gp.prove(n_cols=4, trace_log=14, log_blowup=4, n_queries=16, seed=s))
               for s in (0, 1, 2)]
     assert len({bytes(p.roots[1]) for p in proofs}) == 3
-    status = gp.ver.verify_stwo(proofs)
+    status = gp.ver.verify_stwo(proofs, cfg=[p.cfg for p in proofs])
     assert status.tolist() == [0, 0, 0]
     assert gp.timings["total"] > 0
 
@@ -112,7 +112,7 @@ def test_random_shapes_prove_verify_and_match_the_oracle(gp):
         proof = ss.stwo_from_json(gp.prove(**kw))
         batch = [proof] + [formats.stwo_corrupt(proof, rng)[0] for _ in range(6)]
         for mode in (verifier.MODE_FIXTURE, verifier.MODE_LITERAL):
-            got = gp.ver.verify_stwo(batch, mode)
+            got = gp.ver.verify_stwo(batch, mode, cfg=batch[0].cfg)
             want = O.stwo_verify_batch(batch, mode)
             assert got.tolist() == want.tolist(), (kw, mode)
-        assert gp.ver.verify_stwo(batch)[0] == 0, kw
+        assert gp.ver.verify_stwo(batch, cfg=batch[0].cfg)[0] == 0, kw

@@ -24,7 +24,8 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(binding.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ss_version() == 0x00010000
+    assert lib.ss_version() == 0x00020000
+    assert lib.ss_abi_sizeof_cfg() == C.sizeof(binding.StwoCfg) == 40 and lib.ss_abi_sizeof_shape() == 8
 
 
 def test_library_exports_every_prover_symbol():
@@ -118,12 +119,12 @@ def _tile_word(base, tile_len, inst, level, w):
 
 def test_stwo_record_and_pack_layout(stwo_prod):
     cfg = stwo_prod.cfg
-    rec, shape = verifier.stwo_record(stwo_prod)
-    assert shape == 0
+    rec = verifier.stwo_record(stwo_prod)
     lib = binding.lib()
     cs = verifier.stwo_cfg_struct(cfg, verifier.MODE_FIXTURE)
     assert rec.size == lib.ss_stwo_record_words(C.byref(cs))
-    assert rec.size * 4 == cfg.packed_bytes  # the record is exactly the algorithmic bytes
+    # the record is the algorithmic bytes + one length word per Merkle path
+    assert rec.size * 4 == cfg.packed_bytes + 4 * (cfg.n_layers + 3) * cfg.n_queries
     n = 70
     other = rec.copy()
     other[::7] ^= 0xA5A5A5A5
@@ -139,7 +140,8 @@ def test_stwo_record_and_pack_layout(stwo_prod):
     off_tv = off_head + head_words * npad
     off_cv = off_tv + N * nip
     off_wit = off_cv + 16 * nip
-    off_tp = off_wit + (K + 1) * 4 * nip
+    off_len = off_wit + (K + 1) * 4 * nip
+    off_tp = off_len + (K + 3) * nip
     off_cp = off_tp + L * 8 * nip
     off_fp = [off_cp + L * 8 * nip]
     for l in range(K + 1):
@@ -168,6 +170,9 @@ def test_stwo_record_and_pack_layout(stwo_prod):
                 for lv in range(ln):
                     for w in range(8):
                         expect[_tile_word(off_fp[l], ln, inst, lv, w)] = r[pos]; pos += 1
+        for kind in range(K + 3):
+            for q in range(Q):
+                expect[off_len + kind * nip + p * Q + q] = r[pos]; pos += 1
         assert pos == r.size
     assert np.array_equal(batch, expect)
 
@@ -176,9 +181,13 @@ def test_stwo_record_reports_wrong_path_lengths(stwo_prod):
     p = stwo_prod.copy()
     p.fri_paths[2][5] = p.fri_paths[2][5][:-1]
     p.cp_paths[9] = p.cp_paths[9][:3]
-    rec, shape = verifier.stwo_record(p)
-    assert shape == verifier.stwo_code(5, 0, 9, 2)
-    assert rec.size * 4 == p.cfg.packed_bytes
+    rec = verifier.stwo_record(p)
+    c = p.cfg
+    lens = rec[c.packed_bytes // 4:].reshape(c.n_layers + 3, c.n_queries)
+    assert lens[1, 9] == 3 and lens[2 + 2, 5] == c.fri_path_len(2) - 1
+    want = np.array([[c.lde_log] * c.n_queries] * 2 + [[c.fri_path_len(l)] * c.n_queries for l in range(c.n_layers + 1)])
+    want[1, 9], want[4, 5] = 3, c.fri_path_len(2) - 1
+    assert np.array_equal(lens, want)
 
 
 def test_s101_record_and_pack(s101_proof):
@@ -346,3 +355,51 @@ def test_oracle_sha256_portable_and_sha_extension_paths_agree():
     assert outs[0][:8] == [hashlib.sha256(m).hexdigest() for m in msgs]
     assert outs[0][8] == 0 and outs[0][9] == (7 << 24) | 1
     assert O.sha256(b"abc") == hashlib.sha256(b"abc").digest()
+
+
+# ------------------------------------------------ the verifier's config, not the proof's
+def test_security_parameters_come_from_the_caller_not_the_proof(stwo_small, stwo_prod):
+    """The reference compiles NUM_FRI_QUERIES / LDE_LOG_SIZE / POW_TARGET_64 in (config.simf:10-51):
+    a one-query, blow-up-2 test proof must not pass where the production config is expected."""
+    status, groups = verifier.apply_config_policy([stwo_prod, stwo_small, stwo_prod], ss.PRODUCTION_CONFIG)
+    assert status.tolist() == [0xFFFFFFFF, verifier.STATUS_CONFIG_MISMATCH, 0xFFFFFFFF] and groups == [[0, 2]]
+    status, groups = verifier.apply_config_policy([stwo_prod, stwo_small], [stwo_small.cfg, stwo_prod.cfg])
+    assert (status == 0xFFFFFFFF).all() and groups == [[0], [1]]
+    with pytest.raises(TypeError):
+        verifier.apply_config_policy([stwo_prod], [])
+    import dataclasses
+    for field, value in (("pow_bits", 0), ("hash", "blake2s"), ("n_queries", 1), ("trace_log", 8)):
+        declared = dataclasses.replace(stwo_prod.cfg, **{field: value})
+        p = stwo_prod.copy()
+        p.cfg = declared
+        assert verifier.apply_config_policy([p], ss.PRODUCTION_CONFIG)[0].tolist() == [1], field
+
+
+def test_json_without_pow_bits_never_means_no_proof_of_work():
+    obj = json.load(open(os.path.join(ROOT, "tests", "golden", "stwo_proof.json")))
+    assert ss.stwo_from_json(obj).cfg == ss.PRODUCTION_CONFIG
+    del obj["config"]["pow_bits"]
+    with pytest.raises(ss.MalformedProof):
+        ss.stwo_from_json(obj)
+    assert ss.stwo_from_json(obj, expect=ss.PRODUCTION_CONFIG).cfg == ss.PRODUCTION_CONFIG
+    obj["config"]["pow_bits"] = 0  # a downgrade the proof declares: parsed as declared, refused by the policy
+    p = ss.stwo_from_json(obj, expect=ss.PRODUCTION_CONFIG)
+    assert p.cfg.pow_bits == 0 and verifier.apply_config_policy([p], ss.PRODUCTION_CONFIG)[0].tolist() == [1]
+    del obj["config"]
+    with pytest.raises(ss.MalformedProof):
+        ss.stwo_from_json(obj)
+
+
+def test_oracle_batch_groups_mixed_configs(stwo_small, stwo_prod):
+    """a mixed-config list used to be verified under the first proof's config (wrong
+    verdict or out-of-bounds read)."""
+    from oracle import oracle as O
+    for order in ([stwo_small, stwo_prod, stwo_small], [stwo_prod, stwo_small]):
+        assert O.stwo_verify_batch(order).tolist() == [0] * len(order)
+    assert O.stwo_verify_batch([stwo_prod, stwo_small], cfg=stwo_prod.cfg).tolist() == [0, 1]
+    with pytest.raises(ValueError):
+        O.StwoBatch([stwo_small, stwo_prod])
+    bad = stwo_prod.copy()
+    bad.trace_paths = bad.trace_paths[:-1]  # fewer paths than queries: refused before C sees a pointer
+    with pytest.raises(ValueError):
+        O.stwo_verify(bad)

@@ -22,8 +22,9 @@ from stark_symphony_amd import formats, records, verifier  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 import stwo_prover  # noqa: E402
 
-N = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
-SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 20251003
+_cli = __name__ == "__main__"
+N = int(sys.argv[1]) if _cli and len(sys.argv) > 1 else 2000
+SEED = int(sys.argv[2]) if _cli and len(sys.argv) > 2 else 20251003
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 P31 = 2147483647
 P101 = 3221225473
@@ -59,7 +60,7 @@ def mutate_stwo(p, rng):
         q.fri_witness[int(rng.integers(K + 1)), int(rng.integers(Q))] = 0
     elif kind == 5:  # nonce tweaks
         q.pow_nonce = (q.pow_nonce + int(rng.integers(1, 5))) & 0xFFFFFFFFFFFFFFFF
-    elif kind == 6:  # drop / duplicate a path node (shape_status path)
+    elif kind == 6:  # drop / duplicate a path node (the record's path_len trailer)
         paths = [q.trace_paths, q.cp_paths] + q.fri_paths
         pl = paths[int(rng.integers(len(paths)))]
         j = int(rng.integers(Q))
@@ -118,7 +119,7 @@ def main():
     for name, base in cases:
         muts = [base] + [mutate_stwo(base, rng) for _ in range(N)]
         for mode in (verifier.MODE_FIXTURE, verifier.MODE_LITERAL):
-            got, want = ver.verify_stwo(muts, mode), O.stwo_verify_batch(muts, mode)
+            got, want = ver.verify_stwo(muts, mode, cfg=muts[0].cfg), O.stwo_verify_batch(muts, mode)
             mism = int((got != want).sum())
             print("stwo %-16s mode %d: %d mutants, %d distinct codes, accepts %d, mismatches %d"
                   % (name, mode, N, len(set(want.tolist())), int((want == 0).sum()), mism), flush=True)

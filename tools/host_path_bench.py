@@ -14,7 +14,7 @@ from stark_symphony_amd import binding as B, records, verifier  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 proofs = records.load_stwo_npz(os.path.join(ROOT, "tests", "golden", "stwo_trace20.npz"))
-recs = [verifier.stwo_record(p)[0] for p in proofs]
+recs = [verifier.stwo_record(p) for p in proofs]
 cfg = verifier.stwo_cfg_struct(proofs[0].cfg, verifier.MODE_FIXTURE)
 ver = verifier.Verifier(0)
 ptrs = verifier._ptr_array([recs[i % len(recs)] for i in range(n)])

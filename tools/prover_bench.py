@@ -27,7 +27,7 @@ for r in range(reps):
         best = (dt, dict(gp.timings))
     print("run %d: %.3f s" % (r, dt), {k: round(v, 4) for k, v in gp.timings.items()}, flush=True)
 proof = ss.stwo_from_json(pj)
-print("verify on GPU:", ver.verify_stwo([proof]).tolist())
+print("verify on GPU:", ver.verify_stwo([proof], cfg=proof.cfg).tolist())
 gold = os.path.join(ROOT, "tests", "golden", "stwo_trace20.npz")
 if trace_log == 20 and hash_name == "sha256" and os.path.exists(gold):
     want = records.load_stwo_npz(gold)[0]

@@ -44,6 +44,76 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) chain_kernel(uint32_t iters
     out[t] = x;
 }
 
+// A/B for the north-star's "message schedule staged in LDS": the same chain with the 16-word
+// rolling schedule window of the first compression kept in LDS (column per lane, conflict free)
+// instead of VGPRs.  Every round then costs one ds_read_b32, every schedule update three reads
+// and one write, on top of the same VALU instructions -- the loop's cost is its instruction count,
+// so this can only lose; measured here so the claim has a number (profiles/r02_sha_lds_ab.txt).
+__global__ void __launch_bounds__(256) chain_kernel_lds(uint32_t iters, uint32_t *out)
+{
+    __shared__ uint32_t sw[16][256];
+    uint32_t node[8], sib[8];
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, l = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { node[j] = t * 0x9E3779B1u + j; sib[j] = t ^ (0x85EBCA6Bu * (j + 1)); }
+    uint32_t auth = t;
+    for (uint32_t it = 0; it < iters; it++) {
+        const bool right = auth & 1;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            sw[j][l] = right ? sib[j] : node[j];
+            sw[8 + j][l] = right ? node[j] : sib[j];
+        }
+        sha_iv(node);
+        uint32_t a = node[0], b = node[1], c = node[2], d = node[3], e = node[4], f = node[5], g = node[6],
+                 h = node[7];
+#pragma unroll
+        for (int r = 0; r < 64; r++) {
+            if (r >= 16)
+                sw[r & 15][l] += sha_s0(sw[(r + 1) & 15][l]) + sw[(r + 9) & 15][l] + sha_s1(sw[(r + 14) & 15][l]);
+            const uint32_t t1 = h + sha_S1(e) + sha_ch(e, f, g) + (kK.k[r] + sw[r & 15][l]);
+            const uint32_t t2 = sha_S0(a) + sha_maj(a, b, c);
+            h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        }
+        node[0] += a; node[1] += b; node[2] += c; node[3] += d; node[4] += e; node[5] += f; node[6] += g;
+        node[7] += h;
+        sha256_compress_pad64(node);
+        auth = (auth >> 1) | (auth << 31);
+#pragma unroll
+        for (int j = 0; j < 8; j++) sib[j] += node[(j + 3) & 7];
+    }
+    uint32_t x = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) x ^= node[j];
+    out[t] = x;
+}
+
+static void run_lds(uint32_t iters, int blocks_per_cu, int cus)
+{
+    const int grid = cus * blocks_per_cu;
+    uint32_t *out;
+    hipMalloc(&out, (size_t)grid * 256 * 4);
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    chain_kernel_lds<<<grid, 256>>>(iters / 8 + 1, out);
+    hipDeviceSynchronize();
+    float best = 1e30f;
+    for (int r = 0; r < 5; r++) {
+        hipEventRecord(a);
+        chain_kernel_lds<<<grid, 256>>>(iters, out);
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        float ms;
+        hipEventElapsedTime(&ms, a, b);
+        if (ms < best) best = ms;
+    }
+    const double pairs = (double)grid * 256 * iters;
+    printf("%-28s blocks/CU %2d  iters %5u  %8.3f ms  %7.2f G pair-hashes/s  %7.2f G compressions/s\n",
+           "schedule window in LDS", blocks_per_cu, iters, best, pairs / best / 1e6, 2 * pairs / best / 1e6);
+    hipFree(out);
+}
+
 // Blake2s-256 variant of the same chain: one compression per 64-byte node.
 __global__ void __launch_bounds__(256) chain_kernel_b2s(uint32_t iters, uint32_t *out)
 {
@@ -140,6 +210,7 @@ int main(int argc, char **argv)
         run<6>("launch_bounds(256,6)", iters, bpc, cus);
         run<8>("launch_bounds(256,8)", iters, bpc, cus);
     }
+    for (int bpc : {2, 4, 8}) run_lds(iters, bpc, cus);
     for (int bpc : {1, 2, 4, 8}) run_b2s(iters * 2, bpc, cus);
     return 0;
 }
