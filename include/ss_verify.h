@@ -95,8 +95,15 @@ typedef struct ss_stwo_cfg {
     uint32_t mode;       /* SS_MODE_*                                      */
     uint64_t pow_target; /* POW_TARGET_64: digest value must be < target   */
     uint32_t hash;       /* SS_HASH_*                                      */
-    uint32_t reserved;   /* 0; explicit tail padding: sizeof == 40         */
+    uint32_t flags;      /* SS_FLAG_*; 0 = defaults (explicit tail word: sizeof == 40) */
 } ss_stwo_cfg;
+
+/* SS_FLAG_NO_DEDUP: hash every query's Merkle path in full, as the reference does
+ * (fri/queries.simf:41 notes that it does not deduplicate).  By default the library hashes each
+ * distinct (left, right) pair of the top levels of a tree once per proof and checks byte for byte
+ * that every query presenting that node presents the same pair; trees where two queries disagree
+ * are re-hashed query by query, so the status words are the reference's either way.        */
+#define SS_FLAG_NO_DEDUP 1u
 
 /* SS_HASH_SHA256 is the reference (hasher.simf:13-104, channel.simf:36-172).  SS_HASH_BLAKE2S is
  * the "Blake2s Merkle" variant BASELINE.json names: the same protocol over the same byte
@@ -187,6 +194,53 @@ int ss_s101_verify_records(ss_ctx *ctx, const ss_s101_shape *shape, size_t n,
                            const uint32_t *const *records, uint32_t *status_host);
 int ss_stwo_verify_records(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n,
                            const uint32_t *const *records, uint32_t *status_host);
+
+/* ===================================================================== text ingestion
+ * The reference's callers hand the verifier TEXT: proof.json (stwo: the schema read by
+ * stwo-verifier/scripts/generate_wit.py:106-245; stark101: fibsquare/prover.py:108,143-167) or
+ * proof.wit (generate_wit.py:218-243, stark101/scripts/generate_wit.py:13-30), the file `simfony run
+ * --witness` consumes (simfony-cli/src/main.rs:163-209).  These entry points read that text natively
+ * (host threads, straight into the pinned staging buffers of the upload), so the drop-in path is
+ * not bound by a Python parser.  `cfg` is the config the CALLER expects: a proof that declares, or
+ * has the shape of, any other config is not verified against it.
+ * Status words of stage 0 (host side, before any kernel; smaller than every assert code):
+ *   SS_STATUS_CONFIG_MISMATCH  well-formed witness of another shape / declared parameters -- the
+ *                              reference would fail to type it (main.rs:77-81,187-190)
+ *   SS_STATUS_MALFORMED        not a witness of the reference's types at all                     */
+#define SS_TEXT_AUTO 0 /* sniff: a .wit is a JSON object with a COMMITMENTS / P_MT_ROOT member */
+#define SS_TEXT_JSON 1
+#define SS_TEXT_WIT 2
+#define SS_STATUS_CONFIG_MISMATCH 1u
+#define SS_STATUS_MALFORMED 2u
+
+/* One text -> one record (ss_stwo_record_words words).  Returns 0 = parsed, SS_STATUS_CONFIG_MISMATCH,
+ * SS_STATUS_MALFORMED (record_out untouched or zeroed), or < 0 on a bad argument.  No GPU involved. */
+int ss_stwo_parse(const ss_stwo_cfg *cfg, const char *text, size_t len, int fmt, uint32_t *record_out);
+/* stark101: the shape is data.  ss_s101_parse returns 0 / SS_STATUS_MALFORMED and the proof's shape;
+ * record_out (may be NULL) receives ss_s101_record_words(shape_inout) words when the proof fits the
+ * shape passed in (layers / path lengths up to 31 always fit {31, 31}).                           */
+int ss_s101_parse(const char *text, size_t len, int fmt, ss_s101_shape *shape_inout, uint32_t *record_out);
+
+typedef struct ss_ingest_stats {
+    double read_s;    /* wall time reading files (0 for the *_texts entry points)      */
+    double parse_s;   /* wall time in the parallel text -> record phases              */
+    double total_s;   /* the whole call: read + parse + upload + verify + download    */
+    uint64_t text_bytes, record_bytes;
+    uint32_t threads; /* host threads used (scheduler affinity capped by the cgroup quota) */
+    uint32_t reserved;
+} ss_ingest_stats;
+
+/* Texts / files -> verdicts, synchronous: chunks are parsed by host threads into pinned staging
+ * while the previous chunk uploads, then re-tiled and verified on the GPU.  status_host[i] is the
+ * verdict of input i (stage-0 codes above included).  stats may be NULL.                         */
+int ss_stwo_verify_texts(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const char *const *texts,
+                         const size_t *lens, int fmt, uint32_t *status_host, ss_ingest_stats *stats);
+int ss_stwo_verify_files(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const char *const *paths, int fmt,
+                         uint32_t *status_host, ss_ingest_stats *stats);
+int ss_s101_verify_texts(ss_ctx *ctx, size_t n, const char *const *texts, const size_t *lens, int fmt,
+                         uint32_t *status_host, ss_ingest_stats *stats);
+int ss_s101_verify_files(ss_ctx *ctx, size_t n, const char *const *paths, int fmt, uint32_t *status_host,
+                         ss_ingest_stats *stats);
 
 /* Per-stage intermediates of one proof after a verify call (the reference's counterpart is the
  * debug tracker of `simfony run`, simfony-cli/src/tracker.rs:48-80, which prints the values a

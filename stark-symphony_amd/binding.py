@@ -26,7 +26,7 @@ class StwoCfg(C.Structure):
     """ss_stwo_cfg"""
     _fields_ = [("n_cols", C.c_uint32), ("trace_log", C.c_uint32), ("lde_log", C.c_uint32),
                 ("n_queries", C.c_uint32), ("n_layers", C.c_uint32), ("mode", C.c_uint32),
-                ("pow_target", C.c_uint64), ("hash", C.c_uint32), ("reserved", C.c_uint32)]
+                ("pow_target", C.c_uint64), ("hash", C.c_uint32), ("flags", C.c_uint32)]
 
 
 class S101Shape(C.Structure):
@@ -42,9 +42,20 @@ class StwoWsLayout(C.Structure):
                 ("n_pow", C.c_uint32)]
 
 
+class IngestStats(C.Structure):
+    """ss_ingest_stats"""
+    _fields_ = [("read_s", C.c_double), ("parse_s", C.c_double), ("total_s", C.c_double),
+                ("text_bytes", C.c_uint64), ("record_bytes", C.c_uint64), ("threads", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+TEXT_AUTO, TEXT_JSON, TEXT_WIT = 0, 1, 2
+STATUS_CONFIG_MISMATCH, STATUS_MALFORMED = 1, 2
+
 EXPORTS = [
     "ss_version", "ss_last_error", "ss_device_count", "ss_abi_sizeof_cfg", "ss_abi_sizeof_shape",
-    "ss_stwo_ws_layout_of", "ss_stwo_read_intermediates",
+    "ss_stwo_ws_layout_of", "ss_stwo_read_intermediates", "ss_stwo_parse", "ss_s101_parse",
+    "ss_stwo_verify_texts", "ss_stwo_verify_files", "ss_s101_verify_texts", "ss_s101_verify_files",
     "ss_s101_record_words", "ss_s101_batch_words", "ss_s101_workspace_bytes", "ss_s101_pack",
     "ss_stwo_record_words", "ss_stwo_batch_words", "ss_stwo_workspace_bytes", "ss_stwo_pack",
     "ss_ctx_create", "ss_ctx_destroy", "ss_s101_verify_batch_dev", "ss_stwo_verify_batch_dev",
@@ -104,6 +115,13 @@ def lib() -> C.CDLL:
     sig("ss_stwo_verify_records", C.c_int, vp, cp, sz, pp, vp)
     sig("ss_ctx_set_timing", C.c_int, vp, C.c_int)
     sig("ss_ctx_collect_timing", C.c_int, vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_float), u32p)
+    cpp, szp, stp = C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.POINTER(IngestStats)
+    sig("ss_stwo_parse", C.c_int, cp, C.c_char_p, sz, C.c_int, vp)
+    sig("ss_s101_parse", C.c_int, C.c_char_p, sz, C.c_int, sp, vp)
+    sig("ss_stwo_verify_texts", C.c_int, vp, cp, sz, cpp, szp, C.c_int, vp, stp)
+    sig("ss_stwo_verify_files", C.c_int, vp, cp, sz, cpp, C.c_int, vp, stp)
+    sig("ss_s101_verify_texts", C.c_int, vp, sz, cpp, szp, C.c_int, vp, stp)
+    sig("ss_s101_verify_files", C.c_int, vp, sz, cpp, C.c_int, vp, stp)
     sig("ss_stwo_ws_layout_of", C.c_int, cp, sz, C.POINTER(StwoWsLayout))
     sig("ss_stwo_read_intermediates", C.c_int, vp, cp, sz, vp, sz, vp, vp, vp, vp, vp, vp)
     sig("ss_selftest", C.c_int, vp, C.c_int, sz, vp, vp)

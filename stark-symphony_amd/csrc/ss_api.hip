@@ -8,8 +8,12 @@
 #include <thread>
 #include <vector>
 
+#include <chrono>
+#include <string>
+
 #include "../../include/ss_verify.h"
 #include "ss_fields.h"
+#include "ss_ingest.h"
 #include "ss_kernels.h"
 #include "ss_layout.h"
 #include "ss_sha256.h"
@@ -197,13 +201,13 @@ static void parallel_for(size_t n, F f, size_t max_threads = 16)
 // ================================================================================ stwo
 static bool cfg_ok(const ss_stwo_cfg *c)
 {
-    return c && c->hash <= SS_HASH_BLAKE2S &&
+    return c && c->hash <= SS_HASH_BLAKE2S && c->flags <= SS_FLAG_NO_DEDUP &&
            stwo_cfg_ok(c->n_cols, c->trace_log, c->lde_log, c->n_queries, c->n_layers, c->mode);
 }
 static StwoLayout lay_of(const ss_stwo_cfg *c, size_t n)
 {
     return stwo_layout(c->n_cols, c->trace_log, c->lde_log, c->n_queries, c->n_layers, c->mode,
-                       c->pow_target, n);
+                       c->pow_target, n, !(c->flags & SS_FLAG_NO_DEDUP));
 }
 
 extern "C" size_t ss_stwo_record_words(const ss_stwo_cfg *c)
@@ -337,6 +341,12 @@ extern "C" int ss_stwo_verify_phase_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_
         hipLaunchKernelGGL(c->hash == SS_HASH_BLAKE2S ? stwo_merkle_kernel_b2s : stwo_merkle_kernel_sha,
                            dim3((tiles + 3) / 4), dim3(256), 0, s, y, batch, ws, status);
         t.end("stwo_merkle");
+        if (y.T) {
+            t.begin();
+            hipLaunchKernelGGL(c->hash == SS_HASH_BLAKE2S ? stwo_top_kernel_b2s : stwo_top_kernel_sha,
+                               dim3(y.top_blocks), dim3(kTopChains), 0, s, y, batch, ws, status);
+            t.end("stwo_top");
+        }
         t.begin();
         hipLaunchKernelGGL(stwo_finalize_kernel, dim3((y.n + 255) / 256), dim3(256), 0, s, y.n, status,
                            accept_count);
@@ -676,6 +686,204 @@ extern "C" int ss_s101_verify_records(ss_ctx *ctx, const ss_s101_shape *sh, size
     HIP_TRY(hipMemcpyAsync(status_host, hp.dev[3], n * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return SS_OK;
+}
+
+// ======================================================================= text ingestion
+extern "C" int ss_stwo_parse(const ss_stwo_cfg *c, const char *text, size_t len, int fmt, uint32_t *record_out)
+{
+    if (!cfg_ok(c)) return set_err(SS_ERR_ARG, "unsupported stwo config");
+    if (!text || !record_out || fmt < SS_TEXT_AUTO || fmt > SS_TEXT_WIT) return set_err(SS_ERR_ARG, "bad argument");
+    const ParseResult r = stwo_parse_text(*c, text, len, fmt, record_out);
+    if (r != kParsed) memset(record_out, 0, ss_stwo_record_words(c) * 4);
+    return r == kParsed ? 0 : r == kConfigMismatch ? (int)SS_STATUS_CONFIG_MISMATCH : (int)SS_STATUS_MALFORMED;
+}
+
+extern "C" int ss_s101_parse(const char *text, size_t len, int fmt, ss_s101_shape *shape, uint32_t *record_out)
+{
+    if (!text || !shape || fmt < SS_TEXT_AUTO || fmt > SS_TEXT_WIT) return set_err(SS_ERR_ARG, "bad argument");
+    S101Parsed *p = s101_parse_text(text, len, fmt);
+    if (!p) return (int)SS_STATUS_MALFORMED;
+    uint32_t nl, pm;
+    s101_parsed_shape(p, &nl, &pm);
+    if (record_out && shape_ok(shape) && nl <= shape->max_layers && pm <= shape->max_path)
+        s101_parsed_record(p, *shape, record_out);
+    else { shape->max_layers = nl; shape->max_path = pm; }
+    s101_parsed_free(p);
+    return 0;
+}
+
+static double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static bool read_file(const char *path, std::string &out)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return false;
+    out.clear();
+    char buf[1 << 16];
+    size_t k;
+    while ((k = fread(buf, 1, sizeof buf, f)) > 0) out.append(buf, k);
+    const bool ok = !ferror(f);
+    fclose(f);
+    return ok;
+}
+
+// texts (or files, read inside the worker threads) -> records in pinned staging -> GPU
+static int stwo_ingest(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *const *texts, const size_t *lens,
+                       const char *const *paths, int fmt, uint32_t *status_host, ss_ingest_stats *stats)
+{
+    if (!ctx || !status_host || (!texts && !paths) || (texts && !lens)) return set_err(SS_ERR_ARG, "null argument");
+    if (!cfg_ok(c)) return set_err(SS_ERR_ARG, "unsupported stwo config");
+    if (!n) return set_err(SS_ERR_ARG, "empty batch");
+    if (fmt < SS_TEXT_AUTO || fmt > SS_TEXT_WIT) return set_err(SS_ERR_ARG, "unknown text format");
+    if (n * (size_t)c->n_queries > 0x7fffffffu) return set_err(SS_ERR_ARG, "batch too large");
+    const double t0 = now_s();
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t W = ss_stwo_record_words(c), words = ss_stwo_batch_words(c, n);
+    const size_t wsb = ss_stwo_workspace_bytes(c, n);
+    int rc;
+    if ((rc = hp_reserve(ctx, 0, n * W * 4))) return rc;
+    if ((rc = hp_reserve(ctx, 1, words * 4))) return rc;
+    if ((rc = hp_reserve(ctx, 2, wsb))) return rc;
+    if ((rc = hp_reserve(ctx, 3, n * 4))) return rc;
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, (64u << 20) / (W * 4)));
+    if ((rc = hp_pinned(ctx, chunk * W * 4))) return rc;
+    HostPath &hp = ctx->hp;
+    hipStream_t s = hp.stream;
+    uint32_t *rec_dev = (uint32_t *)hp.dev[0];
+    const unsigned threads = effective_cpus();
+    std::vector<uint8_t> outcome(n, 0);
+    std::vector<uint64_t> tbytes(n, 0);
+    double parse_s = 0;
+    int buf = 0;
+    for (size_t lo = 0; lo < n; lo += chunk, buf ^= 1) {
+        const size_t cnt = std::min(chunk, n - lo);
+        HIP_TRY(hipEventSynchronize(hp.pinned_free[buf]));  // previous upload from this buffer done
+        uint32_t *stage = (uint32_t *)hp.pinned[buf];
+        const double tp = now_s();
+        parallel_for(cnt, [&](size_t i) {
+            uint32_t *dst = stage + i * W;
+            ParseResult r;
+            if (paths) {
+                std::string text;
+                r = read_file(paths[lo + i], text) ? stwo_parse_text(*c, text.data(), text.size(), fmt, dst) : kMalformed;
+                tbytes[lo + i] = text.size();
+            } else {
+                r = stwo_parse_text(*c, texts[lo + i], lens[lo + i], fmt, dst);
+                tbytes[lo + i] = lens[lo + i];
+            }
+            if (r != kParsed) memset(dst, 0, W * 4);
+            outcome[lo + i] = (uint8_t)r;
+        }, threads);
+        parse_s += now_s() - tp;
+        HIP_TRY(hipMemcpyAsync(rec_dev + lo * W, stage, cnt * W * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipEventRecord(hp.pinned_free[buf], s));
+    }
+    if ((rc = ss_stwo_pack_dev(ctx, c, n, rec_dev, (uint32_t *)hp.dev[1], s))) return rc;
+    rc = ss_stwo_verify_batch_dev(ctx, c, n, (const uint32_t *)hp.dev[1], hp.dev[2], wsb, (uint32_t *)hp.dev[3],
+                                  nullptr, s);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(status_host, hp.dev[3], n * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    uint64_t tb = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (outcome[i] == kMalformed) status_host[i] = SS_STATUS_MALFORMED;
+        else if (outcome[i] == kConfigMismatch) status_host[i] = SS_STATUS_CONFIG_MISMATCH;
+        tb += tbytes[i];
+    }
+    if (stats) {
+        stats->read_s = 0;  // files are read inside the parse workers
+        stats->parse_s = parse_s;
+        stats->total_s = now_s() - t0;
+        stats->text_bytes = tb;
+        stats->record_bytes = (uint64_t)n * W * 4;
+        stats->threads = threads;
+        stats->reserved = 0;
+    }
+    return SS_OK;
+}
+
+extern "C" int ss_stwo_verify_texts(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *const *texts,
+                                    const size_t *lens, int fmt, uint32_t *status_host, ss_ingest_stats *stats)
+{
+    return stwo_ingest(ctx, c, n, texts, lens, nullptr, fmt, status_host, stats);
+}
+
+extern "C" int ss_stwo_verify_files(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *const *paths, int fmt,
+                                    uint32_t *status_host, ss_ingest_stats *stats)
+{
+    return stwo_ingest(ctx, c, n, nullptr, nullptr, paths, fmt, status_host, stats);
+}
+
+// stark101: parse everything (the shape of the batch is the largest proof's), then records -> GPU
+static int s101_ingest(ss_ctx *ctx, size_t n, const char *const *texts, const size_t *lens, const char *const *paths,
+                       int fmt, uint32_t *status_host, ss_ingest_stats *stats)
+{
+    if (!ctx || !status_host || (!texts && !paths) || (texts && !lens)) return set_err(SS_ERR_ARG, "null argument");
+    if (!n) return set_err(SS_ERR_ARG, "empty batch");
+    if (fmt < SS_TEXT_AUTO || fmt > SS_TEXT_WIT) return set_err(SS_ERR_ARG, "unknown text format");
+    const double t0 = now_s();
+    const unsigned threads = effective_cpus();
+    std::vector<S101Parsed *> parsed(n, nullptr);
+    std::vector<uint64_t> tbytes(n, 0);
+    parallel_for(n, [&](size_t i) {
+        if (paths) {
+            std::string text;
+            if (read_file(paths[i], text)) parsed[i] = s101_parse_text(text.data(), text.size(), fmt);
+            tbytes[i] = text.size();
+        } else {
+            parsed[i] = s101_parse_text(texts[i], lens[i], fmt);
+            tbytes[i] = lens[i];
+        }
+    }, threads);
+    ss_s101_shape sh = {0, 0};
+    for (size_t i = 0; i < n; i++)
+        if (parsed[i]) {
+            uint32_t nl, pm;
+            s101_parsed_shape(parsed[i], &nl, &pm);
+            sh.max_layers = std::max(sh.max_layers, nl);
+            sh.max_path = std::max(sh.max_path, pm);
+        }
+    const size_t W = ss_s101_record_words(&sh);
+    std::vector<uint32_t> recs(n * W, 0);
+    std::vector<const uint32_t *> ptrs(n);
+    parallel_for(n, [&](size_t i) {
+        if (parsed[i]) s101_parsed_record(parsed[i], sh, recs.data() + i * W);
+        ptrs[i] = recs.data() + i * W;
+    }, threads);
+    const double parse_s = now_s() - t0;
+    int rc = ss_s101_verify_records(ctx, &sh, n, ptrs.data(), status_host);
+    uint64_t tb = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (!parsed[i]) status_host[i] = SS_STATUS_MALFORMED;
+        else s101_parsed_free(parsed[i]);
+        tb += tbytes[i];
+    }
+    if (rc) return rc;
+    if (stats) {
+        stats->read_s = 0;
+        stats->parse_s = parse_s;
+        stats->total_s = now_s() - t0;
+        stats->text_bytes = tb;
+        stats->record_bytes = (uint64_t)n * W * 4;
+        stats->threads = threads;
+        stats->reserved = 0;
+    }
+    return SS_OK;
+}
+
+extern "C" int ss_s101_verify_texts(ss_ctx *ctx, size_t n, const char *const *texts, const size_t *lens, int fmt,
+                                    uint32_t *status_host, ss_ingest_stats *stats)
+{
+    return s101_ingest(ctx, n, texts, lens, nullptr, fmt, status_host, stats);
+}
+
+extern "C" int ss_s101_verify_files(ss_ctx *ctx, size_t n, const char *const *paths, int fmt, uint32_t *status_host,
+                                    ss_ingest_stats *stats)
+{
+    return s101_ingest(ctx, n, nullptr, nullptr, paths, fmt, status_host, stats);
 }
 
 // =========================================================================== self-test

@@ -1,0 +1,837 @@
+// Text -> record: native readers of proof.json / proof.wit (see ss_ingest.h).
+//
+// One small tree parser serves both syntaxes: JSON (objects, arrays, unsigned integers of any
+// size up to 2^256, strings) and the SimplicityHL value literals inside a .wit (`( .. )` tuples,
+// `[ .. ]` arrays, `list![ .. ]`, decimal / 0x integers with `_` separators; "(x)" without a comma
+// is x itself -- generate_wit.py:8 wraps every FriLayer in a redundant pair of parentheses).
+// Every acceptance / rejection rule mirrors stark-symphony_amd/formats.py, which tests/test_ingest.py
+// holds this file against on the reference's own files, on random proofs and on malformed inputs.
+#include "ss_ingest.h"
+
+#include <sched.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "ss_layout.h"
+
+namespace ss {
+namespace {
+
+enum Kind : uint8_t { kInt, kBig, kList, kObj, kStr, kAlias, kOther };
+
+struct Node {
+    uint8_t kind = kOther, key_len = 0;
+    uint32_t val = 0;      // kInt: value; kBig: index into bigs; kList / kObj: children; kStr: text offset
+    uint32_t next = 0;     // next sibling (0 = last)
+    uint32_t key_off = 0;  // members of an object: their key
+    uint32_t len = 0;      // kStr: length
+};
+
+struct U256 { uint32_t w[8]; };  // w[0] most significant = word 0 of a stored hash
+
+struct Tree {
+    const char *text = nullptr;
+    std::vector<Node> nodes;
+    std::vector<U256> bigs;
+    bool ok = true;
+    uint32_t root = 0;  // accessors use index 0 for "absent": literal trees keep a dummy there
+
+    uint32_t push(Kind k)
+    {
+        nodes.emplace_back();
+        nodes.back().kind = k;
+        return (uint32_t)nodes.size() - 1;
+    }
+    uint32_t resolve(uint32_t i) const
+    {
+        while (nodes[i].kind == kAlias) i++;
+        return i;
+    }
+    bool is_list(uint32_t i) const { return nodes[i].kind == kList; }
+    uint32_t count(uint32_t i) const { return nodes[i].val; }
+    // k-th child of list / object i (resolved), 0 if absent (node 0 is the root, never a child)
+    uint32_t child(uint32_t i, uint32_t k) const
+    {
+        if ((nodes[i].kind != kList && nodes[i].kind != kObj) || k >= nodes[i].val) return 0;
+        uint32_t c = i + 1;
+        while (k--) c = nodes[c].next;
+        return resolve(c);
+    }
+    uint32_t member(uint32_t obj, const char *key) const
+    {
+        if (nodes[obj].kind != kObj) return 0;
+        const size_t kl = strlen(key);
+        uint32_t c = nodes[obj].val ? obj + 1 : 0;
+        while (c) {
+            if (nodes[c].key_len == kl && memcmp(text + nodes[c].key_off, key, kl) == 0) return resolve(c);
+            c = nodes[c].next;
+        }
+        return 0;
+    }
+};
+
+// ------------------------------------------------------------------------------ numbers
+// digits[0..n) decimal -> node.  Values below 2^32 are kInt, others kBig; >= 2^256 is an error.
+bool number_node(Tree &t, uint32_t idx, const char *digits, size_t n, int base)
+{
+    if (base == 10 && n <= 9) {  // bytes, field words below 10^9: most numbers of a proof.json
+        uint32_t v = 0;
+        for (size_t i = 0; i < n; i++) v = v * 10 + (uint32_t)(digits[i] - '0');
+        t.nodes[idx].kind = kInt;
+        t.nodes[idx].val = v;
+        return true;
+    }
+    uint32_t limb[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // little endian
+    if (base == 16) {
+        while (n && *digits == '0') { digits++; n--; }
+        if (n > 64) return false;
+        for (size_t i = 0; i < n; i++) {
+            const char ch = digits[n - 1 - i];
+            const uint32_t v = ch <= '9' ? ch - '0' : (ch | 0x20) - 'a' + 10;
+            limb[i / 8] |= v << (4 * (i % 8));
+        }
+    } else {
+        if (n > 78 + 16) {  // longer than any u256, allowing for leading zeros
+            while (n && *digits == '0') { digits++; n--; }
+            if (n > 78) return false;
+        }
+        size_t i = 0;
+        while (i < n) {
+            const size_t k = n - i < 9 ? n - i : 9;
+            uint32_t chunk = 0, mul = 1;
+            for (size_t j = 0; j < k; j++) { chunk = chunk * 10 + (uint32_t)(digits[i + j] - '0'); mul *= 10; }
+            uint64_t carry = chunk;
+            for (int l = 0; l < 8; l++) {
+                const uint64_t v = (uint64_t)limb[l] * mul + carry;
+                limb[l] = (uint32_t)v;
+                carry = v >> 32;
+            }
+            if (carry) return false;  // >= 2^256
+            i += k;
+        }
+    }
+    bool small = true;
+    for (int l = 1; l < 8; l++) small &= limb[l] == 0;
+    Node &nd = t.nodes[idx];
+    if (small) {
+        nd.kind = kInt;
+        nd.val = limb[0];
+    } else {
+        U256 b;
+        for (int l = 0; l < 8; l++) b.w[l] = limb[7 - l];
+        nd.kind = kBig;
+        nd.val = (uint32_t)t.bigs.size();
+        t.bigs.push_back(b);
+    }
+    return true;
+}
+
+constexpr int kMaxDepth = 48;
+
+// ------------------------------------------------------------------------------- JSON
+struct Json {
+    Tree &t;
+    const char *p, *end;
+    void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++; }
+    bool fail() { t.ok = false; return false; }
+
+    // a string body up to the closing quote; escapes are skipped over, never decoded (no key or
+    // literal of the formats contains one; a value with an escape simply matches nothing)
+    bool string(uint32_t &off, uint32_t &len)
+    {
+        p++;  // opening quote
+        const char *s = p;
+        while (p < end && *p != '"') {
+            if (*p == '\\') p++;
+            p++;
+        }
+        if (p >= end) return fail();
+        off = (uint32_t)(s - t.text);
+        len = (uint32_t)(p - s);
+        p++;
+        return true;
+    }
+
+    uint32_t value(int depth)
+    {
+        ws();
+        if (p >= end || depth > kMaxDepth) { fail(); return 0; }
+        const char ch = *p;
+        if (ch == '[' || ch == '{') {
+            const bool obj = ch == '{';
+            const uint32_t idx = t.push(obj ? kObj : kList);
+            p++;
+            uint32_t prev = 0, n = 0;
+            ws();
+            if (p < end && *p == (obj ? '}' : ']')) { p++; return idx; }
+            while (t.ok) {
+                uint32_t ko = 0, kl = 0;
+                if (obj) {
+                    ws();
+                    if (p >= end || *p != '"' || !string(ko, kl)) { fail(); break; }
+                    ws();
+                    if (p >= end || *p != ':') { fail(); break; }
+                    p++;
+                }
+                const uint32_t c = value(depth + 1);
+                if (!t.ok) break;
+                if (obj) {
+                    if (kl > 255) { fail(); break; }
+                    t.nodes[c].key_off = ko;
+                    t.nodes[c].key_len = (uint8_t)kl;
+                }
+                if (prev) t.nodes[prev].next = c;
+                prev = c;
+                n++;
+                ws();
+                if (p < end && *p == ',') { p++; continue; }
+                if (p < end && *p == (obj ? '}' : ']')) { p++; break; }
+                fail();
+            }
+            t.nodes[idx].val = n;
+            return idx;
+        }
+        if (ch == '"') {
+            const uint32_t idx = t.push(kStr);
+            uint32_t off = 0, len = 0;
+            if (!string(off, len)) return idx;
+            t.nodes[idx].val = off;
+            t.nodes[idx].len = len;
+            return idx;
+        }
+        if (ch >= '0' && ch <= '9') {
+            const char *s = p;
+            while (p < end && *p >= '0' && *p <= '9') p++;
+            const uint32_t idx = t.push(kOther);
+            if (p < end && (*p == '.' || *p == 'e' || *p == 'E')) {  // a float: never a witness word
+                while (p < end && (*p == '.' || *p == 'e' || *p == 'E' || *p == '+' || *p == '-' || (*p >= '0' && *p <= '9'))) p++;
+                return idx;
+            }
+            if (!number_node(t, idx, s, (size_t)(p - s), 10)) t.nodes[idx].kind = kOther;
+            return idx;
+        }
+        // true / false / null / negative numbers: syntactically fine, never a witness value
+        const uint32_t idx = t.push(kOther);
+        if (ch == '-' || (ch >= 'a' && ch <= 'z')) {
+            p++;
+            while (p < end && ((*p >= 'a' && *p <= 'z') || (*p >= '0' && *p <= '9') || *p == '.' || *p == 'e' || *p == 'E' || *p == '+' || *p == '-')) p++;
+            return idx;
+        }
+        fail();
+        return idx;
+    }
+};
+
+bool parse_json(Tree &t, const char *text, size_t len)
+{
+    t.text = text;
+    t.nodes.reserve(len / 4 + 16);
+    Json j{t, text, text + len};
+    j.value(0);
+    j.ws();
+    return t.ok && j.p == j.end;
+}
+
+// ------------------------------------------------------------------ SimplicityHL literal
+struct Literal {
+    Tree &t;
+    const char *p, *end;
+    void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++; }
+
+    uint32_t seq(char close, int depth)
+    {
+        const uint32_t idx = t.push(kList);
+        p++;  // opening bracket
+        uint32_t prev = 0, n = 0, commas = 0;
+        while (t.ok) {
+            ws();
+            if (p >= end) { t.ok = false; break; }
+            if (*p == close) {
+                p++;
+                if (close == ')' && n == 1 && commas == 0) t.nodes[idx].kind = kAlias;  // "(x)" is x
+                break;
+            }
+            const uint32_t c = value(depth + 1);
+            if (!t.ok) break;
+            if (prev) t.nodes[prev].next = c;
+            prev = c;
+            n++;
+            ws();
+            if (p < end && *p == ',') { p++; commas++; }
+        }
+        if (t.nodes[idx].kind == kList) t.nodes[idx].val = n;
+        return idx;
+    }
+
+    uint32_t value(int depth)
+    {
+        ws();
+        if (p >= end || depth > kMaxDepth) { t.ok = false; return 0; }
+        if (end - p >= 5 && memcmp(p, "list!", 5) == 0) {
+            p += 5;
+            ws();
+            if (p >= end || *p != '[') { t.ok = false; return 0; }
+            return seq(']', depth);
+        }
+        if (*p == '(') return seq(')', depth);
+        if (*p == '[') return seq(']', depth);
+        const uint32_t idx = t.push(kOther);
+        std::string digits;  // '_' separators removed; short for every value of the formats
+        int base = 10;
+        if (end - p >= 2 && p[0] == '0' && (p[1] == 'x' || p[1] == 'X')) {
+            base = 16;
+            p += 2;
+            while (p < end && ((*p >= '0' && *p <= '9') || ((*p | 0x20) >= 'a' && (*p | 0x20) <= 'f') || *p == '_')) {
+                if (*p != '_') digits.push_back(*p);
+                p++;
+            }
+        } else {
+            while (p < end && ((*p >= '0' && *p <= '9') || *p == '_')) {
+                if (*p != '_') digits.push_back(*p);
+                p++;
+            }
+        }
+        if (digits.empty()) { t.ok = false; return idx; }
+        if (!number_node(t, idx, digits.data(), digits.size(), base)) t.nodes[idx].kind = kOther;
+        return idx;
+    }
+};
+
+// the literal inside {"NAME": {"value": "<literal>", ...}} of a .wit, parsed into its own tree
+bool wit_member(const Tree &j, const char *name, Tree &out)
+{
+    const uint32_t m = j.member(0, name);
+    if (!m) return false;
+    const uint32_t v = j.member(m, "value");
+    if (!v || j.nodes[v].kind != kStr) return false;
+    const char *s = j.text + j.nodes[v].val;
+    const size_t n = j.nodes[v].len;
+    if (memchr(s, '\\', n)) return false;
+    out.text = s;
+    out.nodes.reserve(n / 8 + 16);
+    out.push(kOther);
+    out.root = 1;
+    Literal l{out, s, s + n};
+    l.value(0);
+    l.ws();
+    return out.ok && l.p == l.end;
+}
+
+// --------------------------------------------------------------------------- accessors
+bool get_u32(const Tree &t, uint32_t i, uint32_t &out)
+{
+    if (!i || t.nodes[i].kind != kInt) return false;
+    out = t.nodes[i].val;
+    return true;
+}
+
+bool get_u64(const Tree &t, uint32_t i, uint64_t &out)
+{
+    if (!i) return false;
+    if (t.nodes[i].kind == kInt) { out = t.nodes[i].val; return true; }
+    if (t.nodes[i].kind != kBig) return false;
+    const U256 &b = t.bigs[t.nodes[i].val];
+    for (int k = 0; k < 6; k++)
+        if (b.w[k]) return false;
+    out = ((uint64_t)b.w[6] << 32) | b.w[7];
+    return true;
+}
+
+// a u256 integer, or a list of 32 byte values -> 8 stored hash words
+bool get_hash(const Tree &t, uint32_t i, uint32_t *out)
+{
+    if (!i) return false;
+    const Node &nd = t.nodes[i];
+    if (nd.kind == kInt) {
+        for (int k = 0; k < 7; k++) out[k] = 0;
+        out[7] = nd.val;
+        return true;
+    }
+    if (nd.kind == kBig) {
+        memcpy(out, t.bigs[nd.val].w, 32);
+        return true;
+    }
+    if (nd.kind != kList || nd.val != 32) return false;
+    uint32_t c = i + 1;
+    for (int k = 0; k < 8; k++) {
+        uint32_t w = 0;
+        for (int b = 0; b < 4; b++) {
+            const Node &x = t.nodes[t.resolve(c)];
+            if (x.kind != kInt || x.val > 255) return false;
+            w = (w << 8) | x.val;
+            c = t.nodes[c].next;
+        }
+        out[k] = w;
+    }
+    return true;
+}
+
+// formats._qm31: single-element lists around the value are peeled off, then ((a, b), (c, d))
+bool get_qm31(const Tree &t, uint32_t i, uint32_t *out)
+{
+    if (!i) return false;
+    while (t.is_list(i) && t.count(i) == 1 && t.is_list(t.child(i, 0))) i = t.child(i, 0);
+    if (!t.is_list(i) || t.count(i) != 2) return false;
+    for (uint32_t h = 0; h < 2; h++) {
+        const uint32_t pr = t.child(i, h);
+        if (!pr || !t.is_list(pr) || t.count(pr) != 2) return false;
+        if (!get_u32(t, t.child(pr, 0), out[2 * h]) || !get_u32(t, t.child(pr, 1), out[2 * h + 1])) return false;
+    }
+    return true;
+}
+
+// nodes [first, first + count) of list `lst` as one Merkle path: at most 31 siblings (List<u256, 32>),
+// the first `slot` of them stored, the real length reported
+bool get_path(const Tree &t, uint32_t lst, uint32_t first, uint32_t count, uint32_t slot, uint32_t *dst,
+              uint32_t &plen)
+{
+    if (count > kMaxList) return false;
+    uint32_t c = lst + 1;
+    for (uint32_t k = 0; k < first; k++) c = t.nodes[c].next;
+    for (uint32_t k = 0; k < count; k++) {
+        uint32_t h[8];
+        if (!get_hash(t, t.resolve(c), h)) return false;
+        if (k < slot) memcpy(dst + 8 * k, h, 32);
+        c = t.nodes[c].next;
+    }
+    plen = count;
+    return true;
+}
+
+uint64_t pow_target_of_bits(uint32_t bits) { return bits == 0 ? ~(uint64_t)0 : (((uint64_t)1 << (64 - bits)) - 1); }
+
+// word offsets of a record's sections (include/ss_verify.h)
+struct RecordMap {
+    uint32_t N, L, Q, K;
+    uint32_t head, qstride, fbase, tbase, words;
+    uint32_t foff[kMaxList + 1];
+    explicit RecordMap(const ss_stwo_cfg &c) : N(c.n_cols), L(c.lde_log), Q(c.n_queries), K(c.n_layers)
+    {
+        head = 24 + 4 * N + 64 + 8 * (K + 1) + 4 + 2;
+        qstride = N + kCp + 16 * L;
+        fbase = head + Q * qstride;
+        uint32_t o = 0;
+        for (uint32_t l = 0; l <= K; l++) { foff[l] = o; o += Q * (4 + 8 * (L - 1 - l)); }
+        tbase = fbase + o;
+        words = tbase + (K + 3) * Q;
+    }
+    uint32_t *trace_vals(uint32_t *r, uint32_t q) const { return r + head + q * qstride; }
+    uint32_t *cp_vals(uint32_t *r, uint32_t q) const { return trace_vals(r, q) + N; }
+    uint32_t *trace_path(uint32_t *r, uint32_t q) const { return cp_vals(r, q) + kCp; }
+    uint32_t *cp_path(uint32_t *r, uint32_t q) const { return trace_path(r, q) + 8 * L; }
+    uint32_t *fri_wit(uint32_t *r, uint32_t l, uint32_t q) const { return r + fbase + foff[l] + q * (4 + 8 * (L - 1 - l)); }
+    uint32_t &plen(uint32_t *r, uint32_t kind, uint32_t q) const { return r[tbase + kind * Q + q]; }
+};
+
+// ---------------------------------------------------------------- stwo, format C (proof.json)
+// formats.stwo_from_json, with the expected config given (`expect=`): what the JSON does not
+// declare is the verifier's; what it declares, and every array length, must agree with it.
+ParseResult stwo_from_json(const ss_stwo_cfg &cfg, const Tree &t, uint32_t *rec)
+{
+    const RecordMap m(cfg);
+    if (t.nodes.empty() || t.nodes[0].kind != kObj) return kMalformed;
+    bool mismatch = false;
+    // ---- declared parameters
+    const uint32_t conf = t.member(0, "config");
+    const uint32_t fconf = conf ? t.member(conf, "fri_config") : 0;
+    uint32_t Q = cfg.n_queries, v;
+    if (conf && t.nodes[conf].kind != kObj) return kMalformed;
+    if (fconf && t.nodes[fconf].kind != kObj) return kMalformed;
+    if (uint32_t x = fconf ? t.member(fconf, "n_queries") : 0) {
+        if (!get_u32(t, x, Q)) return kMalformed;
+    }
+    if (uint32_t x = conf ? t.member(conf, "pow_bits") : 0) {
+        if (!get_u32(t, x, v)) return kMalformed;
+        mismatch |= v > 64 || pow_target_of_bits(v) != cfg.pow_target;  // > 64 bits: no verifier's config
+    }
+    if (uint32_t x = conf ? t.member(conf, "hash") : 0) {
+        const Node &s = t.nodes[x];
+        if (s.kind != kStr) return kMalformed;
+        const bool sha = s.len == 6 && memcmp(t.text + s.val, "sha256", 6) == 0;
+        const bool b2s = s.len == 7 && memcmp(t.text + s.val, "blake2s", 7) == 0;
+        if (!sha && !b2s) return kMalformed;
+        mismatch |= (b2s ? SS_HASH_BLAKE2S : SS_HASH_SHA256) != cfg.hash;
+    }
+    if (Q == 0) return kMalformed;  // formats._split: n <= 0
+    mismatch |= Q != cfg.n_queries;
+    // ---- commitments
+    const uint32_t com = t.member(0, "commitments");
+    if (!com || !t.is_list(com) || t.count(com) != 3) return kMalformed;
+    uint32_t roots[24];
+    for (uint32_t k = 0; k < 3; k++) {
+        const uint32_t c = t.child(com, k);
+        if (!t.is_list(c) || !get_hash(t, c, roots + 8 * k)) return kMalformed;
+    }
+    // ---- sampled values
+    const uint32_t sv = t.member(0, "sampled_values");
+    const uint32_t sv1 = sv ? t.child(sv, 1) : 0, sv2 = sv ? t.child(sv, 2) : 0;
+    if (!sv1 || !sv2 || !t.is_list(sv1) || !t.is_list(sv2) || t.count(sv2) != kCp) return kMalformed;
+    const uint32_t N = t.count(sv1);
+    mismatch |= N != cfg.n_cols;
+    // ---- decommitments and queried values: concatenated over the queries, split equally
+    const uint32_t dec = t.member(0, "decommitments"), qv = t.member(0, "queried_values");
+    const uint32_t d1 = dec ? t.child(dec, 1) : 0, d2 = dec ? t.child(dec, 2) : 0;
+    const uint32_t hw1 = d1 ? t.member(d1, "hash_witness") : 0, hw2 = d2 ? t.member(d2, "hash_witness") : 0;
+    const uint32_t qv1 = qv ? t.child(qv, 1) : 0, qv2 = qv ? t.child(qv, 2) : 0;
+    if (!hw1 || !hw2 || !qv1 || !qv2 || !t.is_list(hw1) || !t.is_list(hw2) || !t.is_list(qv1) || !t.is_list(qv2))
+        return kMalformed;
+    if (t.count(hw1) % Q || t.count(hw2) % Q || t.count(qv1) % Q || t.count(qv2) % Q) return kMalformed;
+    const uint32_t tlen = t.count(hw1) / Q, clen = t.count(hw2) / Q;
+    if (tlen > kMaxList || clen > kMaxList) return kMalformed;
+    if (t.count(qv1) != Q * N || t.count(qv2) != Q * kCp) return kMalformed;
+    mismatch |= tlen != cfg.lde_log;  // LDE_LOG_SIZE is the length of the first trace path
+    // ---- FRI
+    const uint32_t fri = t.member(0, "fri_proof");
+    const uint32_t first = fri ? t.member(fri, "first_layer") : 0;
+    if (!fri || !first) return kMalformed;
+    const uint32_t inner = t.member(fri, "inner_layers");
+    if (inner && !t.is_list(inner)) return kMalformed;
+    const uint32_t K = inner ? t.count(inner) : 0;
+    if (K > kMaxList) return kMalformed;
+    mismatch |= K != cfg.n_layers;
+    const uint32_t llp = t.member(fri, "last_layer_poly");
+    const uint32_t coeffs = llp ? t.member(llp, "coeffs") : 0;
+    if (!coeffs || !t.is_list(coeffs) || t.count(coeffs) != 1) return kMalformed;
+    // ---- trace_log = lde_log - declared blow-up
+    if (uint32_t x = fconf ? t.member(fconf, "log_blowup_factor") : 0) {
+        if (!get_u32(t, x, v)) return kMalformed;
+        mismatch |= (int64_t)tlen - (int64_t)v != (int64_t)cfg.trace_log;
+    }
+    uint64_t nonce = 0;
+    if (uint32_t x = t.member(0, "proof_of_work")) {
+        if (!get_u64(t, x, nonce)) return kMalformed;
+    }
+    // Everything below is validated even when the shape already mismatches, so that a proof that is
+    // malformed AND of another shape is reported as malformed, as the Python reader does (it parses
+    // completely before the policy looks at the config).  The record is written only on a match.
+    std::vector<uint32_t> scratch;
+    uint32_t *r = rec;
+    if (mismatch) {  // validate into a scratch record of the proof's own shape? no: validate without storing
+        r = nullptr;
+    }
+    uint32_t tmp[8 * kMaxList];
+    auto store = [&](uint32_t *dst, const uint32_t *src, size_t words) {
+        if (r) memcpy(dst, src, words * 4);
+    };
+    if (r) {
+        memset(r, 0, (size_t)m.words * 4);
+        store(r, roots, 24);
+    }
+    for (uint32_t k = 0; k < N; k++) {
+        if (!get_qm31(t, t.child(sv1, k), tmp)) return kMalformed;
+        if (r) store(r + 24 + 4 * k, tmp, 4);
+    }
+    for (uint32_t k = 0; k < kCp; k++) {
+        if (!get_qm31(t, t.child(sv2, k), tmp)) return kMalformed;
+        if (r) store(r + 24 + 4 * m.N + 4 * k, tmp, 4);
+    }
+    // queried values: walk the two flat lists once
+    {
+        uint32_t c1 = t.count(qv1) ? qv1 + 1 : 0, c2 = t.count(qv2) ? qv2 + 1 : 0;
+        for (uint32_t q = 0; q < Q; q++) {
+            for (uint32_t k = 0; k < N; k++) {
+                if (!get_u32(t, t.resolve(c1), v)) return kMalformed;
+                if (r) m.trace_vals(r, q)[k] = v;
+                c1 = t.nodes[c1].next;
+            }
+            for (uint32_t k = 0; k < kCp; k++) {
+                if (!get_u32(t, t.resolve(c2), v)) return kMalformed;
+                if (r) m.cp_vals(r, q)[k] = v;
+                c2 = t.nodes[c2].next;
+            }
+        }
+    }
+    auto paths = [&](uint32_t hw, uint32_t len, uint32_t slot, auto dst_of, uint32_t kind) -> bool {
+        uint32_t c = t.count(hw) ? hw + 1 : 0;
+        for (uint32_t q = 0; q < Q; q++) {
+            for (uint32_t k = 0; k < len; k++) {
+                uint32_t h[8];
+                if (!get_hash(t, t.resolve(c), h)) return false;
+                if (r && k < slot) memcpy(dst_of(q) + 8 * k, h, 32);
+                c = t.nodes[c].next;
+            }
+            if (r) m.plen(r, kind, q) = len;
+        }
+        return true;
+    };
+    if (!paths(hw1, tlen, m.L, [&](uint32_t q) { return m.trace_path(r, q); }, 0)) return kMalformed;
+    if (!paths(hw2, clen, m.L, [&](uint32_t q) { return m.cp_path(r, q); }, 1)) return kMalformed;
+    for (uint32_t l = 0; l <= K; l++) {
+        const uint32_t layer = l == 0 ? first : t.child(inner, l - 1);
+        if (!layer || t.nodes[layer].kind != kObj) return kMalformed;
+        const uint32_t w = t.member(layer, "fri_witness"), d = t.member(layer, "decommitment");
+        const uint32_t hw = d ? t.member(d, "hash_witness") : 0, cm = t.member(layer, "commitment");
+        if (!w || !hw || !cm || !t.is_list(w) || !t.is_list(hw) || t.count(w) != Q || t.count(hw) % Q) return kMalformed;
+        uint32_t h[8];
+        if (!t.is_list(cm) || !get_hash(t, cm, h)) return kMalformed;
+        const bool keep = r && l <= m.K;
+        if (keep) memcpy(r + 24 + 4 * m.N + 64 + 8 * l, h, 32);
+        const uint32_t len = t.count(hw) / Q;
+        if (len > kMaxList) return kMalformed;
+        uint32_t cw = w + 1, ch = t.count(hw) ? hw + 1 : 0;
+        for (uint32_t q = 0; q < Q; q++) {
+            if (!get_qm31(t, t.resolve(cw), tmp)) return kMalformed;
+            cw = t.nodes[cw].next;
+            uint32_t *dst = keep ? m.fri_wit(r, l, q) : nullptr;
+            if (dst) memcpy(dst, tmp, 16);
+            const uint32_t slot = keep ? m.L - 1 - l : 0;
+            for (uint32_t k = 0; k < len; k++) {
+                if (!get_hash(t, t.resolve(ch), h)) return kMalformed;
+                if (dst && k < slot) memcpy(dst + 4 + 8 * k, h, 32);
+                ch = t.nodes[ch].next;
+            }
+            if (keep) m.plen(r, 2 + l, q) = len;
+        }
+    }
+    if (!get_qm31(t, t.child(coeffs, 0), tmp)) return kMalformed;
+    if (mismatch) return kConfigMismatch;
+    memcpy(r + 24 + 4 * m.N + 64 + 8 * (m.K + 1), tmp, 16);
+    r[m.head - 2] = (uint32_t)(nonce >> 32);
+    r[m.head - 1] = (uint32_t)nonce;
+    return kParsed;
+}
+
+// ------------------------------------------------------------------ stwo, format D (proof.wit)
+// formats.stwo_from_wit / _stwo_from_parts: six literals; a .wit declares nothing, so TRACE_LOG_SIZE,
+// the PoW target and the hash are the verifier's and only the shape is compared.
+ParseResult stwo_from_wit(const ss_stwo_cfg &cfg, const Tree &j, uint32_t *rec)
+{
+    const RecordMap m(cfg);
+    if (j.nodes.empty() || j.nodes[0].kind != kObj) return kMalformed;
+    Tree com, dec, oods, fric, frid, non;
+    if (!wit_member(j, "COMMITMENTS", com) || !wit_member(j, "DECOMMITMENTS", dec) ||
+        !wit_member(j, "OODS_EVALS", oods) || !wit_member(j, "FRI_COMMITMENTS", fric) ||
+        !wit_member(j, "FRI_DECOMMITMENTS", frid) || !wit_member(j, "POW_NONCE", non))
+        return kMalformed;
+    const uint32_t c0 = com.resolve(com.root), d0 = dec.resolve(dec.root), o0 = oods.resolve(oods.root), fc0 = fric.resolve(fric.root),
+                   fd0 = frid.resolve(frid.root);
+    if (!com.is_list(c0) || com.count(c0) != 3 || !dec.is_list(d0)) return kMalformed;
+    const uint32_t Q = dec.count(d0);
+    const uint32_t ot = oods.child(o0, 0), oc = oods.child(o0, 1);
+    if (!ot || !oc || !oods.is_list(ot) || !oods.is_list(oc) || oods.count(oc) != kCp) return kMalformed;
+    const uint32_t N = oods.count(ot);
+    const uint32_t fd_first = frid.child(fd0, 0), fd_inner = frid.child(fd0, 1);
+    if (!fd_first || !fd_inner || !frid.is_list(fd_first) || !frid.is_list(fd_inner)) return kMalformed;
+    const uint32_t K = frid.count(fd_inner);
+    const uint32_t fc_inner = fric.child(fc0, 1);
+    if (!fric.child(fc0, 0) || !fc_inner || !fric.is_list(fc_inner) || fric.count(fc_inner) != K || !fric.child(fc0, 2))
+        return kMalformed;
+    if (K > kMaxList) return kMalformed;
+    bool mismatch = Q != cfg.n_queries || N != cfg.n_cols || K != cfg.n_layers;
+    uint32_t *r = nullptr;
+    uint32_t tmp[8 * kMaxList], v, pl;
+    if (!mismatch) {
+        r = rec;
+        memset(r, 0, (size_t)m.words * 4);
+    }
+    for (uint32_t k = 0; k < 3; k++) {
+        const uint32_t c = com.child(c0, k);
+        if (com.is_list(c) || !get_hash(com, c, tmp)) return kMalformed;  // u256 integers here
+        if (r) memcpy(r + 8 * k, tmp, 32);
+    }
+    for (uint32_t k = 0; k < N; k++) {  // each column is an array of its MAX_COLUMN_OFFSET = 1 samples
+        const uint32_t col = oods.child(ot, k);
+        if (!col || !oods.is_list(col) || oods.count(col) < 1 || !get_qm31(oods, oods.child(col, 0), tmp)) return kMalformed;
+        if (r) memcpy(r + 24 + 4 * k, tmp, 16);
+    }
+    for (uint32_t k = 0; k < kCp; k++) {
+        if (!get_qm31(oods, oods.child(oc, k), tmp)) return kMalformed;
+        if (r) memcpy(r + 24 + 4 * m.N + 4 * k, tmp, 16);
+    }
+    uint32_t lde_log = 0;
+    for (uint32_t q = 0; q < Q; q++) {
+        const uint32_t d = dec.child(d0, q);
+        const uint32_t tpart = d ? dec.child(d, 0) : 0, cpart = d ? dec.child(d, 1) : 0;
+        const uint32_t tv = tpart ? dec.child(tpart, 0) : 0, tp = tpart ? dec.child(tpart, 1) : 0;
+        const uint32_t cv = cpart ? dec.child(cpart, 0) : 0, cp = cpart ? dec.child(cpart, 1) : 0;
+        if (!tv || !tp || !cv || !cp || !dec.is_list(tv) || !dec.is_list(tp) || !dec.is_list(cv) || !dec.is_list(cp))
+            return kMalformed;
+        if (dec.count(tv) != N || dec.count(cv) != kCp) return kMalformed;
+        for (uint32_t k = 0; k < N; k++) {
+            const uint32_t col = dec.child(tv, k);
+            if (!col || !dec.is_list(col) || dec.count(col) < 1 || !get_u32(dec, dec.child(col, 0), v)) return kMalformed;
+            if (r) m.trace_vals(r, q)[k] = v;
+        }
+        for (uint32_t k = 0; k < kCp; k++) {
+            if (!get_u32(dec, dec.child(cv, k), v)) return kMalformed;
+            if (r) m.cp_vals(r, q)[k] = v;
+        }
+        if (!get_path(dec, tp, 0, dec.count(tp), m.L, tmp, pl)) return kMalformed;
+        if (q == 0) {
+            lde_log = pl;
+            if (lde_log != cfg.lde_log) { mismatch = true; r = nullptr; }
+        }
+        if (r) { memcpy(m.trace_path(r, q), tmp, (size_t)(pl < m.L ? pl : m.L) * 32); m.plen(r, 0, q) = pl; }
+        if (!get_path(dec, cp, 0, dec.count(cp), m.L, tmp, pl)) return kMalformed;
+        if (r) { memcpy(m.cp_path(r, q), tmp, (size_t)(pl < m.L ? pl : m.L) * 32); m.plen(r, 1, q) = pl; }
+    }
+    for (uint32_t l = 0; l <= K; l++) {
+        const uint32_t root = l == 0 ? fric.child(fc0, 0) : fric.child(fc_inner, l - 1);
+        if (fric.is_list(root) || !get_hash(fric, root, tmp)) return kMalformed;
+        const bool keep = r && l <= m.K;
+        if (keep) memcpy(r + 24 + 4 * m.N + 64 + 8 * l, tmp, 32);
+        const uint32_t layer = l == 0 ? fd_first : frid.child(fd_inner, l - 1);
+        if (!layer || !frid.is_list(layer) || frid.count(layer) != Q) return kMalformed;
+        for (uint32_t q = 0; q < Q; q++) {
+            const uint32_t x = frid.child(layer, q);
+            const uint32_t w = x ? frid.child(x, 0) : 0, pth = x ? frid.child(x, 1) : 0;
+            if (!w || !pth || !frid.is_list(pth) || !get_qm31(frid, w, tmp)) return kMalformed;
+            uint32_t *dst = keep ? m.fri_wit(r, l, q) : nullptr;
+            if (dst) memcpy(dst, tmp, 16);
+            const uint32_t slot = keep ? m.L - 1 - l : 0;
+            if (!get_path(frid, pth, 0, frid.count(pth), slot, tmp, pl)) return kMalformed;
+            if (dst) { memcpy(dst + 4, tmp, (size_t)(pl < slot ? pl : slot) * 32); m.plen(r, 2 + l, q) = pl; }
+        }
+    }
+    if (!get_qm31(fric, fric.child(fc0, 2), tmp)) return kMalformed;
+    uint64_t nonce;
+    if (!get_u64(non, non.resolve(non.root), nonce)) return kMalformed;
+    if (mismatch || Q == 0) return kConfigMismatch;
+    memcpy(r + 24 + 4 * m.N + 64 + 8 * (m.K + 1), tmp, 16);
+    r[m.head - 2] = (uint32_t)(nonce >> 32);
+    r[m.head - 1] = (uint32_t)nonce;
+    return kParsed;
+}
+
+}  // namespace
+
+ParseResult stwo_parse_text(const ss_stwo_cfg &cfg, const char *text, size_t len, int fmt, uint32_t *record)
+{
+    Tree j;
+    if (!parse_json(j, text, len) || j.nodes.empty() || j.nodes[0].kind != kObj) return kMalformed;
+    if (fmt == SS_TEXT_AUTO) fmt = j.member(0, "COMMITMENTS") ? SS_TEXT_WIT : SS_TEXT_JSON;
+    return fmt == SS_TEXT_WIT ? stwo_from_wit(cfg, j, record) : stwo_from_json(cfg, j, record);
+}
+
+// ============================================================================= stark101
+struct S101Chain {
+    uint32_t ev = 0;
+    std::vector<uint32_t> path;  // 8 words per sibling
+};
+struct S101Layer {
+    uint32_t root[8], beta;
+    S101Chain cpa, cpb;
+};
+struct S101Parsed {
+    uint32_t root[8], last;
+    S101Chain evals[3];
+    std::vector<S101Layer> layers;
+};
+
+namespace {
+
+bool s101_chain(const Tree &t, uint32_t ev, uint32_t path, S101Chain &out)
+{
+    if (!ev || !path || !get_u32(t, ev, out.ev) || !t.is_list(path) || t.count(path) > kMaxList) return false;
+    out.path.resize((size_t)t.count(path) * 8);
+    uint32_t pl;
+    return get_path(t, path, 0, t.count(path), kMaxList, out.path.data(), pl);
+}
+
+// formats._s101_from_parts on (root, evals, layers, last) nodes of possibly different trees
+bool s101_from_parts(const Tree &tr, uint32_t root, const Tree &te, uint32_t evals, const Tree &tl, uint32_t layers,
+                     const Tree &tz, uint32_t last, S101Parsed &out)
+{
+    if (tr.is_list(root) || !get_hash(tr, root, out.root)) return false;
+    if (!te.is_list(evals) || te.count(evals) != 3 || !tl.is_list(layers) || tl.count(layers) > kMaxList) return false;
+    for (uint32_t k = 0; k < 3; k++) {
+        const uint32_t e = te.child(evals, k);
+        if (!e || !s101_chain(te, te.child(e, 0), te.child(e, 1), out.evals[k])) return false;
+    }
+    out.layers.resize(tl.count(layers));
+    for (uint32_t i = 0; i < out.layers.size(); i++) {
+        const uint32_t l = tl.child(layers, i);
+        if (!l || !tl.is_list(l) || tl.count(l) != 6) return false;
+        S101Layer &y = out.layers[i];
+        const uint32_t rt = tl.child(l, 0);
+        if (tl.is_list(rt) || !get_hash(tl, rt, y.root) || !get_u32(tl, tl.child(l, 1), y.beta)) return false;
+        if (!s101_chain(tl, tl.child(l, 2), tl.child(l, 3), y.cpa) || !s101_chain(tl, tl.child(l, 4), tl.child(l, 5), y.cpb))
+            return false;
+    }
+    return get_u32(tz, last, out.last);
+}
+
+}  // namespace
+
+S101Parsed *s101_parse_text(const char *text, size_t len, int fmt)
+{
+    Tree j;
+    if (!parse_json(j, text, len) || j.nodes.empty() || j.nodes[0].kind != kObj) return nullptr;
+    if (fmt == SS_TEXT_AUTO) fmt = j.member(0, "P_MT_ROOT") ? SS_TEXT_WIT : SS_TEXT_JSON;
+    S101Parsed *p = new S101Parsed();
+    bool ok;
+    if (fmt == SS_TEXT_WIT) {
+        Tree a, b, c, d;
+        ok = wit_member(j, "P_MT_ROOT", a) && wit_member(j, "P_EVALS", b) && wit_member(j, "FRI_LAYERS", c) &&
+             wit_member(j, "FRI_LAST_LAYER", d) &&
+             s101_from_parts(a, a.resolve(a.root), b, b.resolve(b.root), c, c.resolve(c.root), d, d.resolve(d.root), *p);
+    } else {
+        const uint32_t a = j.member(0, "p_mt_root"), b = j.member(0, "evals"), c = j.member(0, "fri_layers"),
+                       d = j.member(0, "fri_last_layer");
+        ok = a && b && c && d && s101_from_parts(j, a, j, b, j, c, j, d, *p);
+    }
+    if (!ok) { delete p; return nullptr; }
+    return p;
+}
+
+void s101_parsed_shape(const S101Parsed *p, uint32_t *n_layers, uint32_t *max_path)
+{
+    size_t pm = 0;
+    for (const auto &e : p->evals) pm = e.path.size() / 8 > pm ? e.path.size() / 8 : pm;
+    for (const auto &l : p->layers) {
+        pm = l.cpa.path.size() / 8 > pm ? l.cpa.path.size() / 8 : pm;
+        pm = l.cpb.path.size() / 8 > pm ? l.cpb.path.size() / 8 : pm;
+    }
+    *n_layers = (uint32_t)p->layers.size();
+    *max_path = (uint32_t)pm;
+}
+
+void s101_parsed_record(const S101Parsed *p, const ss_s101_shape &sh, uint32_t *r)
+{
+    const uint32_t ML = sh.max_layers, PM = sh.max_path;
+    memset(r, 0, (size_t)s101_record_words(ML, PM) * 4);
+    memcpy(r, p->root, 32);
+    r[8] = (uint32_t)p->layers.size();
+    r[9] = p->last;
+    uint32_t *o = r + 10;
+    auto chain = [&](const S101Chain &c) {
+        o[0] = c.ev;
+        o[1] = (uint32_t)(c.path.size() / 8);
+        memcpy(o + 2, c.path.data(), c.path.size() * 4);
+        o += 2 + 8 * PM;
+    };
+    for (const auto &e : p->evals) chain(e);
+    for (uint32_t i = 0; i < ML && i < p->layers.size(); i++) {
+        memcpy(o, p->layers[i].root, 32);
+        o[8] = p->layers[i].beta;
+        o += 9;
+        chain(p->layers[i].cpa);
+        chain(p->layers[i].cpb);
+    }
+}
+
+void s101_parsed_free(S101Parsed *p) { delete p; }
+
+unsigned effective_cpus()
+{
+    unsigned n = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = (unsigned)CPU_COUNT(&set);
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota> <period>" or "max <period>"
+        char quota[32];
+        long period = 0;
+        if (fscanf(f, "%31s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0) {
+            const long q = atol(quota);
+            const unsigned cores = (unsigned)((q + period - 1) / period);
+            if (cores >= 1 && cores < n) n = cores;
+        }
+        fclose(f);
+    }
+    return n ? n : 1;
+}
+
+}  // namespace ss

@@ -51,7 +51,24 @@ struct StwoLayout {
     uint32_t c_queries, c_p, c_p2, c_b01, c_b02, c_a1, c_c1, c_a2, c_c2, c_m1, c_fold, ctx_words;
     uint32_t n_pow;  // DEEP alpha powers kept per proof
     uint64_t ws_ctx, ws_alpha, ws_leaf, ws_total_words;
+    // Merkle pair memoisation (stwo_top_kernel): the top T levels of every tree are hashed once per
+    // distinct (left, right) pair of a proof instead of once per query.  T = 0 switches it off.
+    uint32_t T;           // levels below the root handled by the top kernel (per tree: min(T, len))
+    uint32_t top_G;       // proofs per top-kernel group: top_G * Q <= kTopChains chains
+    uint32_t top_blocks;  // persistent blocks of the top kernel (each owns a slice of ws_vals)
+    uint64_t ws_top;      // top[type][inst][8]: node of every chain at depth min(T, len), native words
+    uint64_t ws_vals;     // vals[block][parity][type][slot][8]: nodes of the distinct pairs, two depths
 };
+
+constexpr uint32_t kTopChains = 256;     // chains a top-kernel block plans at once (= its threads)
+constexpr uint32_t kTopMaxBlocks = 1024;
+
+SS_HD inline uint32_t ceil_log2(uint32_t v)
+{
+    uint32_t r = 0;
+    while (r < 31 && (1u << r) < v) r++;
+    return r;
+}
 
 SS_HD inline bool stwo_cfg_ok(uint32_t N, uint32_t TL, uint32_t L, uint32_t Q, uint32_t K, uint32_t mode)
 {
@@ -60,7 +77,7 @@ SS_HD inline bool stwo_cfg_ok(uint32_t N, uint32_t TL, uint32_t L, uint32_t Q, u
 }
 
 SS_HD inline StwoLayout stwo_layout(uint32_t N, uint32_t TL, uint32_t L, uint32_t Q, uint32_t K,
-                                    uint32_t mode, uint64_t pow_target, uint64_t n)
+                                    uint32_t mode, uint64_t pow_target, uint64_t n, bool dedup = true)
 {
     StwoLayout y{};
     y.N = N; y.TL = TL; y.L = L; y.Q = Q; y.K = K; y.mode = mode; y.pow_target = pow_target;
@@ -108,6 +125,14 @@ SS_HD inline StwoLayout stwo_layout(uint32_t N, uint32_t TL, uint32_t L, uint32_
     y.n_pow = N + kCp;
     y.ws_alpha = w; w += (uint64_t)y.n_pow * 4 * y.np;
     y.ws_leaf = w;  w += (uint64_t)(K + 1) * 8 * y.nip;
+    // Q random leaves share their ancestors down to about log2(Q) levels below the root; two more
+    // levels still merge ~1.5 pairs per tree, below that almost nothing
+    y.T = (dedup && Q > 1) ? (ceil_log2(Q) + 2 < L ? ceil_log2(Q) + 2 : L) : 0;
+    y.top_G = kTopChains / Q;  // Q <= kMaxQueries = 64
+    const uint64_t groups = (n + y.top_G - 1) / y.top_G;
+    y.top_blocks = y.T ? (uint32_t)(groups < kTopMaxBlocks ? groups : kTopMaxBlocks) : 0;
+    y.ws_top = w;   w += y.T ? (uint64_t)(K + 3) * y.nip * 8 : 0;
+    y.ws_vals = w;  w += (uint64_t)y.top_blocks * 2 * (K + 3) * kTopChains * 8;
     y.ws_total_words = w;
     return y;
 }

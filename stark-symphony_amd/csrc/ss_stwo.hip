@@ -456,7 +456,7 @@ stwo_query_kernel(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *
 // chains first, so the tail of the grid is made of the shortest ones).
 template <int HF>
 __device__ __forceinline__ void stwo_merkle_body(const StwoLayout &lay, const uint32_t *__restrict__ batch,
-                                                 const uint32_t *__restrict__ ws, uint32_t *__restrict__ status)
+                                                 uint32_t *__restrict__ ws, uint32_t *__restrict__ status)
 {
     const uint32_t tiles_per_type = lay.nip >> 6;
     const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -505,13 +505,16 @@ __device__ __forceinline__ void stwo_merkle_body(const StwoLayout &lay, const ui
         code_base = stwo_code(7, l, q, 0);
     }
 
-    // merkle_verify_32 (merkle.simf:22-44): fold the siblings leaf -> root
+    // merkle_verify_32 (merkle.simf:22-44): fold the siblings leaf -> root.  With pair memoisation
+    // on (lay.T) this kernel stops `top` levels below the root and hands the node to stwo_top_kernel.
+    const uint32_t top = lay.T < len ? lay.T : len;
+    const uint32_t n_lvl = len - top;
     const uint4 *tp = reinterpret_cast<const uint4 *>(path) + ((size_t)g * len * 2) * 64 + lane;
     uint4 s0 = make_uint4(0, 0, 0, 0), s1 = s0;
-    if (len) { s0 = tp[0]; s1 = tp[64]; }
-    for (uint32_t lvl = 0; lvl < len; lvl++) {
+    if (n_lvl) { s0 = tp[0]; s1 = tp[64]; }
+    for (uint32_t lvl = 0; lvl < n_lvl; lvl++) {
         uint4 n0 = s0, n1 = s1;
-        if (lvl + 1 < len) {  // prefetch the next level while this one is hashed
+        if (lvl + 1 < n_lvl) {  // prefetch the next level while this one is hashed
             n0 = tp[(size_t)(lvl + 1) * 128];
             n1 = tp[(size_t)(lvl + 1) * 128 + 64];
         }
@@ -531,28 +534,330 @@ __device__ __forceinline__ void stwo_merkle_body(const StwoLayout &lay, const ui
     }
     if (!live) return;
     uint32_t fail = 0xffffffffu;
-    bool same = true;
+    if (top == 0) {
+        bool same = true;
 #pragma unroll
-    for (int j = 0; j < 8; j++) same &= node[j] == Hasher<HF>::native(head[(size_t)(root_w + j) * np + p]);
-    if (!same) fail = code_base + 1;   // assert!(eq_256(computed_root, root))  merkle.simf:43
+        for (int j = 0; j < 8; j++) same &= node[j] == Hasher<HF>::native(head[(size_t)(root_w + j) * np + p]);
+        if (!same) fail = code_base + 1;   // assert!(eq_256(computed_root, root))  merkle.simf:43
+    } else {
+        uint4 *out = reinterpret_cast<uint4 *>(ws + lay.ws_top) + ((size_t)type * nip + inst) * 2;
+        out[0] = make_uint4(node[0], node[1], node[2], node[3]);
+        out[1] = make_uint4(node[4], node[5], node[6], node[7]);
+    }
     // assert!(eq_32(path, 1)), merkle.simf:42, evaluated first by the reference.  The index starts
     // in [2^len, 2^(len+1)) and loses one bit per sibling of the List<u256, 32>, so it ends at 1 iff
     // the proof's path holds exactly `len` siblings -- whatever they contain.
-    if (auth != 1 || batch[lay.off_plen + (size_t)type * nip + inst] != len) fail = code_base;
+    if (batch[lay.off_plen + (size_t)type * nip + inst] != len) fail = code_base;
     if (fail != 0xffffffffu) atomicMin(&status[p], fail);
 }
 
+// ================================================================================= top
+// Merkle pair memoisation (the reference notes at fri/queries.simf:41 that it
+// does not deduplicate).  The Q queries of a proof index random leaves, so near the root their
+// authentication paths run through the same nodes: at depth d (root = 0) the Q chains of a tree meet
+// in at most min(2^d, Q) nodes, and an honest proof presents the same (left, right) pair for a node
+// in every chain that passes through it.  This kernel hashes each DISTINCT node once.
+//
+// Exactness.  Chain c's node at depth d is H(pair_c), pair_c = its node at depth d+1 and its own
+// sibling, ordered by its index bit.  Chains of one proof at the same position of depth d elect the
+// lowest one as that node's leader.  Invariant I(d): every chain's true node at depth d equals the
+// node stored for its depth-d leader.  I(top) is checked directly where this kernel takes over from
+// stwo_merkle_kernel (chains at one position must carry equal nodes).  Step d+1 -> d, for a node P
+// with chains S_L through its left and S_R through its right child, led at depth d+1 by cL and cR:
+//   (i)  every chain of S_L presents the sibling bytes cL presents, likewise S_R / cR   ("same");
+//   (ii) if both are non-empty, cL's sibling is cR's node and cR's sibling is cL's node ("cross").
+// With I(d+1) these say that all chains through P present one pair, so one hash -- by P's leader, which
+// is cL or cR -- gives every chain's node: I(d).  If every check of a (proof, tree) passes, comparing
+// its single depth-0 node with the root is the reference's verdict for all Q chains (all fail or none;
+// the reference stops at the first, query 0).  If any check fails the tree is flagged and its Q
+// chains are re-hashed one by one from depth `top` (merkle.simf:22-44 as written), so a proof in which
+// two queries disagree about a node still gets the reference's status word.  Positions depend on the
+// queries only, and FRI layer l's leaf index is query >> (l+1) in a tree of depth L-1-l, so depth d
+// of EVERY tree of a proof has position query >> (L-d): one plan per proof and depth serves all trees.
+//
+// One block = top_G proofs (top_G * Q <= 256 chains), persistent over groups.  Per depth: plan
+// (leaders, slots, the other child's leader) in LDS, then the checks (64-128 bytes of loads and a
+// compare each, four in flight per lane) and the hashes, all trees at once, dense over the block's
+// lanes.  Nodes of two consecutive depths live in the block's slice of ws_vals.
+template <int HF>
+__device__ __forceinline__ void stwo_top_body(const StwoLayout &lay, const uint32_t *__restrict__ batch,
+                                              uint32_t *__restrict__ ws, uint32_t *__restrict__ status)
+{
+    constexpr uint32_t NT = kMaxList + 3;  // tree kinds: trace, cp, FRI layer 0..K (K <= 30)
+    constexpr uint16_t kNone = 0xffff;
+    __shared__ uint32_t s_query[kTopChains];
+    __shared__ uint16_t s_leader[2][kTopChains];  // chain's leader, by depth parity
+    __shared__ uint16_t s_slot[2][kTopChains];    // slot of the chain's leader, by depth parity
+    __shared__ uint16_t s_fol[2][kTopChains];     // chains that are not leaders, by depth parity
+    __shared__ uint16_t s_item[kTopChains];       // leaders of the current depth in slot order
+    __shared__ uint16_t s_other[kTopChains];      // per leader slot: depth-(d+1) leader of the other child
+    __shared__ uint16_t s_cross[kTopChains];      // leader slots whose node has both children
+    __shared__ uint32_t s_cnt[2][kTopChains / 64];
+    __shared__ uint32_t s_nfol[2];
+    __shared__ uint8_t s_bad[NT][kTopChains];     // [tree][proof of the group]: some check failed
+    __shared__ uint64_t s_path[NT];               // word offset of the tree's path tiles
+    __shared__ uint32_t s_len[NT], s_rootw[NT], s_code[NT];
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t Q = lay.Q, G = lay.top_G, L = lay.L, K = lay.K, np = lay.np, nip = lay.nip;
+    const uint32_t n_types = K + 3;
+    const uint32_t n_groups = (lay.n + G - 1) / G;
+    const uint32_t Tmax = lay.T < L ? lay.T : L;
+    const uint32_t *head = batch + lay.off_head;
+    const uint4 *topn = reinterpret_cast<const uint4 *>(ws + lay.ws_top);
+    uint4 *vals = reinterpret_cast<uint4 *>(ws + lay.ws_vals) + (size_t)blockIdx.x * 2 * n_types * kTopChains * 2;
+
+    if (tid < n_types) {
+        const uint32_t l = tid < 2 ? 0 : tid - 2;
+        s_len[tid] = tid < 2 ? L : L - 1 - l;
+        s_path[tid] = tid == 0 ? lay.off_trace_path : tid == 1 ? lay.off_cp_path : lay.off_fri_path[l];
+        s_rootw[tid] = tid < 2 ? lay.h_roots + 8 * (tid + 1) : lay.h_fri_roots + 8 * l;
+        s_code[tid] = tid < 2 ? stwo_code(5, 0, 0, 2 * tid) : stwo_code(7, l, 0, 0);
+    }
+
+    struct H8 { uint4 a, b; };
+    auto differ = [](const H8 &x, const H8 &y) {
+        return ((x.a.x ^ y.a.x) | (x.a.y ^ y.a.y) | (x.a.z ^ y.a.z) | (x.a.w ^ y.a.w) | (x.b.x ^ y.b.x) |
+                (x.b.y ^ y.b.y) | (x.b.z ^ y.b.z) | (x.b.w ^ y.b.w)) != 0;
+    };
+    // sibling of chain `inst` at `lvl` levels above its leaf, as native words
+    auto sibling = [&](uint32_t ti, uint32_t inst, uint32_t lvl) {
+        const uint32_t len = s_len[ti];
+        const uint4 *tp = reinterpret_cast<const uint4 *>(batch + s_path[ti]) +
+                          ((size_t)(inst >> 6) * len + lvl) * 128 + (inst & 63);
+        H8 h = {tp[0], tp[64]};
+        h.a.x = Hasher<HF>::native(h.a.x); h.a.y = Hasher<HF>::native(h.a.y);
+        h.a.z = Hasher<HF>::native(h.a.z); h.a.w = Hasher<HF>::native(h.a.w);
+        h.b.x = Hasher<HF>::native(h.b.x); h.b.y = Hasher<HF>::native(h.b.y);
+        h.b.z = Hasher<HF>::native(h.b.z); h.b.w = Hasher<HF>::native(h.b.w);
+        return h;
+    };
+    auto unpack = [](const H8 &h, uint32_t (&v)[8]) {
+        v[0] = h.a.x; v[1] = h.a.y; v[2] = h.a.z; v[3] = h.a.w; v[4] = h.b.x; v[5] = h.b.y; v[6] = h.b.z; v[7] = h.b.w;
+    };
+
+    for (uint32_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const uint32_t p0 = grp * G;
+        const uint32_t gp = lay.n - p0 < G ? lay.n - p0 : G;  // proofs of this group
+        const uint32_t nch = gp * Q, inst0 = p0 * Q;
+        __syncthreads();  // the previous group's LDS is no longer read
+        if (tid < nch) {
+            const uint32_t g = tid / Q, q = tid - g * Q;
+            s_query[tid] = ws[lay.ws_ctx + (size_t)(lay.c_queries + q) * np + p0 + g];
+        }
+        for (uint32_t i = tid; i < NT * kTopChains; i += kTopChains) (&s_bad[0][0])[i] = 0;
+        __syncthreads();
+
+        // leaders / followers / slots of depth d into the parity-(d & 1) arrays; returns the leader count
+        auto plan = [&](uint32_t d) {
+            const uint32_t par = d & 1;
+            bool lead = false;
+            if (tid < nch) {
+                const uint32_t pos = s_query[tid] >> (L - d);
+                uint32_t c0 = tid;
+                for (uint32_t c2 = tid - tid % Q; c2 < tid; c2++)
+                    if ((s_query[c2] >> (L - d)) == pos) { c0 = c2; break; }
+                lead = c0 == tid;
+                s_leader[par][tid] = (uint16_t)c0;
+            }
+            const uint64_t vote = __ballot(lead);
+            if (lane == 0) s_cnt[par][wave] = (uint32_t)__popcll(vote);
+            __syncthreads();
+            uint32_t before = (uint32_t)__popcll(vote & ((1ull << lane) - 1)), nlead = 0;
+            for (uint32_t w = 0; w < kTopChains / 64; w++) {
+                if (w < wave) before += s_cnt[par][w];
+                nlead += s_cnt[par][w];
+            }
+            if (tid < nch) {
+                if (lead) { s_slot[par][tid] = (uint16_t)before; if (d < Tmax) s_item[before] = (uint16_t)tid; }
+                else s_fol[par][tid - before] = (uint16_t)tid;
+            }
+            if (tid == 0) s_nfol[par] = nch - nlead;
+            __syncthreads();
+            if (tid < nch && !lead) s_slot[par][tid] = s_slot[par][s_leader[par][tid]];
+            return nlead;
+        };
+        // node of chain c (a leader of depth d+1, or any chain where the tree enters this kernel)
+        auto node_in = [&](uint32_t ti, uint32_t c, uint32_t d) {
+            const uint32_t len = s_len[ti];
+            const uint32_t top = lay.T < len ? lay.T : len;
+            const uint4 *p = d + 1 == top
+                ? topn + ((size_t)ti * nip + inst0 + c) * 2
+                : vals + ((size_t)(((d + 1) & 1) * n_types + ti) * kTopChains + s_slot[(d + 1) & 1][c]) * 2;
+            return H8{p[0], p[1]};
+        };
+
+        plan(Tmax);  // positions where the longest trees enter: who must carry equal nodes
+        for (uint32_t d = Tmax; d-- > 0;) {
+            const uint32_t par = d & 1, prv = par ^ 1;
+            const uint32_t nlead = plan(d);
+            // the other child of each depth-d node: first chain of the proof at position (child ^ 1)
+            uint32_t has_cross = 0;
+            if (tid < nch && s_leader[par][tid] == tid) {
+                const uint32_t want = (s_query[tid] >> (L - d - 1)) ^ 1;
+                uint16_t other = kNone;
+                for (uint32_t c2 = tid - tid % Q, e = c2 + Q; c2 < e; c2++)
+                    if ((s_query[c2] >> (L - d - 1)) == want) { other = (uint16_t)c2; break; }
+                s_other[s_slot[par][tid]] = other;
+                has_cross = other != kNone;
+            }
+            const uint64_t vote = __ballot(has_cross != 0);
+            if (lane == 0) s_cnt[prv][wave] = (uint32_t)__popcll(vote);  // (s_cnt[prv] is free: plan(d+1) is long done)
+            __syncthreads();
+            uint32_t cbefore = (uint32_t)__popcll(vote & ((1ull << lane) - 1)), ncross = 0;
+            for (uint32_t w = 0; w < kTopChains / 64; w++) {
+                if (w < wave) cbefore += s_cnt[prv][w];
+                ncross += s_cnt[prv][w];
+            }
+            if (has_cross) s_cross[cbefore] = s_slot[par][tid];
+            __syncthreads();
+            const uint32_t nsame = s_nfol[prv];                          // followers of depth d+1
+            const uint32_t fri = L - 1 - d < K + 1 ? L - 1 - d : K + 1;  // FRI trees deeper than d
+            const uint32_t ntd = 2 + fri;
+
+            // ---- (i) chains at one position of depth d+1 present one sibling (and, where the tree
+            // enters this kernel, carry one node); four checks in flight per lane
+            auto same_checks = [&]() {
+                const uint32_t total = nsame * ntd;
+                for (uint32_t i0 = tid; i0 < total; i0 += 4 * kTopChains) {
+                    H8 a[4], b[4];
+                    uint32_t tis[4], cs[4];
+                    bool edge[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t i = i0 + u * kTopChains;
+                        const bool on = i < total;
+                        const uint32_t ti = on ? i / nsame : 0, c = s_fol[prv][on ? i - ti * nsame : 0];
+                        const uint32_t c1 = s_leader[prv][c], len = s_len[ti];
+                        tis[u] = on ? ti : NT; cs[u] = c;
+                        edge[u] = on && d + 1 == (lay.T < len ? lay.T : len);
+                        if (on) { a[u] = sibling(ti, inst0 + c, len - 1 - d); b[u] = sibling(ti, inst0 + c1, len - 1 - d); }
+                        else { a[u] = b[u] = H8{make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)}; }
+                        if (edge[u]) {
+                            const H8 x = node_in(ti, c, d), y = node_in(ti, c1, d);
+                            if (differ(x, y)) s_bad[ti][c / Q] = 1;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (tis[u] < NT && differ(a[u], b[u])) s_bad[tis[u]][cs[u] / Q] = 1;
+                }
+            };
+            // ---- (ii) the two children of a node agree about each other
+            auto cross_checks = [&]() {
+                for (uint32_t i = tid; i < ncross * ntd; i += kTopChains) {
+                    const uint32_t ti = i / ncross, k = s_cross[i - ti * ncross], c = s_item[k], o = s_other[k];
+                    const uint32_t lvl = s_len[ti] - 1 - d;
+                    const H8 nc = node_in(ti, c, d), no = node_in(ti, o, d);
+                    const H8 sc = sibling(ti, inst0 + c, lvl), so = sibling(ti, inst0 + o, lvl);
+                    if (differ(nc, so) || differ(no, sc)) s_bad[ti][c / Q] = 1;
+                }
+            };
+            // ---- one hash per distinct node; the next item's 64 bytes are fetched while this one is hashed
+            auto hashes = [&]() {
+                const uint32_t total = nlead * ntd;
+                auto fetch = [&](uint32_t i, H8 &nd, H8 &sb, uint32_t &ti, uint32_t &k, bool &right) {
+                    ti = i / nlead; k = i - ti * nlead;
+                    const uint32_t c = s_item[k];
+                    nd = node_in(ti, c, d);
+                    sb = sibling(ti, inst0 + c, s_len[ti] - 1 - d);
+                    right = (s_query[c] >> (L - d - 1)) & 1;  // the chain's node is the right child
+                };
+                H8 nd, sb;
+                uint32_t ti = 0, k = 0;
+                bool right = false;
+                if (tid < total) fetch(tid, nd, sb, ti, k, right);
+                for (uint32_t i = tid; i < total; i += kTopChains) {
+                    H8 nd2 = nd, sb2 = sb;
+                    uint32_t ti2 = ti, k2 = k;
+                    bool right2 = right;
+                    if (i + kTopChains < total) fetch(i + kTopChains, nd2, sb2, ti2, k2, right2);
+                    uint32_t a[8], b[8], lft[8], rgt[8], out[8];
+                    unpack(nd, a);
+                    unpack(sb, b);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        lft[j] = right ? b[j] : a[j];
+                        rgt[j] = right ? a[j] : b[j];
+                    }
+                    Hasher<HF>::template pair<true>(lft, rgt, out);
+                    uint4 *o = vals + ((size_t)(par * n_types + ti) * kTopChains + k) * 2;
+                    o[0] = make_uint4(out[0], out[1], out[2], out[3]);
+                    o[1] = make_uint4(out[4], out[5], out[6], out[7]);
+                    nd = nd2; sb = sb2; ti = ti2; k = k2; right = right2;
+                }
+            };
+            // Blocks that share a CU run the same schedule; alternating the order keeps the latency-bound
+            // checks of one block over the ALU-bound hashes of its neighbour.
+            if (blockIdx.x & 1) { hashes(); same_checks(); cross_checks(); }
+            else { same_checks(); cross_checks(); hashes(); }
+            __syncthreads();
+        }
+
+        // ---- roots: at depth 0 proof g's only leader is its first chain, slot g
+        for (uint32_t i = tid; i < gp * n_types; i += kTopChains) {
+            const uint32_t ti = i / gp, g = i - ti * gp;
+            if (s_bad[ti][g]) continue;
+            const uint4 *v = vals + ((size_t)ti * kTopChains + g) * 2;  // parity 0
+            uint32_t nd[8];
+            unpack(H8{v[0], v[1]}, nd);
+            bool same = true;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                same &= nd[j] == Hasher<HF>::native(head[(size_t)(s_rootw[ti] + j) * np + p0 + g]);
+            if (!same) atomicMin(&status[p0 + g], s_code[ti] + 1);  // all Q chains fail: query 0 is first
+        }
+        // ---- flagged trees: every chain on its own, as merkle_verify_32 is written
+        for (uint32_t i = tid; i < nch * n_types; i += kTopChains) {
+            const uint32_t ti = i / nch, c = i - ti * nch, g = c / Q;
+            if (!s_bad[ti][g]) continue;
+            const uint32_t len = s_len[ti], top = lay.T < len ? lay.T : len;
+            const uint4 *v = topn + ((size_t)ti * nip + inst0 + c) * 2;
+            uint32_t nd[8];
+            unpack(H8{v[0], v[1]}, nd);
+            for (uint32_t d = top; d-- > 0;) {
+                uint32_t sib[8], lft[8], rgt[8];
+                unpack(sibling(ti, inst0 + c, len - 1 - d), sib);
+                const bool right = (s_query[c] >> (L - d - 1)) & 1;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    lft[j] = right ? sib[j] : nd[j];
+                    rgt[j] = right ? nd[j] : sib[j];
+                }
+                Hasher<HF>::template pair<false>(lft, rgt, nd);
+            }
+            bool same = true;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                same &= nd[j] == Hasher<HF>::native(head[(size_t)(s_rootw[ti] + j) * np + p0 + g]);
+            if (!same) atomicMin(&status[p0 + g], s_code[ti] + ((c - g * Q) << 4) + 1);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
-stwo_merkle_kernel_sha(StwoLayout lay, const uint32_t *__restrict__ batch, const uint32_t *__restrict__ ws,
+stwo_merkle_kernel_sha(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,
                        uint32_t *__restrict__ status)
 {
     stwo_merkle_body<0>(lay, batch, ws, status);
 }
 __global__ void __launch_bounds__(256)
-stwo_merkle_kernel_b2s(StwoLayout lay, const uint32_t *__restrict__ batch, const uint32_t *__restrict__ ws,
+stwo_merkle_kernel_b2s(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,
                        uint32_t *__restrict__ status)
 {
     stwo_merkle_body<1>(lay, batch, ws, status);
+}
+__global__ void __launch_bounds__(kTopChains, 4)
+stwo_top_kernel_sha(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,
+                    uint32_t *__restrict__ status)
+{
+    stwo_top_body<0>(lay, batch, ws, status);
+}
+__global__ void __launch_bounds__(kTopChains, 4)
+stwo_top_kernel_b2s(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,
+                    uint32_t *__restrict__ status)
+{
+    stwo_top_body<1>(lay, batch, ws, status);
 }
 
 // ============================================================================ finalize

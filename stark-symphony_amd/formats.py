@@ -50,10 +50,20 @@ def bytes_to_u256(b: bytes) -> int:
 
 
 def _u32(v: Any) -> int:
+    # integers only: int() would also take 1.5 or "7", which no witness of the reference can hold
+    # (generate_wit.py prints the value into a u32 literal)
+    if isinstance(v, bool) or not isinstance(v, (int, np.integer)):
+        raise MalformedProof("u32 expected, got %r" % (v,))
     v = int(v)
     if not (0 <= v < 1 << 32):
         raise MalformedProof("u32 out of range: %r" % (v,))
     return v
+
+
+def _uint(v: Any, bits: int) -> int:
+    if isinstance(v, bool) or not isinstance(v, (int, np.integer)) or not (0 <= int(v) < 1 << bits):
+        raise MalformedProof("u%d expected, got %r" % (bits, v))
+    return int(v)
 
 
 def _path(nodes: Sequence[Any]) -> np.ndarray:
@@ -75,6 +85,8 @@ def _path(nodes: Sequence[Any]) -> np.ndarray:
 # ----------------------------------------------------------- SimplicityHL literal parser
 def parse_literal(text: str) -> Any:
     """Parse a SimplicityHL value literal into nested Python lists / ints."""
+    if not isinstance(text, str):
+        raise MalformedProof("a witness value is a string holding a literal")
     pos = 0
     n = len(text)
 
@@ -237,7 +249,7 @@ def stark101_from_wit(text: Any) -> Stark101Proof:
         evals = parse_literal(obj["P_EVALS"]["value"])
         layers = parse_literal(obj["FRI_LAYERS"]["value"])
         last = parse_literal(obj["FRI_LAST_LAYER"]["value"])
-    except KeyError as e:
+    except (KeyError, TypeError) as e:
         raise MalformedProof("missing witness %s" % e) from e
     return _s101_from_parts(root, evals, layers, last)
 
@@ -405,7 +417,7 @@ def stwo_from_json(data: Any, trace_log: int | None = None, hash: str | None = N
 
         def declared(d: dict, key: str, fallback: Any) -> int:
             if key in d:
-                return int(d[key])
+                return _uint(d[key], 32)
             if fallback is None:
                 raise MalformedProof("config has no %r and no expected config was given" % key)
             return int(fallback)
@@ -454,9 +466,7 @@ def stwo_from_json(data: Any, trace_log: int | None = None, hash: str | None = N
         if hname not in ("sha256", "blake2s"):
             raise MalformedProof("unknown hash %r" % (hname,))
         cfg = StwoConfig(N, tl, lde_log, Q, K, declared(conf, "pow_bits", expect and expect.pow_bits), hname)
-        nonce = int(data.get("proof_of_work", 0))
-        if not (0 <= nonce < 1 << 64):
-            raise MalformedProof("u64 out of range")
+        nonce = _uint(data.get("proof_of_work", 0), 64)
         return StwoProof(cfg, roots.copy(), oods_trace, oods_cp, trace_vals, cp_vals, trace_paths,
                          cp_paths, fri_roots.copy(), last, fri_witness, fri_paths, nonce)
     except (KeyError, IndexError, TypeError) as e:
@@ -509,7 +519,7 @@ def stwo_from_wit(text: Any, trace_log: int, pow_bits: int = 5, hash: str = "sha
         fric = parse_literal(obj["FRI_COMMITMENTS"]["value"])
         frid = parse_literal(obj["FRI_DECOMMITMENTS"]["value"])
         nonce = parse_literal(obj["POW_NONCE"]["value"])
-    except KeyError as e:
+    except (KeyError, TypeError) as e:
         raise MalformedProof("missing witness %s" % e) from e
     return _stwo_from_parts(com, dec, oods, fric, frid, nonce, trace_log, pow_bits, hash)
 
@@ -541,7 +551,7 @@ def _stwo_from_parts(com: Any, dec: Any, oods: Any, fric: Any, frid: Any, nonce:
         lde_log = len(trace_paths[0]) if Q else 0
         cfg = StwoConfig(N, trace_log, lde_log, Q, K, pow_bits, hash)
         return StwoProof(cfg, roots.copy(), oods_trace, oods_cp, trace_vals, cp_vals, trace_paths,
-                         cp_paths, fri_roots.copy(), last, fri_witness, fri_paths, int(nonce))
+                         cp_paths, fri_roots.copy(), last, fri_witness, fri_paths, _uint(nonce, 64))
     except (IndexError, TypeError, ValueError) as e:
         if isinstance(e, MalformedProof):
             raise

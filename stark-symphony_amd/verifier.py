@@ -9,6 +9,7 @@ which is used for device memory and streams only.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -199,6 +200,45 @@ def _allowed_configs(cfg) -> List[StwoConfig]:
     return allowed
 
 
+def merkle_node_hashes(cfg: StwoConfig, queries: Sequence[int], levels: Optional[int] = None) -> Tuple[int, int]:
+    """-> (node hashes of the reference algorithm, node hashes the kernels execute) for one proof
+    with these query indices.  The reference hashes every sibling of every query's path
+    (fri/queries.simf:41: no deduplication); stwo_top_kernel hashes each distinct pair of the top
+    `levels` levels once (default: what csrc/ss_layout.h picks).  Depth d of every tree of a proof
+    has position query >> (lde_log - d)."""
+    L, Q, K = cfg.lde_log, cfg.n_queries, cfg.n_layers
+    if levels is None:
+        levels = min((Q - 1).bit_length() + 2, L) if Q > 1 else 0
+    lens = [L, L] + [L - 1 - l for l in range(K + 1)]
+    full = Q * sum(lens)
+    done = 0
+    for ln in lens:
+        top = min(levels, ln)
+        done += Q * (ln - top) + sum(len({int(q) >> (L - d) for q in queries}) for d in range(top))
+    return full, done
+
+
+def parse_stwo_text(cfg: StwoConfig, text: bytes, mode: int = MODE_FIXTURE, fmt: int = B.TEXT_AUTO):
+    """One proof.json / proof.wit text -> (outcome, record) with the library's native reader
+    (ss_stwo_parse; no GPU): outcome 0 = parsed, STATUS_CONFIG_MISMATCH (1), STATUS_MALFORMED (2)."""
+    cs = stwo_cfg_struct(cfg, mode)
+    rec = np.zeros(B.lib().ss_stwo_record_words(C.byref(cs)), dtype=np.uint32)
+    text = bytes(text)
+    return B.check(B.lib().ss_stwo_parse(C.byref(cs), text, len(text), fmt, rec.ctypes.data)), rec
+
+
+def parse_s101_text(text: bytes, fmt: int = B.TEXT_AUTO):
+    """-> (outcome, (n_layers, max_path), record or None) with the native reader (ss_s101_parse)."""
+    text = bytes(text)
+    sh = B.S101Shape(0, 0)
+    rc = B.check(B.lib().ss_s101_parse(text, len(text), fmt, C.byref(sh), None))
+    if rc:
+        return rc, None, None
+    rec = np.zeros(B.lib().ss_s101_record_words(C.byref(sh)), dtype=np.uint32)
+    B.check(B.lib().ss_s101_parse(text, len(text), fmt, C.byref(sh), rec.ctypes.data))
+    return 0, (sh.max_layers, sh.max_path), rec
+
+
 def group_by_config(proofs: Sequence[StwoProof]) -> List[List[int]]:
     """Indices of `proofs` grouped by StwoConfig, groups in order of first appearance."""
     groups: dict = {}
@@ -240,9 +280,12 @@ def _ptr_array(records: Sequence[np.ndarray]):
     return arr
 
 
-def stwo_cfg_struct(cfg: StwoConfig, mode: int) -> B.StwoCfg:
+FLAG_NO_DEDUP = 1  # SS_FLAG_NO_DEDUP: hash every query's Merkle path in full (A/B and tests)
+
+
+def stwo_cfg_struct(cfg: StwoConfig, mode: int, flags: int = 0) -> B.StwoCfg:
     return B.StwoCfg(cfg.n_cols, cfg.trace_log, cfg.lde_log, cfg.n_queries, cfg.n_layers, mode,
-                     cfg.pow_target, 1 if cfg.hash == "blake2s" else 0)
+                     cfg.pow_target, 1 if cfg.hash == "blake2s" else 0, flags)
 
 
 def pack_stwo(cfg: StwoConfig, mode: int, records: Sequence[np.ndarray]) -> np.ndarray:
@@ -330,7 +373,7 @@ class StwoDeviceBatch(_DeviceBatch):
         65 536-proof batch made of a few distinct proofs costs no 11 GB host pack and upload."""
         L = B.lib()
         self.cfg, self.mode = cfg, mode
-        self.cs = stwo_cfg_struct(cfg, mode)
+        self.cs = stwo_cfg_struct(cfg, mode, ver.stwo_flags)
         if index is None:
             n = len(records)
             packed = pack_stwo(cfg, mode, records)
@@ -394,6 +437,7 @@ class Verifier:
         B.check(B.lib().ss_ctx_create(device, C.byref(ctx)))
         self.ctx = ctx
         self.timing = False
+        self.stwo_flags = 0  # SS_FLAG_* for the batches this verifier builds
         torch.cuda.set_device(self.device)
 
     def close(self) -> None:
@@ -462,7 +506,7 @@ class Verifier:
                             mode: int = MODE_FIXTURE) -> np.ndarray:
         """Host-buffer path (ss_stwo_verify_records): raw records are uploaded in pinned
         chunks, re-tiled on the GPU and verified.  PCIe-bound; synchronous."""
-        cs = stwo_cfg_struct(cfg, mode)
+        cs = stwo_cfg_struct(cfg, mode, self.stwo_flags)
         want = B.lib().ss_stwo_record_words(C.byref(cs))
         if want == 0:
             raise B.SsError(B.SS_ERR_ARG, "unsupported stwo config %r" % (cfg,))
@@ -473,6 +517,41 @@ class Verifier:
         B.check(B.lib().ss_stwo_verify_records(self.ctx, C.byref(cs), len(records), _ptr_array(records),
                                                status.ctypes.data))
         return status
+
+    # -- text in, verdicts out (native readers, csrc/ss_ingest.cpp) --------------------------
+    def _ingest(self, fn, head_args, items, fmt):
+        n = len(items)
+        status = np.full(n, 0xFFFFFFFF, dtype=np.uint32)
+        stats = B.IngestStats()
+        if items and isinstance(items[0], (bytes, bytearray, memoryview)):
+            bufs = [bytes(t) for t in items]
+            arr = (C.c_char_p * n)(*bufs)
+            lens = (C.c_size_t * n)(*[len(b) for b in bufs])
+            B.check(fn(self.ctx, *head_args, n, arr, lens, fmt, status.ctypes.data, C.byref(stats)))
+        else:
+            arr = (C.c_char_p * n)(*[os.fsencode(p) for p in items])
+            B.check(fn(self.ctx, *head_args, n, arr, fmt, status.ctypes.data, C.byref(stats)))
+        return status, {k: getattr(stats, k) for k, _ in B.IngestStats._fields_ if k != "reserved"}
+
+    def verify_stwo_texts(self, cfg: StwoConfig, texts: Sequence[bytes], mode: int = MODE_FIXTURE,
+                          fmt: int = B.TEXT_AUTO):
+        """proof.json / proof.wit texts (bytes) -> (status, stats): parsed by the library's host
+        threads straight into the upload staging, verified against `cfg` -- the config the caller
+        expects; other shapes / declared parameters get STATUS_CONFIG_MISMATCH, unreadable texts
+        STATUS_MALFORMED (ss_stwo_verify_texts)."""
+        cs = stwo_cfg_struct(cfg, mode, self.stwo_flags)
+        return self._ingest(B.lib().ss_stwo_verify_texts, (C.byref(cs),), list(texts), fmt)
+
+    def verify_stwo_files(self, cfg: StwoConfig, paths: Sequence[str], mode: int = MODE_FIXTURE,
+                          fmt: int = B.TEXT_AUTO):
+        cs = stwo_cfg_struct(cfg, mode, self.stwo_flags)
+        return self._ingest(B.lib().ss_stwo_verify_files, (C.byref(cs),), [str(p) for p in paths], fmt)
+
+    def verify_stark101_texts(self, texts: Sequence[bytes], fmt: int = B.TEXT_AUTO):
+        return self._ingest(B.lib().ss_s101_verify_texts, (), list(texts), fmt)
+
+    def verify_stark101_files(self, paths: Sequence[str], fmt: int = B.TEXT_AUTO):
+        return self._ingest(B.lib().ss_s101_verify_files, (), [str(p) for p in paths], fmt)
 
     def pack_stwo_on_device(self, cfg: StwoConfig, mode: int, records: Sequence[np.ndarray]):
         """Upload records as they are and re-tile them with ss_stwo_pack_dev; returns the batch

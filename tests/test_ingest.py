@@ -1,0 +1,203 @@
+"""Native text readers (csrc/ss_ingest.cpp, C ABI ss_stwo_parse / ss_s101_parse) against the Python
+grammar of stark-symphony_amd/formats.py: same records for everything the reference's adapters print
+(stwo-verifier/scripts/generate_wit.py, stark101/scripts/generate_wit.py) and for random proofs, same
+accept / malformed / other-config outcome for broken inputs.  No GPU needed: parsing is host code."""
+import json
+import os
+
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+import stark_symphony_amd as ss
+from stark_symphony_amd import formats, records, verifier
+
+from conftest import GOLDEN
+
+FORMATS = os.path.join(GOLDEN, "formats")
+OK, MISMATCH, MALFORMED = 0, verifier.STATUS_CONFIG_MISMATCH, 2
+
+
+def _python_outcome(text: bytes, cfg, kind):
+    """What the Python path says about `text` when `cfg` is expected: (outcome, record or None)."""
+    try:
+        if kind == "json":
+            p = ss.stwo_from_json(json.loads(text), expect=cfg)
+        else:
+            p = ss.stwo_from_wit(text.decode(), cfg.trace_log, cfg.pow_bits, cfg.hash)
+    except (ss.MalformedProof, ValueError, OverflowError, AttributeError):
+        return MALFORMED, None
+    if p.cfg != cfg:
+        return MISMATCH, None
+    return OK, verifier.stwo_record(p)
+
+
+def _check(text: bytes, cfg, kind):
+    want, rec = _python_outcome(text, cfg, kind)
+    got, grec = verifier.parse_stwo_text(cfg, text)
+    assert got == want, (got, want, text[:120])
+    if want == OK:
+        assert np.array_equal(grec, rec)
+    else:
+        assert not grec.any()  # nothing half-written
+    return want
+
+
+@pytest.mark.parametrize("name,cfg", [("stwo_proof", ss.PRODUCTION_CONFIG), ("stwo_proof_test", ss.TESTING_CONFIG)])
+def test_reference_files_parse_to_the_same_record(name, cfg):
+    j = open(os.path.join(GOLDEN, name + ".json"), "rb").read()
+    w = open(os.path.join(FORMATS, name + ".wit"), "rb").read()
+    assert _check(j, cfg, "json") == OK and _check(w, cfg, "wit") == OK
+    assert np.array_equal(verifier.parse_stwo_text(cfg, j)[1], verifier.parse_stwo_text(cfg, w)[1])
+    other = ss.TESTING_CONFIG if cfg is ss.PRODUCTION_CONFIG else ss.PRODUCTION_CONFIG
+    assert _check(j, other, "json") == MISMATCH and _check(w, other, "wit") == MISMATCH
+
+
+@pytest.mark.parametrize("npz", ["stwo_trace16.npz", "stwo_wide256.npz", "stwo_trace20.npz", "stwo_trace16_blake2s.npz"])
+def test_prover_made_proofs_through_both_text_formats(npz):
+    p = records.load_stwo_npz(os.path.join(GOLDEN, npz))[0]
+    j = json.dumps(ss.stwo_to_json(p)).encode()
+    w = ss.stwo_to_wit(p).encode()
+    assert _check(j, p.cfg, "json") == OK and _check(w, p.cfg, "wit") == OK
+    assert np.array_equal(verifier.parse_stwo_text(p.cfg, w)[1], verifier.stwo_record(p))
+
+
+def test_stark101_files():
+    for fn, reader in (("stark101_proof.json", lambda t: ss.stark101_from_json(json.loads(t))),
+                       (os.path.join("formats", "stark101_proof.wit"), lambda t: ss.stark101_from_wit(t.decode()))):
+        text = open(os.path.join(GOLDEN, fn), "rb").read()
+        rc, shape, rec = verifier.parse_s101_text(text)
+        p = reader(text)
+        assert rc == 0 and shape == verifier.s101_shape_of([p])
+        assert np.array_equal(rec, verifier.s101_record(p, *shape))
+    for bad in (b"{}", b"[1, 2]", b"{\"p_mt_root\": 1, \"evals\": [], \"fri_layers\": [], \"fri_last_layer\": 0}",
+                text[:-40], text.replace(b"list!", b"lisp!", 1)):
+        assert verifier.parse_s101_text(bad)[0] == MALFORMED
+
+
+from test_formats_property import _rand_stwo  # noqa: E402
+
+
+shapes = st.tuples(st.integers(0, 2 ** 32 - 1), st.integers(1, 9), st.integers(3, 12), st.integers(1, 7),
+                   st.integers(0, 3)).filter(lambda t: t[4] + 1 < t[2])
+
+
+@settings(max_examples=40, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(shapes, st.booleans())
+def test_random_proofs_and_ragged_paths(t, ragged):
+    seed, n_cols, lde_log, n_queries, n_layers = t
+    p = _rand_stwo(seed, n_cols, lde_log, n_queries, n_layers, ragged)
+    w = ss.stwo_to_wit(p).encode()
+    back = ss.stwo_from_wit(w.decode(), p.cfg.trace_log, p.cfg.pow_bits)
+    import ctypes as C
+    from stark_symphony_amd import binding
+    cs = verifier.stwo_cfg_struct(back.cfg, verifier.MODE_FIXTURE)
+    if binding.lib().ss_stwo_record_words(C.byref(cs)):  # ragged first path = another LDE_LOG_SIZE
+        _check(w, back.cfg, "wit")
+    else:  # ... possibly one no verifier can be configured for: a loud error, not a verdict
+        with pytest.raises(binding.SsError):
+            verifier.parse_stwo_text(back.cfg, w)
+    _check(w, p.cfg, "wit")
+    if not ragged:
+        _check(json.dumps(ss.stwo_to_json(p)).encode(), p.cfg, "json")
+
+
+def _json_mutants(obj):
+    """(description, object) pairs, each a small edit of a valid proof.json object"""
+    import copy
+    def edit(f):
+        o = copy.deepcopy(obj)
+        f(o)
+        return o
+    out = []
+    out.append(("byte 256", edit(lambda o: o["commitments"][1].__setitem__(5, 256))))
+    out.append(("31-byte hash", edit(lambda o: o["commitments"][0].pop())))
+    out.append(("u32 overflow", edit(lambda o: o["queried_values"][1].__setitem__(0, 2 ** 32))))
+    out.append(("negative", edit(lambda o: o["queried_values"][2].__setitem__(3, -1))))
+    out.append(("float", edit(lambda o: o["queried_values"][2].__setitem__(3, 1.5))))
+    out.append(("string value", edit(lambda o: o["queried_values"][2].__setitem__(3, "7"))))
+    out.append(("missing fri_proof", edit(lambda o: o.pop("fri_proof"))))
+    out.append(("missing commitments", edit(lambda o: o.pop("commitments"))))
+    out.append(("two coeffs", edit(lambda o: o["fri_proof"]["last_layer_poly"]["coeffs"].append(
+        o["fri_proof"]["last_layer_poly"]["coeffs"][0]))))
+    out.append(("qm31 with 3 words", edit(lambda o: o["sampled_values"][1][0][0][1].append(1))))
+    out.append(("one witness less", edit(lambda o: o["fri_proof"]["first_layer"]["fri_witness"].pop())))
+    out.append(("hash_witness not divisible", edit(lambda o: o["decommitments"][1]["hash_witness"].pop())))
+    out.append(("one queried value less", edit(lambda o: o["queried_values"][1].pop())))
+    out.append(("15 cp columns", edit(lambda o: o["sampled_values"][2].pop())))
+    out.append(("extra column = other config", edit(lambda o: (o["sampled_values"][1].append(o["sampled_values"][1][0]),
+                                                               o["queried_values"][1].extend([1] * o["config"]["fri_config"]["n_queries"])))))
+    out.append(("declares pow_bits 0", edit(lambda o: o["config"].__setitem__("pow_bits", 0))))
+    out.append(("declares pow_bits 65", edit(lambda o: o["config"].__setitem__("pow_bits", 65))))
+    out.append(("no pow_bits", edit(lambda o: o["config"].pop("pow_bits"))))
+    out.append(("no config", edit(lambda o: o.pop("config"))))
+    out.append(("declares 1 query", edit(lambda o: o["config"]["fri_config"].__setitem__("n_queries", 1))))
+    out.append(("declares blake2s", edit(lambda o: o["config"].__setitem__("hash", "blake2s"))))
+    out.append(("declares md5", edit(lambda o: o["config"].__setitem__("hash", "md5"))))
+    out.append(("declares blow-up 3", edit(lambda o: o["config"]["fri_config"].__setitem__("log_blowup_factor", 3))))
+    out.append(("one inner layer less", edit(lambda o: o["fri_proof"]["inner_layers"].pop())))
+    out.append(("nonce 2^64", edit(lambda o: o.__setitem__("proof_of_work", 2 ** 64))))
+    out.append(("nonce 2^64-1", edit(lambda o: o.__setitem__("proof_of_work", 2 ** 64 - 1))))
+    out.append(("path node as big integer", edit(lambda o: o["decommitments"][1]["hash_witness"].__setitem__(
+        0, int.from_bytes(bytes(o["decommitments"][1]["hash_witness"][0]), "big")))))
+    out.append(("path node 2^256", edit(lambda o: o["decommitments"][2]["hash_witness"].__setitem__(1, 2 ** 256))))
+    out.append(("commitment as integer", edit(lambda o: o["commitments"].__setitem__(0, 5))))
+    out.append(("null member", edit(lambda o: o["fri_proof"].__setitem__("first_layer", None))))
+    return out
+
+
+def test_malformed_and_downgraded_json_get_the_python_outcome():
+    obj = json.load(open(os.path.join(GOLDEN, "stwo_proof.json")))
+    seen = set()
+    for what, o in _json_mutants(obj):
+        seen.add((_check(json.dumps(o).encode(), ss.PRODUCTION_CONFIG, "json")))
+    assert seen == {OK, MISMATCH, MALFORMED}
+    text = json.dumps(obj).encode()
+    for cut in (1, 10, len(text) // 2, len(text) - 1):
+        assert _check(text[:cut], ss.PRODUCTION_CONFIG, "json") == MALFORMED
+    assert _check(text + b" x", ss.PRODUCTION_CONFIG, "json") == MALFORMED
+    assert _check(b"  " + text + b"\n\t ", ss.PRODUCTION_CONFIG, "json") == OK
+    assert _check(b"[]", ss.PRODUCTION_CONFIG, "json") == MALFORMED
+
+
+def test_malformed_wit_gets_the_python_outcome():
+    cfg = ss.TESTING_CONFIG
+    wit = json.load(open(os.path.join(FORMATS, "stwo_proof_test.wit")))
+
+    def with_value(name, f):
+        w = json.loads(json.dumps(wit))
+        w[name]["value"] = f(w[name]["value"])
+        return json.dumps(w).encode()
+    cases = [
+        with_value("POW_NONCE", lambda v: "0x" + "%X" % int(v)),                 # hex, upper case
+        with_value("POW_NONCE", lambda v: "1_8_5"),                              # `_` separators
+        with_value("POW_NONCE", lambda v: v + " 1"),                             # trailing characters
+        with_value("POW_NONCE", lambda v: "(" + v + ")"),                        # "(x)" is x
+        with_value("POW_NONCE", lambda v: "((" + v + "))"),
+        with_value("POW_NONCE", lambda v: "(" + v + ",)"),                       # a 1-tuple is not a u64
+        with_value("POW_NONCE", lambda v: str(2 ** 64)),
+        with_value("POW_NONCE", lambda v: ""),
+        with_value("COMMITMENTS", lambda v: v.replace("(", "[", 1)[:-1] + "]"),  # array instead of tuple
+        with_value("COMMITMENTS", lambda v: v[:-1] + ", 1)"),                    # four commitments
+        with_value("COMMITMENTS", lambda v: v.replace("0x", "0x1" + "0" * 64, 1)),  # 2^256 and more
+        with_value("COMMITMENTS", lambda v: v.replace("0x", "0x" + "0" * 20, 1)),   # leading zeros
+        with_value("DECOMMITMENTS", lambda v: v.replace("list![", "list! [", 1)),
+        with_value("DECOMMITMENTS", lambda v: v.replace("list![", "list [", 1)),
+        with_value("DECOMMITMENTS", lambda v: v.replace(", ", " ", 3)),          # commas are optional to formats.py
+        with_value("DECOMMITMENTS", lambda v: v.replace("[1]", "[1, 2]", 1)),    # only the first offset is read
+        with_value("DECOMMITMENTS", lambda v: v.replace("[1]", "1", 1)),
+        with_value("DECOMMITMENTS", lambda v: v[:-1]),                           # unterminated
+        with_value("OODS_EVALS", lambda v: v.replace("((1, 0), (0, 0))", "[[((1, 0), (0, 0))]]", 1)),
+        with_value("OODS_EVALS", lambda v: v.replace("((1, 0), (0, 0))", "((1, 0, 0), (0,))", 1)),
+        with_value("OODS_EVALS", lambda v: v.replace("(1, 0)", "(4294967296, 0)", 1)),
+        with_value("FRI_COMMITMENTS", lambda v: v.replace("[", "list![", 1)),
+        with_value("FRI_DECOMMITMENTS", lambda v: v.replace("list![", "list![" + "1, " * 31, 1)),  # 32+ siblings
+        with_value("FRI_DECOMMITMENTS", lambda v: v.replace("list![", "list![7, ", 1)),           # one sibling more
+        json.dumps({k: v for k, v in wit.items() if k != "OODS_EVALS"}).encode(),
+        json.dumps(dict(wit, COMMITMENTS={"type": "x"})).encode(),
+        json.dumps(dict(wit, COMMITMENTS={"value": 5, "type": "x"})).encode(),
+    ]
+    seen = {_check(c, cfg, "wit") for c in cases}
+    assert seen == {OK, MALFORMED}
+    assert _check(json.dumps(wit).encode(), ss.PRODUCTION_CONFIG, "wit") == MISMATCH

@@ -51,7 +51,9 @@ __global__ void __launch_bounds__(256, WAVES_PER_EU) chain_kernel(uint32_t iters
 // so this can only lose; measured here so the claim has a number (profiles/r02_sha_lds_ab.txt).
 __global__ void __launch_bounds__(256) chain_kernel_lds(uint32_t iters, uint32_t *out)
 {
-    __shared__ uint32_t sw[16][256];
+    // volatile: without it the compiler forwards every store to the later loads of the same lane
+    // (no barrier, so it may) and only the ds_write traffic remains -- measured: no difference
+    __shared__ volatile uint32_t sw[16][256];
     uint32_t node[8], sib[8];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, l = threadIdx.x;
 #pragma unroll
@@ -70,7 +72,7 @@ __global__ void __launch_bounds__(256) chain_kernel_lds(uint32_t iters, uint32_t
 #pragma unroll
         for (int r = 0; r < 64; r++) {
             if (r >= 16)
-                sw[r & 15][l] += sha_s0(sw[(r + 1) & 15][l]) + sw[(r + 9) & 15][l] + sha_s1(sw[(r + 14) & 15][l]);
+                sw[r & 15][l] = sw[r & 15][l] + sha_s0(sw[(r + 1) & 15][l]) + sw[(r + 9) & 15][l] + sha_s1(sw[(r + 14) & 15][l]);
             const uint32_t t1 = h + sha_S1(e) + sha_ch(e, f, g) + (kK.k[r] + sw[r & 15][l]);
             const uint32_t t2 = sha_S0(a) + sha_maj(a, b, c);
             h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
