@@ -171,6 +171,43 @@ def time_simfony(exe: str):
                 "sample": "%d x `simfony run` of the stark101 proof" % n}
 
 
+def end_to_end(ver, proofs, n: int):
+    """Text in, verdicts out (never `value`): what a caller holding proof.json / proof.wit files sees.
+    n texts of this workload's proofs go through ss_stwo_verify_texts -- native readers on the host
+    threads, pinned staging, upload, GPU re-tiling, verification, download -- timed around the call;
+    beside it the same texts through the Python reader (formats.py) for a few proofs, one thread."""
+    import stark_symphony_amd as ss
+    from stark_symphony_amd import binding, verifier
+    cfg = proofs[0].cfg
+    distinct = proofs[:8]
+    texts = {"json": [json.dumps(ss.stwo_to_json(p)).encode() for p in distinct],
+             "wit": [ss.stwo_to_wit(p).encode() for p in distinct]}
+    out = {"proofs": n, "note": "proof text -> verdict through ss_stwo_verify_texts (csrc/ss_ingest.cpp), host "
+                                "parse + PCIe included; parse-bound, not what `value` measures"}
+    for kind, fmt in (("json", binding.TEXT_JSON), ("wit", binding.TEXT_WIT)):
+        batch = [texts[kind][i % len(distinct)] for i in range(n)]
+        ver.verify_stwo_texts(cfg, batch[:32], fmt=fmt)  # warm-up: scratch allocation
+        t0 = time.perf_counter()
+        status, st = ver.verify_stwo_texts(cfg, batch, fmt=fmt)
+        dt = time.perf_counter() - t0
+        assert (status == 0).all(), "e2e: a benchmark proof was not accepted"
+        t1 = time.perf_counter()
+        k = 0
+        while k < 3 or time.perf_counter() - t1 < 0.5:
+            t = texts[kind][k % len(distinct)]
+            p = ss.stwo_from_json(json.loads(t), expect=cfg) if kind == "json" else \
+                ss.stwo_from_wit(t.decode(), cfg.trace_log, cfg.pow_bits, cfg.hash)
+            verifier.stwo_record(p)
+            k += 1
+        py = k / (time.perf_counter() - t1)
+        out[kind] = {"proofs_per_s": n / dt, "total_s": dt, "parse_s": st["parse_s"],
+                     "parse_share": st["parse_s"] / st["total_s"], "host_threads": st["threads"],
+                     "text_bytes_per_proof": st["text_bytes"] // n,
+                     "parse_MB_per_s_per_thread": st["text_bytes"] / st["parse_s"] / st["threads"] / 1e6,
+                     "python_reader_proofs_per_s_one_thread": py}
+    return out
+
+
 def spawn_ranks(n: int) -> int:
     """One child process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment,
     the same contract torch.distributed.run provides), same command line.  Rank 0's stdout -- the
@@ -226,6 +263,8 @@ def main() -> None:
                     help="distinct valid proofs in the batch (made by the GPU prover; 0 = fixtures only)")
     ap.add_argument("--inflight", type=int, default=3,
                     help="batch passes in flight (one HIP stream each)")
+    ap.add_argument("--e2e", type=int, default=384,
+                    help="proof.json / proof.wit texts for the end-to-end (text -> verdict) figures; 0 = skip")
     ap.add_argument("--no-dedup", action="store_true",
                     help="SS_FLAG_NO_DEDUP: hash every query's Merkle path in full (A/B of the pair memoisation)")
     args = ap.parse_args()
@@ -406,6 +445,8 @@ def main() -> None:
                                      "profiles/r01_sha_calibration.txt"},
             "kernels_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in timing.items()},
         }
+        if family == "stwo" and args.e2e > 0 and world == 1:
+            out["e2e"] = end_to_end(ver, proofs, args.e2e)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(family, proofs, args.cpu_seconds)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

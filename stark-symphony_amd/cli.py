@@ -84,43 +84,43 @@ def main(argv=None) -> int:
         return convert(args)
 
     import dataclasses
+    from . import binding
     expected = formats.PRODUCTION_CONFIG if args.config == "production" else formats.TESTING_CONFIG
     over = {k: getattr(args, k) for k in ("n_cols", "trace_log", "lde_log", "n_queries", "n_layers",
                                           "pow_bits", "hash") if getattr(args, k) is not None}
     expected = dataclasses.replace(expected, **over)
-    proofs, names = [], []
-    try:
-        for path in args.witness:
-            text = open(path).read()
-            if args.family == "stark101":
-                proofs.append(formats.stark101_from_wit(text))
-            else:  # a .wit declares nothing: what cannot be read off its shape is the verifier's
-                proofs.append(formats.stwo_from_wit(text, expected.trace_log, expected.pow_bits, expected.hash))
-            names.append(path)
-        for path in args.proof:
-            obj = json.load(open(path))
-            proofs.append(formats.stark101_from_json(obj) if args.family == "stark101"
-                          else formats.stwo_from_json(obj, expect=expected))
-            names.append(path)
-    except (formats.MalformedProof, OSError, ValueError) as e:
-        print("Error: %s" % e, file=sys.stderr)
-        return 1
-    if not proofs:
+    if not args.witness and not args.proof:
         print("Error: nothing to verify", file=sys.stderr)
         return 1
-    ver = verifier.Verifier(args.device)
-    if args.family == "stark101":
-        status = ver.verify_stark101(proofs)
-    else:
-        mode = verifier.MODE_FIXTURE if args.mode == "fixture" else verifier.MODE_LITERAL
-        status = ver.verify_stwo(proofs, mode, cfg=expected)
+    # The files go to the library as they are: its native readers (csrc/ss_ingest.cpp) parse them on
+    # host threads into the upload staging; nothing is parsed in Python on this path.
+    try:
+        ver = verifier.Verifier(args.device)
+        names, status = [], []
+        for paths, fmt in ((args.witness, binding.TEXT_WIT), (args.proof, binding.TEXT_JSON)):
+            if not paths:
+                continue
+            if args.family == "stark101":
+                st, _ = ver.verify_stark101_files(paths, fmt)
+            else:
+                mode = verifier.MODE_FIXTURE if args.mode == "fixture" else verifier.MODE_LITERAL
+                st, _ = ver.verify_stwo_files(expected, paths, mode, fmt)
+            names += list(paths)
+            status += st.tolist()
+    except binding.SsError as e:  # no GPU / unsupported config: an error, never a verdict
+        print("Error: %s" % e, file=sys.stderr)
+        return 1
     bad = 0
-    for name, st in zip(names, status.tolist()):
+    for name, st in zip(names, status):
         if st == 0:
             print("%s: ACCEPT" % name)
+            continue
+        bad += 1
+        if st == binding.STATUS_MALFORMED:  # main.rs:77-81,187-190: the witness does not type-check
+            print("Error: %s: malformed witness (not a value of the program's witness types)" % name,
+                  file=sys.stderr)
         else:
-            bad += 1
-            why = ("witness does not have the shape of the expected config" if st == verifier.STATUS_CONFIG_MISMATCH
+            why = ("witness does not have the shape of the expected config" if st == binding.STATUS_CONFIG_MISMATCH
                    else "first failing assert 0x%08x" % st)
             print("Error: Failed to run program: %s: REJECT (%s)" % (name, why), file=sys.stderr)
     return 1 if bad else 0

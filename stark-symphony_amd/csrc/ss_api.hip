@@ -76,6 +76,8 @@ struct HostPath {
 struct ss_ctx {
     int device;
     int timing;
+    int cus;                 // compute units of the device
+    int top_blocks_per_cu[2];  // resident stwo_top_kernel blocks per CU, per hash family (0 = not yet asked)
     std::vector<TimedSpan> spans;   // recorded since the last collect
     std::vector<hipEvent_t> pool;   // recycled events
     HostPath hp;
@@ -98,6 +100,8 @@ extern "C" int ss_ctx_create(int device, ss_ctx **out)
     ss_ctx *c = new ss_ctx();
     c->device = device;
     c->timing = 0;
+    c->cus = prop.multiProcessorCount;
+    c->top_blocks_per_cu[0] = c->top_blocks_per_cu[1] = 0;
     *out = c;
     return SS_OK;
 }
@@ -307,6 +311,26 @@ extern "C" int ss_stwo_pack(const ss_stwo_cfg *c, size_t n, const uint32_t *cons
     return SS_OK;
 }
 
+// Blocks of the persistent top kernel that are resident at once: from the kernel's own register and
+// LDS footprint (512 VGPRs per SIMD lane in granules of 8, 160 KB LDS per CU; one 256-thread block
+// puts one wave on each of the CU's four SIMDs).  The grid must not exceed this, or the surplus blocks
+// run after the others at a fraction of the occupancy.
+static int top_resident_blocks(ss_ctx *ctx, int hf)
+{
+    if (!ctx->top_blocks_per_cu[hf]) {
+        hipFuncAttributes a;
+        const void *fn = hf ? (const void *)stwo_top_kernel_b2s : (const void *)stwo_top_kernel_sha;
+        int per_cu = 4;
+        if (hipFuncGetAttributes(&a, fn) == hipSuccess && a.numRegs > 0) {
+            const int by_regs = 512 / ((a.numRegs + 7) / 8 * 8);
+            const int by_lds = a.sharedSizeBytes ? (int)((160u << 10) / a.sharedSizeBytes) : 8;
+            per_cu = std::max(1, std::min(8, std::min(by_regs, by_lds)));
+        }
+        ctx->top_blocks_per_cu[hf] = per_cu;
+    }
+    return ctx->top_blocks_per_cu[hf] * ctx->cus;
+}
+
 extern "C" int ss_stwo_verify_phase_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n,
                                         const uint32_t *batch, void *workspace, size_t workspace_bytes,
                                         uint32_t *status, uint32_t *accept_count, int phases,
@@ -343,8 +367,11 @@ extern "C" int ss_stwo_verify_phase_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_
         t.end("stwo_merkle");
         if (y.T) {
             t.begin();
-            hipLaunchKernelGGL(c->hash == SS_HASH_BLAKE2S ? stwo_top_kernel_b2s : stwo_top_kernel_sha,
-                               dim3(y.top_blocks), dim3(kTopChains), 0, s, y, batch, ws, status);
+            const int hf = c->hash == SS_HASH_BLAKE2S;
+            const uint32_t blocks = std::min<uint32_t>(y.top_blocks, (uint32_t)top_resident_blocks(ctx, hf));
+            HIP_TRY(hipMemsetAsync(ws + y.ws_counter, 0, 4, s));  // the kernel's group counter
+            hipLaunchKernelGGL(hf ? stwo_top_kernel_b2s : stwo_top_kernel_sha, dim3(blocks), dim3(kTopChains), 0, s,
+                               y, batch, ws, status);
             t.end("stwo_top");
         }
         t.begin();

@@ -58,10 +58,11 @@ struct StwoLayout {
     uint32_t top_blocks;  // persistent blocks of the top kernel (each owns a slice of ws_vals)
     uint64_t ws_top;      // top[type][inst][8]: node of every chain at depth min(T, len), native words
     uint64_t ws_vals;     // vals[block][parity][type][slot][8]: nodes of the distinct pairs, two depths
+    uint64_t ws_counter;  // next group of the top kernel (one word, zeroed before each launch)
 };
 
 constexpr uint32_t kTopChains = 256;     // chains a top-kernel block plans at once (= its threads)
-constexpr uint32_t kTopMaxBlocks = 1024;
+constexpr uint32_t kTopMaxBlocks = 2048;  // workspace slices; the launch uses min(groups, resident blocks)
 
 SS_HD inline uint32_t ceil_log2(uint32_t v)
 {
@@ -133,6 +134,7 @@ SS_HD inline StwoLayout stwo_layout(uint32_t N, uint32_t TL, uint32_t L, uint32_
     y.top_blocks = y.T ? (uint32_t)(groups < kTopMaxBlocks ? groups : kTopMaxBlocks) : 0;
     y.ws_top = w;   w += y.T ? (uint64_t)(K + 3) * y.nip * 8 : 0;
     y.ws_vals = w;  w += (uint64_t)y.top_blocks * 2 * (K + 3) * kTopChains * 8;
+    y.ws_counter = w; w += 4;
     y.ws_total_words = w;
     return y;
 }

@@ -561,11 +561,14 @@ __device__ __forceinline__ void stwo_merkle_body(const StwoLayout &lay, const ui
 // Exactness.  Chain c's node at depth d is H(pair_c), pair_c = its node at depth d+1 and its own
 // sibling, ordered by its index bit.  Chains of one proof at the same position of depth d elect the
 // lowest one as that node's leader.  Invariant I(d): every chain's true node at depth d equals the
-// node stored for its depth-d leader.  I(top) is checked directly where this kernel takes over from
-// stwo_merkle_kernel (chains at one position must carry equal nodes).  Step d+1 -> d, for a node P
-// with chains S_L through its left and S_R through its right child, led at depth d+1 by cL and cR:
+// node stored for its depth-d leader.  Where a tree enters this kernel (depth `top`, nodes from
+// stwo_merkle_kernel) I(top) is checked directly: chains at one position must carry equal nodes
+// ("edge").  Step d+1 -> d, for a node P with chains S_L through its left and S_R through its right
+// child, led at depth d+1 by cL and cR:
 //   (i)  every chain of S_L presents the sibling bytes cL presents, likewise S_R / cR   ("same");
-//   (ii) if both are non-empty, cL's sibling is cR's node and cR's sibling is cL's node ("cross").
+//   (ii) if both are non-empty, cL's sibling is cR's node and cR's sibling is cL's node ("cross";
+//        each half is checked by the lane that has just produced that node, or from the stored
+//        nodes where the tree enters).
 // With I(d+1) these say that all chains through P present one pair, so one hash -- by P's leader, which
 // is cL or cR -- gives every chain's node: I(d).  If every check of a (proof, tree) passes, comparing
 // its single depth-0 node with the root is the reference's verdict for all Q chains (all fail or none;
@@ -573,36 +576,48 @@ __device__ __forceinline__ void stwo_merkle_body(const StwoLayout &lay, const ui
 // chains are re-hashed one by one from depth `top` (merkle.simf:22-44 as written), so a proof in which
 // two queries disagree about a node still gets the reference's status word.  Positions depend on the
 // queries only, and FRI layer l's leaf index is query >> (l+1) in a tree of depth L-1-l, so depth d
-// of EVERY tree of a proof has position query >> (L-d): one plan per proof and depth serves all trees.
+// of EVERY tree of a proof has position query >> (L-d): one plan per proof serves all its trees.
 //
-// One block = top_G proofs (top_G * Q <= 256 chains), persistent over groups.  Per depth: plan
-// (leaders, slots, the other child's leader) in LDS, then the checks (64-128 bytes of loads and a
-// compare each, four in flight per lane) and the hashes, all trees at once, dense over the block's
-// lanes.  Nodes of two consecutive depths live in the block's slice of ws_vals.
+// One block = top_G proofs (top_G * Q <= 256 chains), persistent over groups.  The plan of all depths
+// (leaders, slots, followers, sibling-position leaders) is made once per group in LDS.  The checks
+// are 64 bytes of loads and a compare each and depend on the proof bytes only, so they form one queue
+// per group that the hash loop drains two per iteration: their loads are issued before a SHA-256
+// pair hash and compared after it, which hides their latency behind ALU work of the same wave (blocks
+// sharing a CU run in lockstep, so nothing else would).  Nodes of two consecutive depths live in the
+// block's slice of ws_vals.
+constexpr uint32_t kTopMaxT = 8;  // ceil_log2(kMaxQueries) + 2
+
 template <int HF>
 __device__ __forceinline__ void stwo_top_body(const StwoLayout &lay, const uint32_t *__restrict__ batch,
                                               uint32_t *__restrict__ ws, uint32_t *__restrict__ status)
 {
     constexpr uint32_t NT = kMaxList + 3;  // tree kinds: trace, cp, FRI layer 0..K (K <= 30)
+    constexpr uint32_t D = kTopMaxT + 1;   // depths 0..T
     constexpr uint16_t kNone = 0xffff;
+    constexpr uint32_t kMaxSeg = 3 * kTopMaxT;
     __shared__ uint32_t s_query[kTopChains];
-    __shared__ uint16_t s_leader[2][kTopChains];  // chain's leader, by depth parity
-    __shared__ uint16_t s_slot[2][kTopChains];    // slot of the chain's leader, by depth parity
-    __shared__ uint16_t s_fol[2][kTopChains];     // chains that are not leaders, by depth parity
-    __shared__ uint16_t s_item[kTopChains];       // leaders of the current depth in slot order
-    __shared__ uint16_t s_other[kTopChains];      // per leader slot: depth-(d+1) leader of the other child
-    __shared__ uint16_t s_cross[kTopChains];      // leader slots whose node has both children
-    __shared__ uint32_t s_cnt[2][kTopChains / 64];
-    __shared__ uint32_t s_nfol[2];
-    __shared__ uint8_t s_bad[NT][kTopChains];     // [tree][proof of the group]: some check failed
-    __shared__ uint64_t s_path[NT];               // word offset of the tree's path tiles
+    __shared__ uint16_t s_lead[D][kTopChains];   // [depth][chain]: the chain's leader
+    __shared__ uint16_t s_slot[D][kTopChains];   // [depth][chain]: slot of the chain's leader
+    __shared__ uint16_t s_item[D][kTopChains];   // [depth][slot]: the leader chain
+    __shared__ uint16_t s_fol[D][kTopChains];    // [depth][j]: chains that are not leaders
+    __shared__ uint16_t s_sibl[D][kTopChains];   // [depth][slot]: leader of the sibling position, or kNone
+    __shared__ uint32_t s_cnt[D][kTopChains / 64];
+    __shared__ uint32_t s_nlead[D];
+    // light-check queue: segment s covers items [s_seg_start[s], s_seg_start[s+1]) = entries x trees
+    __shared__ uint32_t s_seg_start[kMaxSeg + 1], s_seg_entries[kMaxSeg], s_seg_t0[kMaxSeg], s_seg_nt[kMaxSeg];
+    __shared__ uint32_t s_seg_kind_dd[kMaxSeg];  // kind << 8 | depth ; kind 0 same, 1 cross at the edge, 2 edge
+    __shared__ uint32_t s_seg_magic[kMaxSeg];    // floor(2^32 / entries) + 1: exact quotients below 2^16
+    __shared__ uint32_t s_nseg, s_grp;
+    __shared__ uint8_t s_g[kTopChains];            // chain -> proof of the group
+    __shared__ uint8_t s_bad[NT][kTopChains / 2];  // [tree][proof of the group] (Q >= 2: <= 128 proofs)
+    __shared__ uint64_t s_path[NT];                // word offset of the tree's path tiles
     __shared__ uint32_t s_len[NT], s_rootw[NT], s_code[NT];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t Q = lay.Q, G = lay.top_G, L = lay.L, K = lay.K, np = lay.np, nip = lay.nip;
     const uint32_t n_types = K + 3;
     const uint32_t n_groups = (lay.n + G - 1) / G;
-    const uint32_t Tmax = lay.T < L ? lay.T : L;
+    const uint32_t Tmax = lay.T < L ? lay.T : L;   // <= kTopMaxT
     const uint32_t *head = batch + lay.off_head;
     const uint4 *topn = reinterpret_cast<const uint4 *>(ws + lay.ws_top);
     uint4 *vals = reinterpret_cast<uint4 *>(ws + lay.ws_vals) + (size_t)blockIdx.x * 2 * n_types * kTopChains * 2;
@@ -635,164 +650,221 @@ __device__ __forceinline__ void stwo_top_body(const StwoLayout &lay, const uint3
     auto unpack = [](const H8 &h, uint32_t (&v)[8]) {
         v[0] = h.a.x; v[1] = h.a.y; v[2] = h.a.z; v[3] = h.a.w; v[4] = h.b.x; v[5] = h.b.y; v[6] = h.b.z; v[7] = h.b.w;
     };
+    const H8 zero8 = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
 
-    for (uint32_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    // Groups are handed out by a counter (zeroed before the launch), not by a fixed stride: the SIMD
+    // favours its oldest wave, so co-resident blocks do not advance at the same pace, and with a fixed
+    // share the fast ones would leave their CU half empty while the slow ones finish (measured: 2.8
+    // of 4 waves per SIMD on average).  Every block keeps fetching until the counter runs out.
+    uint32_t *counter = ws + lay.ws_counter;
+    while (true) {
+        __syncthreads();  // the previous group's LDS is no longer read
+        if (tid == 0) s_grp = atomicAdd(counter, 1u);
+        __syncthreads();
+        const uint32_t grp = s_grp;
+        if (grp >= n_groups) break;
         const uint32_t p0 = grp * G;
         const uint32_t gp = lay.n - p0 < G ? lay.n - p0 : G;  // proofs of this group
         const uint32_t nch = gp * Q, inst0 = p0 * Q;
-        __syncthreads();  // the previous group's LDS is no longer read
         if (tid < nch) {
             const uint32_t g = tid / Q, q = tid - g * Q;
             s_query[tid] = ws[lay.ws_ctx + (size_t)(lay.c_queries + q) * np + p0 + g];
+            s_g[tid] = (uint8_t)g;
         }
-        for (uint32_t i = tid; i < NT * kTopChains; i += kTopChains) (&s_bad[0][0])[i] = 0;
+        for (uint32_t i = tid; i < NT * (kTopChains / 2); i += kTopChains) (&s_bad[0][0])[i] = 0;
         __syncthreads();
 
-        // leaders / followers / slots of depth d into the parity-(d & 1) arrays; returns the leader count
-        auto plan = [&](uint32_t d) {
-            const uint32_t par = d & 1;
+        // ---- plan, all depths at once: leaders, followers, slots
+        const uint32_t first = tid - tid % Q;  // first chain of this chain's proof
+        uint64_t votes[D];
+        uint32_t lead_mask = 0;
+#pragma unroll
+        for (uint32_t dd = 0; dd < D; dd++) {
             bool lead = false;
-            if (tid < nch) {
-                const uint32_t pos = s_query[tid] >> (L - d);
+            if (dd <= Tmax && tid < nch) {
+                const uint32_t pos = s_query[tid] >> (L - dd);
                 uint32_t c0 = tid;
-                for (uint32_t c2 = tid - tid % Q; c2 < tid; c2++)
-                    if ((s_query[c2] >> (L - d)) == pos) { c0 = c2; break; }
+                for (uint32_t c2 = first; c2 < tid; c2++)
+                    if ((s_query[c2] >> (L - dd)) == pos) { c0 = c2; break; }
                 lead = c0 == tid;
-                s_leader[par][tid] = (uint16_t)c0;
+                s_lead[dd][tid] = (uint16_t)c0;
             }
-            const uint64_t vote = __ballot(lead);
-            if (lane == 0) s_cnt[par][wave] = (uint32_t)__popcll(vote);
-            __syncthreads();
-            uint32_t before = (uint32_t)__popcll(vote & ((1ull << lane) - 1)), nlead = 0;
+            votes[dd] = __ballot(lead);
+            lead_mask |= (uint32_t)lead << dd;
+            if (lane == 0) s_cnt[dd][wave] = (uint32_t)__popcll(votes[dd]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t dd = 0; dd < D; dd++) {
+            if (dd > Tmax) continue;
+            uint32_t before = (uint32_t)__popcll(votes[dd] & ((1ull << lane) - 1)), nlead = 0;
             for (uint32_t w = 0; w < kTopChains / 64; w++) {
-                if (w < wave) before += s_cnt[par][w];
-                nlead += s_cnt[par][w];
+                if (w < wave) before += s_cnt[dd][w];
+                nlead += s_cnt[dd][w];
             }
+            if (tid == 0) s_nlead[dd] = nlead;
             if (tid < nch) {
-                if (lead) { s_slot[par][tid] = (uint16_t)before; if (d < Tmax) s_item[before] = (uint16_t)tid; }
-                else s_fol[par][tid - before] = (uint16_t)tid;
+                if ((lead_mask >> dd) & 1) {
+                    s_item[dd][before] = (uint16_t)tid;
+                    s_slot[dd][tid] = (uint16_t)before;
+                    // the chain that leads the sibling position of this depth (the other child of the parent)
+                    uint16_t other = kNone;
+                    if (dd) {
+                        const uint32_t want = (s_query[tid] >> (L - dd)) ^ 1;
+                        for (uint32_t c2 = first, e = first + Q; c2 < e; c2++)
+                            if ((s_query[c2] >> (L - dd)) == want) { other = (uint16_t)c2; break; }
+                    }
+                    s_sibl[dd][before] = other;
+                } else {
+                    s_fol[dd][tid - before] = (uint16_t)tid;
+                }
             }
-            if (tid == 0) s_nfol[par] = nch - nlead;
-            __syncthreads();
-            if (tid < nch && !lead) s_slot[par][tid] = s_slot[par][s_leader[par][tid]];
-            return nlead;
-        };
-        // node of chain c (a leader of depth d+1, or any chain where the tree enters this kernel)
-        auto node_in = [&](uint32_t ti, uint32_t c, uint32_t d) {
+        }
+        __syncthreads();
+        if (tid < nch) {
+#pragma unroll
+            for (uint32_t dd = 0; dd < D; dd++)
+                if (dd <= Tmax && !((lead_mask >> dd) & 1)) s_slot[dd][tid] = s_slot[dd][s_lead[dd][tid]];
+        }
+        // ---- the light-check queue: for dd = Tmax..1, "same" over the trees of depth >= dd, then "cross
+        // at the edge" and "edge" (equal entering nodes) over the trees that enter this kernel at depth dd
+        if (tid == 0) {
+            uint32_t ns = 0, at = 0;
+            for (uint32_t dd = Tmax; dd >= 1; dd--) {
+                const uint32_t fri = L - dd < K + 1 ? L - dd : K + 1;  // FRI trees with len >= dd
+                auto magic = [](uint32_t v) { return v ? 0xffffffffu / v + 1 : 0; };  // v = 1: 0 (caught below)
+                s_seg_start[ns] = at; s_seg_entries[ns] = nch - s_nlead[dd]; s_seg_t0[ns] = 0; s_seg_nt[ns] = 2 + fri;
+                s_seg_kind_dd[ns] = dd; s_seg_magic[ns] = magic(s_seg_entries[ns]);
+                at += s_seg_entries[ns] * s_seg_nt[ns];
+                ns++;
+                // trees with top == dd: every tree of length >= T when dd == Tmax, else the FRI tree of length dd
+                uint32_t t0, nt;
+                if (dd == Tmax) { t0 = 0; nt = 2 + fri; }
+                else { const uint32_t l = L - 1 - dd; t0 = 2 + l; nt = l <= K ? 1 : 0; }
+                s_seg_start[ns] = at; s_seg_entries[ns] = s_nlead[dd]; s_seg_t0[ns] = t0; s_seg_nt[ns] = nt;
+                s_seg_kind_dd[ns] = 0x100 | dd; s_seg_magic[ns] = magic(s_seg_entries[ns]);
+                at += s_seg_entries[ns] * nt;
+                ns++;
+                s_seg_start[ns] = at; s_seg_entries[ns] = nch - s_nlead[dd]; s_seg_t0[ns] = t0; s_seg_nt[ns] = nt;
+                s_seg_kind_dd[ns] = 0x200 | dd; s_seg_magic[ns] = magic(s_seg_entries[ns]);
+                at += s_seg_entries[ns] * nt;
+                ns++;
+            }
+            s_seg_start[ns] = at;
+            s_nseg = ns;
+        }
+        __syncthreads();
+        const uint32_t nseg = s_nseg, n_light = s_seg_start[nseg];
+
+        // node of chain c at depth dd: from stwo_merkle_kernel where the tree enters, else the stored
+        // node of its leader (written at depth dd's step, parity dd & 1)
+        auto node_at = [&](uint32_t ti, uint32_t c, uint32_t dd) {
             const uint32_t len = s_len[ti];
             const uint32_t top = lay.T < len ? lay.T : len;
-            const uint4 *p = d + 1 == top
-                ? topn + ((size_t)ti * nip + inst0 + c) * 2
-                : vals + ((size_t)(((d + 1) & 1) * n_types + ti) * kTopChains + s_slot[(d + 1) & 1][c]) * 2;
+            const uint4 *p = dd == top ? topn + ((size_t)ti * nip + inst0 + c) * 2
+                                       : vals + ((size_t)((dd & 1) * n_types + ti) * kTopChains + s_slot[dd][c]) * 2;
             return H8{p[0], p[1]};
         };
 
-        plan(Tmax);  // positions where the longest trees enter: who must carry equal nodes
-        for (uint32_t d = Tmax; d-- > 0;) {
-            const uint32_t par = d & 1, prv = par ^ 1;
-            const uint32_t nlead = plan(d);
-            // the other child of each depth-d node: first chain of the proof at position (child ^ 1)
-            uint32_t has_cross = 0;
-            if (tid < nch && s_leader[par][tid] == tid) {
-                const uint32_t want = (s_query[tid] >> (L - d - 1)) ^ 1;
-                uint16_t other = kNone;
-                for (uint32_t c2 = tid - tid % Q, e = c2 + Q; c2 < e; c2++)
-                    if ((s_query[c2] >> (L - d - 1)) == want) { other = (uint16_t)c2; break; }
-                s_other[s_slot[par][tid]] = other;
-                has_cross = other != kNone;
+        // one light check: the loads now, the compare later (after the hash they hide behind)
+        struct Light { H8 a, b; uint32_t ti, g; };
+        uint32_t seg = 0;  // each lane walks the queue in increasing order
+        auto light_issue = [&](uint32_t i, Light &x) {
+            x.ti = NT;
+            x.a = x.b = zero8;
+            if (i >= n_light) return;
+            while (i >= s_seg_start[seg + 1]) seg++;
+            const uint32_t ent = s_seg_entries[seg], kd = s_seg_kind_dd[seg], dd = kd & 0xff, kind = kd >> 8;
+            const uint32_t r = i - s_seg_start[seg];
+            const uint32_t qt = ent == 1 ? r : __umulhi(r, s_seg_magic[seg]);  // r / ent: r < 2^16, ent <= 256
+            const uint32_t ti = s_seg_t0[seg] + qt, e = r - qt * ent;
+            const uint32_t lvl = s_len[ti] - dd;  // siblings of the step dd -> dd-1
+            if (kind == 1) {  // cross at the edge: leader c's entering node is what its sibling-position leader presents
+                const uint32_t c = s_item[dd][e], o = s_sibl[dd][e];
+                if (o == kNone) return;
+                x.a = node_at(ti, c, dd);
+                x.b = sibling(ti, inst0 + o, lvl);
+                x.g = s_g[c];
+            } else {
+                const uint32_t c = s_fol[dd][e], c1 = s_lead[dd][c];
+                if (kind == 0) {  // same: a follower presents the sibling its leader presents
+                    x.a = sibling(ti, inst0 + c, lvl);
+                    x.b = sibling(ti, inst0 + c1, lvl);
+                } else {          // edge: it enters with its leader's node
+                    x.a = node_at(ti, c, dd);
+                    x.b = node_at(ti, c1, dd);
+                }
+                x.g = s_g[c];
             }
-            const uint64_t vote = __ballot(has_cross != 0);
-            if (lane == 0) s_cnt[prv][wave] = (uint32_t)__popcll(vote);  // (s_cnt[prv] is free: plan(d+1) is long done)
-            __syncthreads();
-            uint32_t cbefore = (uint32_t)__popcll(vote & ((1ull << lane) - 1)), ncross = 0;
-            for (uint32_t w = 0; w < kTopChains / 64; w++) {
-                if (w < wave) cbefore += s_cnt[prv][w];
-                ncross += s_cnt[prv][w];
-            }
-            if (has_cross) s_cross[cbefore] = s_slot[par][tid];
-            __syncthreads();
-            const uint32_t nsame = s_nfol[prv];                          // followers of depth d+1
-            const uint32_t fri = L - 1 - d < K + 1 ? L - 1 - d : K + 1;  // FRI trees deeper than d
-            const uint32_t ntd = 2 + fri;
+            x.ti = ti;
+        };
+        auto light_settle = [&](const Light &x) {
+            if (x.ti < NT && differ(x.a, x.b)) s_bad[x.ti][x.g] = 1;
+        };
+        uint32_t li = tid;  // next light item of this lane
 
-            // ---- (i) chains at one position of depth d+1 present one sibling (and, where the tree
-            // enters this kernel, carry one node); four checks in flight per lane
-            auto same_checks = [&]() {
-                const uint32_t total = nsame * ntd;
-                for (uint32_t i0 = tid; i0 < total; i0 += 4 * kTopChains) {
-                    H8 a[4], b[4];
-                    uint32_t tis[4], cs[4];
-                    bool edge[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const uint32_t i = i0 + u * kTopChains;
-                        const bool on = i < total;
-                        const uint32_t ti = on ? i / nsame : 0, c = s_fol[prv][on ? i - ti * nsame : 0];
-                        const uint32_t c1 = s_leader[prv][c], len = s_len[ti];
-                        tis[u] = on ? ti : NT; cs[u] = c;
-                        edge[u] = on && d + 1 == (lay.T < len ? lay.T : len);
-                        if (on) { a[u] = sibling(ti, inst0 + c, len - 1 - d); b[u] = sibling(ti, inst0 + c1, len - 1 - d); }
-                        else { a[u] = b[u] = H8{make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)}; }
-                        if (edge[u]) {
-                            const H8 x = node_in(ti, c, d), y = node_in(ti, c1, d);
-                            if (differ(x, y)) s_bad[ti][c / Q] = 1;
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; u++)
-                        if (tis[u] < NT && differ(a[u], b[u])) s_bad[tis[u]][cs[u] / Q] = 1;
-                }
+        for (uint32_t d = Tmax; d-- > 0;) {
+            const uint32_t par = d & 1;
+            const uint32_t nlead = s_nlead[d];
+            const uint32_t fri = L - 1 - d < K + 1 ? L - 1 - d : K + 1;  // FRI trees deeper than d
+            const uint32_t total = nlead * (2 + fri);
+            const uint32_t nlead_magic = 0xffffffffu / nlead + 1;  // nlead >= 1: every proof has a chain
+            // ---- one hash per distinct node of depth d; the next item's bytes are fetched while this one
+            // is hashed, and two light checks ride along
+            H8 nd = zero8, sb = zero8, ys = zero8;
+            uint32_t ti = 0, k = 0, flags = 0;  // flags: 1 = the chain's node is the right child, 2 = has a sibling leader
+            auto fetch = [&](uint32_t i, H8 &nd_, H8 &sb_, H8 &ys_, uint32_t &ti_, uint32_t &k_, uint32_t &fl_) {
+                ti_ = nlead == 1 ? i : __umulhi(i, nlead_magic);  // i / nlead: i < 2^16, nlead <= 256
+                k_ = i - ti_ * nlead;
+                const uint32_t c = s_item[d][k_], len = s_len[ti_];
+                nd_ = node_at(ti_, c, d + 1);
+                sb_ = sibling(ti_, inst0 + c, len - 1 - d);
+                fl_ = (s_query[c] >> (L - d - 1)) & 1;
+                const uint32_t y = d ? s_sibl[d][k_] : kNone;
+                if (y != kNone) { ys_ = sibling(ti_, inst0 + y, len - d); fl_ |= 2; }
             };
-            // ---- (ii) the two children of a node agree about each other
-            auto cross_checks = [&]() {
-                for (uint32_t i = tid; i < ncross * ntd; i += kTopChains) {
-                    const uint32_t ti = i / ncross, k = s_cross[i - ti * ncross], c = s_item[k], o = s_other[k];
-                    const uint32_t lvl = s_len[ti] - 1 - d;
-                    const H8 nc = node_in(ti, c, d), no = node_in(ti, o, d);
-                    const H8 sc = sibling(ti, inst0 + c, lvl), so = sibling(ti, inst0 + o, lvl);
-                    if (differ(nc, so) || differ(no, sc)) s_bad[ti][c / Q] = 1;
-                }
-            };
-            // ---- one hash per distinct node; the next item's 64 bytes are fetched while this one is hashed
-            auto hashes = [&]() {
-                const uint32_t total = nlead * ntd;
-                auto fetch = [&](uint32_t i, H8 &nd, H8 &sb, uint32_t &ti, uint32_t &k, bool &right) {
-                    ti = i / nlead; k = i - ti * nlead;
-                    const uint32_t c = s_item[k];
-                    nd = node_in(ti, c, d);
-                    sb = sibling(ti, inst0 + c, s_len[ti] - 1 - d);
-                    right = (s_query[c] >> (L - d - 1)) & 1;  // the chain's node is the right child
-                };
-                H8 nd, sb;
-                uint32_t ti = 0, k = 0;
-                bool right = false;
-                if (tid < total) fetch(tid, nd, sb, ti, k, right);
-                for (uint32_t i = tid; i < total; i += kTopChains) {
-                    H8 nd2 = nd, sb2 = sb;
-                    uint32_t ti2 = ti, k2 = k;
-                    bool right2 = right;
-                    if (i + kTopChains < total) fetch(i + kTopChains, nd2, sb2, ti2, k2, right2);
-                    uint32_t a[8], b[8], lft[8], rgt[8], out[8];
-                    unpack(nd, a);
-                    unpack(sb, b);
+            if (tid < total) fetch(tid, nd, sb, ys, ti, k, flags);
+            for (uint32_t i = tid; i < total; i += kTopChains) {
+                H8 nd2 = zero8, sb2 = zero8, ys2 = zero8;
+                uint32_t ti2 = 0, k2 = 0, flags2 = 0;
+                if (i + kTopChains < total) fetch(i + kTopChains, nd2, sb2, ys2, ti2, k2, flags2);
+                Light x0, x1;
+                light_issue(li, x0);
+                light_issue(li + kTopChains, x1);
+                li += 2 * kTopChains;
+                uint32_t a[8], b[8], lft[8], rgt[8], out[8];
+                unpack(nd, a);
+                unpack(sb, b);
+                const bool right = flags & 1;
 #pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        lft[j] = right ? b[j] : a[j];
-                        rgt[j] = right ? a[j] : b[j];
-                    }
-                    Hasher<HF>::template pair<true>(lft, rgt, out);
-                    uint4 *o = vals + ((size_t)(par * n_types + ti) * kTopChains + k) * 2;
-                    o[0] = make_uint4(out[0], out[1], out[2], out[3]);
-                    o[1] = make_uint4(out[4], out[5], out[6], out[7]);
-                    nd = nd2; sb = sb2; ti = ti2; k = k2; right = right2;
+                for (int j = 0; j < 8; j++) {
+                    lft[j] = right ? b[j] : a[j];
+                    rgt[j] = right ? a[j] : b[j];
                 }
-            };
-            // Blocks that share a CU run the same schedule; alternating the order keeps the latency-bound
-            // checks of one block over the ALU-bound hashes of its neighbour.
-            if (blockIdx.x & 1) { hashes(); same_checks(); cross_checks(); }
-            else { same_checks(); cross_checks(); hashes(); }
+                Hasher<HF>::template pair<true>(lft, rgt, out);
+                const H8 o8 = {make_uint4(out[0], out[1], out[2], out[3]), make_uint4(out[4], out[5], out[6], out[7])};
+                uint4 *o = vals + ((size_t)(par * n_types + ti) * kTopChains + k) * 2;
+                o[0] = o8.a;
+                o[1] = o8.b;
+                // (ii): the leader of the sibling position presents this node as its sibling
+                if ((flags & 2) && differ(o8, ys)) s_bad[ti][s_g[s_item[d][k]]] = 1;
+                light_settle(x0);
+                light_settle(x1);
+                nd = nd2; sb = sb2; ys = ys2; ti = ti2; k = k2; flags = flags2;
+            }
             __syncthreads();
         }
+        // ---- whatever is left of the queue, four in flight
+        while (true) {
+            Light x[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) light_issue(li + u * kTopChains, x[u]);
+#pragma unroll
+            for (int u = 0; u < 4; u++) light_settle(x[u]);
+            li += 4 * kTopChains;
+            if (li - tid >= n_light) break;  // uniform over the block: li - tid is the same in every lane
+        }
+        __syncthreads();
 
         // ---- roots: at depth 0 proof g's only leader is its first chain, slot g
         for (uint32_t i = tid; i < gp * n_types; i += kTopChains) {

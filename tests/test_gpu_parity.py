@@ -585,3 +585,62 @@ def test_pair_memoisation_equals_full_hashing(stwo_small, stwo_prod, name):
         v.close()
     assert results[0].tolist() == want.tolist() and results[1].tolist() == want.tolist()
     assert (want[:3] == 0).all() and (want != 0).sum() > 50
+
+
+# --------------------------------------------------------- text ingestion (native readers)
+def test_text_ingestion_gives_the_record_path_verdicts(ver, tmp_path, stwo_small, stwo_prod):
+    """ss_stwo_verify_texts / _files: proof.json and proof.wit texts parsed by the library, verified
+    against the expected config.  Verdicts equal the Python reader + record path + oracle; other
+    shapes are status 1, unreadable texts status 2, and nothing of that depends on the batch mix."""
+    import json
+    import os
+    import stark_symphony_amd as ss
+    from stark_symphony_amd import binding
+    from conftest import GOLDEN
+    rng = np.random.default_rng(SEED + 41)
+    bad = [formats.stwo_corrupt(stwo_prod, rng)[0] for _ in range(6)]
+    short = stwo_prod.copy(); short.fri_paths[1][3] = short.fri_paths[1][3][:-2]   # ragged: .wit only
+    proofs = [stwo_prod] + bad
+    texts = [json.dumps(ss.stwo_to_json(p)).encode() for p in proofs] + [ss.stwo_to_wit(p).encode() for p in proofs + [short]]
+    want = O.stwo_verify_batch(proofs).tolist() + O.stwo_verify_batch(proofs + [short]).tolist()
+    texts += [json.dumps(ss.stwo_to_json(stwo_small)).encode(), ss.stwo_to_wit(stwo_small).encode(),
+              b"{\"config\": 1}", b"", texts[0][:5000]]
+    want += [1, 1, 2, 2, 2]
+    status, stats = ver.verify_stwo_texts(stwo_prod.cfg, texts)
+    assert status.tolist() == want
+    assert stats["threads"] >= 1 and stats["parse_s"] > 0 and stats["total_s"] >= stats["parse_s"]
+    assert stats["text_bytes"] == sum(len(t) for t in texts)
+    paths = []
+    for i, t in enumerate(texts):
+        paths.append(str(tmp_path / ("p%d.txt" % i)))
+        open(paths[-1], "wb").write(t)
+    paths.append(str(tmp_path / "absent.json"))
+    status, _ = ver.verify_stwo_files(stwo_prod.cfg, paths)
+    assert status.tolist() == want + [2]
+    # forcing the wrong reader on a text is a malformed witness, not a crash
+    assert ver.verify_stwo_texts(stwo_prod.cfg, texts[:1], fmt=binding.TEXT_WIT)[0].tolist() == [2]
+    # literal mode and the testing profile through the same entry point
+    st, _ = ver.verify_stwo_texts(stwo_prod.cfg, texts[:2], verifier.MODE_LITERAL)
+    assert st.tolist() == O.stwo_verify_batch(proofs[:2], O.MODE_LITERAL).tolist()
+    st, _ = ver.verify_stwo_files(stwo_small.cfg, [os.path.join(GOLDEN, "stwo_proof_test.json"),
+                                                   os.path.join(GOLDEN, "formats", "stwo_proof_test.wit"),
+                                                   os.path.join(GOLDEN, "stwo_proof.json")])
+    assert st.tolist() == [0, 0, 1]
+
+
+def test_stark101_text_ingestion(ver, tmp_path, s101_proof):
+    import json
+    import os
+    import stark_symphony_amd as ss
+    from conftest import GOLDEN
+    rng = np.random.default_rng(SEED + 42)
+    proofs = [s101_proof] + [formats.stark101_corrupt(s101_proof, rng)[0] for _ in range(9)]
+    p = s101_proof.copy(); p.layers = p.layers[:6]; proofs.append(p)                       # ragged shapes
+    p = s101_proof.copy(); p.evals[2].path = p.evals[2].path[:5]; proofs.append(p)
+    texts = [json.dumps(ss.stark101_to_json(q)).encode() for q in proofs] + [ss.stark101_to_wit(q).encode() for q in proofs]
+    want = O.s101_verify_batch(proofs).tolist() * 2
+    status, stats = ver.verify_stark101_texts(texts + [b"{}", b"nonsense"])
+    assert status.tolist() == want + [2, 2] and stats["threads"] >= 1
+    st, _ = ver.verify_stark101_files([os.path.join(GOLDEN, "stark101_proof.json"),
+                                       os.path.join(GOLDEN, "formats", "stark101_proof.wit"), str(tmp_path / "none")])
+    assert st.tolist() == [0, 0, 2]

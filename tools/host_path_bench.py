@@ -22,7 +22,7 @@ status = np.zeros(n, dtype=np.uint32)
 lib = B.lib()
 for rep in range(3):
     t0 = time.perf_counter()
-    B.check(lib.ss_stwo_verify_records(ver.ctx, C.byref(cfg), n, ptrs, None, status.ctypes.data))
+    B.check(lib.ss_stwo_verify_records(ver.ctx, C.byref(cfg), n, ptrs, status.ctypes.data))
     dt = time.perf_counter() - t0
     assert (status == 0).all()
     print("host path: %d proofs in %.3f s = %.0f proofs/s, %.2f GB/s of records"
