@@ -312,8 +312,8 @@ extern "C" int ss_stwo_pack(const ss_stwo_cfg *c, size_t n, const uint32_t *cons
 }
 
 // Blocks of the persistent top kernel that are resident at once: from the kernel's own register and
-// LDS footprint (512 VGPRs per SIMD lane in granules of 8, 160 KB LDS per CU; one 256-thread block
-// puts one wave on each of the CU's four SIMDs).  The grid must not exceed this, or the surplus blocks
+// LDS footprint (512 VGPRs per SIMD lane in granules of 8, 160 KB LDS per CU; a block's
+// kTopChains / 64 waves go to different SIMDs of the CU).  The grid must not exceed this, or the surplus blocks
 // run after the others at a fraction of the occupancy.
 static int top_resident_blocks(ss_ctx *ctx, int hf)
 {
@@ -324,7 +324,7 @@ static int top_resident_blocks(ss_ctx *ctx, int hf)
         if (hipFuncGetAttributes(&a, fn) == hipSuccess && a.numRegs > 0) {
             const int by_regs = 512 / ((a.numRegs + 7) / 8 * 8);
             const int by_lds = a.sharedSizeBytes ? (int)((160u << 10) / a.sharedSizeBytes) : 8;
-            per_cu = std::max(1, std::min(8, std::min(by_regs, by_lds)));
+            per_cu = std::max(1, std::min(16, std::min(by_regs * 4 / (int)(kTopChains / 64), by_lds)));
         }
         ctx->top_blocks_per_cu[hf] = per_cu;
     }
@@ -356,7 +356,8 @@ extern "C" int ss_stwo_verify_phase_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_
                            dim3((y.n + 63) / 64), dim3(64), 0, s, y, batch, ws, status);
         t.end("stwo_transcript");
         t.begin();
-        hipLaunchKernelGGL(stwo_query_kernel, dim3((y.ni + 63) / 64), dim3(64), 0, s, y, batch, ws, status);
+        hipLaunchKernelGGL(stwo_query_kernel, dim3((y.ni + 63) / 64), dim3(64), 2 * (y.K + 3) * 64 * 4, s, y, batch,
+                           ws, status);
         t.end("stwo_query");
     }
     if (phases & SS_PHASE_TAIL) {

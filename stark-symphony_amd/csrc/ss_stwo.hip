@@ -310,14 +310,16 @@ stwo_transcript_kernel_b2s(StwoLayout lay, const uint32_t *__restrict__ batch, u
 // All values are canonical field elements, so this re-association is exact.  The K+1 fold
 // inverses and the (one or two) DEEP denominator norms share ONE m31 inversion (Montgomery's
 // trick); a raw zero still reports the reference's abort code for exactly that inverse.
-constexpr int kInvSlots = kMaxList + 4;
 
 __global__ void __launch_bounds__(64)
 stwo_query_kernel(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,
                   uint32_t *__restrict__ status)
 {
-    __shared__ uint32_t sh_u[kInvSlots][64];
-    __shared__ uint32_t sh_p[kInvSlots][64];
+    // batched-inversion scratch, sized by the launch for THIS config: 2 x (K + 3) rows of 64 words
+    // (a fixed [K_max + 4] array held the kernel at 2 waves per SIMD: 17.9 KB per wave)
+    extern __shared__ uint32_t sh_inv[];
+    uint32_t (*sh_u)[64] = reinterpret_cast<uint32_t (*)[64]>(sh_inv);
+    uint32_t (*sh_p)[64] = reinterpret_cast<uint32_t (*)[64]>(sh_inv + (lay.K + 3) * 64);
     const uint32_t inst = blockIdx.x * blockDim.x + threadIdx.x;
     if (inst >= lay.ni) return;
     const uint32_t lane = threadIdx.x;

@@ -92,7 +92,10 @@ class GraphedPipeline:
     the capture crashes hipStreamEndCapture on ROCm 7.0 (tools/probes/graph_capture_probe.py).
     Per-kernel timing (`Verifier.set_timing`) must be off: timing events cannot be captured."""
 
-    def __init__(self, slots: Sequence["_DeviceBatch"]):
+    def __init__(self, slots: Sequence["_DeviceBatch"], concurrent_tails: bool = False):
+        """concurrent_tails: every slot is its own branch of the graph (HEAD then TAIL on its own
+        stream), so the Merkle kernels of different slots overlap too.  For batches too small to
+        fill the chip on their own (stark101 x 4096 is 1 472 short waves for 1 024 SIMDs)."""
         torch = _torch()
         ver = slots[0].ver
         if ver.timing:
@@ -100,8 +103,12 @@ class GraphedPipeline:
         self.slots = list(slots)
         self.steps_per_replay = len(self.slots)
         self.stream = torch.cuda.Stream(device=ver.device)
-        pipe = Pipeline(self.slots)
-        branches = pipe.head_streams + [pipe.tail_stream]
+        if concurrent_tails:
+            pipe = None
+            branches = [torch.cuda.Stream(device=ver.device) for _ in self.slots]
+        else:
+            pipe = Pipeline(self.slots)
+            branches = pipe.head_streams + [pipe.tail_stream]
         self.graph = torch.cuda.CUDAGraph()
         torch.cuda.synchronize(ver.device)
         with torch.cuda.graph(self.graph, stream=self.stream):
@@ -109,13 +116,17 @@ class GraphedPipeline:
             fork.record(self.stream)
             for s in branches:
                 s.wait_event(fork)
-            for _ in self.slots:
-                pipe.submit()
+            if concurrent_tails:
+                for slot, s in zip(self.slots, branches):
+                    slot.run(s, PHASE_ALL)
+            else:
+                for _ in self.slots:
+                    pipe.submit()
             for s in branches:
                 join = torch.cuda.Event()
                 join.record(s)
                 self.stream.wait_event(join)
-        self._pipe = pipe  # keeps the captured streams and events alive
+        self._pipe, self._branches = pipe, branches  # keeps the captured streams and events alive
 
     def replay(self) -> int:
         """Enqueue one pass over every slot; returns the number of passes."""

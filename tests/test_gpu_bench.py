@@ -81,3 +81,15 @@ def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--workload", "stwo_fixture"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode != 0 and "disagrees" in r.stderr
+
+
+def test_bench_stark101_graphed_submission():
+    """BASELINE.json configs[1] (stark101 x 4096) is launch-bound: bench.py replays hipGraphs of
+    independent slots for the timed steps and takes the kernel durations from an eager pass."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "stark101", "--steps", "24",
+                        "--warmup", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["steps"] == 24 and d["config"]["proofs_per_gpu"] == 4096 and "hipGraph" in d["config"]["submission"]
+    assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["roofline"]["kernel"] == "s101_merkle" and d["roofline"]["kernel_launches"] == 20

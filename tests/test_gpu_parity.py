@@ -328,7 +328,8 @@ def test_stwo_full_size_batch_2p20(ver):
     assert b.accepted() == sum(1 for i in idx if want_d[i] == 0) >= n // 2
 
 
-def test_graphed_pipeline_matches_eager(ver, s101_proof, stwo_prod):
+@pytest.mark.parametrize("concurrent", [False, True])
+def test_graphed_pipeline_matches_eager(ver, s101_proof, stwo_prod, concurrent):
     """hipGraph replay of the pipelined passes (fork / join of the head and tail streams captured
     once) leaves the same status words and accept counts as eager submission."""
     rng = np.random.default_rng(SEED + 17)
@@ -345,7 +346,7 @@ def test_graphed_pipeline_matches_eager(ver, s101_proof, stwo_prod):
             batch = ver.stwo_batch([distinct[i] for i in idx])
         want = [int(want_d[i]) for i in idx]
         slots = [batch, batch.sibling(), batch.sibling()]
-        gp = verifier.GraphedPipeline(slots)
+        gp = verifier.GraphedPipeline(slots, concurrent_tails=concurrent)
         assert gp.steps_per_replay == 3
         for _ in range(3):
             for s in slots:
