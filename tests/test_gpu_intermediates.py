@@ -14,23 +14,6 @@ pytestmark = pytest.mark.gpu
 SEED = 0x5EED2025
 
 
-def _layout(cfg, n):
-    """Workspace offsets of csrc/ss_layout.h (words)."""
-    N, Q, K = cfg.n_cols, cfg.n_queries, cfg.n_layers
-    np_ = (n + 63) // 64 * 64
-    nip = (n * Q + 63) // 64 * 64
-    c = {"queries": 0}
-    at = Q
-    for name, words in (("p", 8), ("p2", 8), ("b01", 4), ("b02", 4), ("a1", 4), ("c1", 4), ("a2", 4), ("c2", 4),
-                        ("m1", 4), ("fold", 4 * (K + 1))):
-        c[name] = at
-        at += words
-    ctx_words = at
-    ws_alpha = ctx_words * np_
-    ws_leaf = ws_alpha + (N + 16) * 4 * np_
-    return c, np_, nip, ws_alpha, ws_leaf
-
-
 @pytest.mark.parametrize("mode", [verifier.MODE_FIXTURE, verifier.MODE_LITERAL])
 @pytest.mark.parametrize("which", ["small", "prod"])
 def test_head_kernels_leave_the_oracles_intermediates(stwo_small, stwo_prod, mode, which):
@@ -48,21 +31,26 @@ def test_head_kernels_leave_the_oracles_intermediates(stwo_small, stwo_prod, mod
     b = ver.stwo_batch(proofs, mode)
     b.run()
     status = b.status()
-    ws = b.ws.cpu().numpy().view(np.uint32)
-    c, np_, nip, ws_alpha, ws_leaf = _layout(cfg, n)
-    ctx = lambda w, p: int(ws[w * np_ + p])  # noqa: E731
+    lay = _ws_layout(b)
+    assert lay.total_words * 4 <= b.ws.numel() * 4 and lay.np % 64 == 0 and lay.nip >= n * Q
     for pi, proof in enumerate(proofs):
         st, tr = O.stwo_verify(proof, mode, trace=True)
         assert int(status[pi]) == st
-        assert [ctx(c["queries"] + q, pi) for q in range(Q)] == list(tr.queries[:Q])
-        got_p = [ctx(c["p"] + w, pi) for w in range(8)]
-        assert got_p == list(tr.oods_point.x.t()) + list(tr.oods_point.y.t())
-        for l in range(K + 1):
-            assert [ctx(c["fold"] + 4 * l + w, pi) for w in range(4)] == list(tr.fold_alpha[l].t())
-        alpha1 = [int(ws[ws_alpha + (pi * (cfg.n_cols + 16)) * 4 + w]) for w in range(4)]
-        assert alpha1 == list(tr.deep_alpha.t())
-        for q in range(Q):  # fri_answer: the evaluation the query kernel feeds into the first fold
-            inst = pi * Q + q
-            half = 4 if tr.queries[q] & 1 else 0
-            ans = [int(ws[ws_leaf + (half + w) * nip + inst]) for w in range(4)]
-            assert ans == list(tr.answers[q].t()), (pi, q, mode)
+        got = b.intermediates(pi)  # ss_stwo_read_intermediates
+        assert got["queries"].tolist() == list(tr.queries[:Q])
+        assert got["oods_point"].tolist() == list(tr.oods_point.x.t()) + list(tr.oods_point.y.t())
+        assert got["fold_alphas"].tolist() == [list(tr.fold_alpha[l].t()) for l in range(K + 1)]
+        assert got["deep_alpha"].tolist() == list(tr.deep_alpha.t())
+        # fri_answer: the evaluation the query kernel feeds into the first fold
+        assert got["fri_answers"].tolist() == [list(tr.answers[q].t()) for q in range(Q)], (pi, mode)
+        # the exported layout addresses the same words (a caller that reads the workspace itself)
+        ws = b.ws.cpu().numpy().view(np.uint32)
+        assert [int(ws[lay.ctx + (lay.c_queries + q) * lay.np + pi]) for q in range(Q)] == list(tr.queries[:Q])
+
+
+def _ws_layout(b):
+    import ctypes as C
+    from stark_symphony_amd import binding
+    lay = binding.StwoWsLayout()
+    binding.check(binding.lib().ss_stwo_ws_layout_of(C.byref(b.cs), b.n, C.byref(lay)))
+    return lay
