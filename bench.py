@@ -313,8 +313,8 @@ def main() -> None:
         from stark_symphony_amd import formats
         c = proofs[0].cfg if proofs else formats.StwoConfig(**GEN_ONLY[wname])
         gp = prover.GpuProver(ver)
-        made = [ss.stwo_from_json(gp.prove(c.n_cols, c.trace_log, c.log_blowup, c.n_queries, c.pow_bits,
-                                           seed=s + rank * args.distinct, hash=c.hash))
+        made = [gp.prove_proof(c.n_cols, c.trace_log, c.log_blowup, c.n_queries, c.pow_bits,
+                               seed=s + rank * args.distinct, hash=c.hash)
                 for s in range(args.distinct)]
         if rank == 0 and proofs:
             assert ss.stwo_to_json(made[0]) == ss.stwo_to_json(proofs[0]), "GPU prover != committed proof"

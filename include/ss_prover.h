@@ -70,6 +70,12 @@ int ss_p_composition(ss_ctx *ctx, uint32_t n_log, uint32_t n_cols, const uint32_
 int ss_p_eval_at_point(ss_ctx *ctx, uint32_t m, const uint32_t *coeffs, const uint32_t *factors_host,
                        uint32_t *scratch, uint32_t *out, void *stream);
 
+/* The same for `ncols` columns (stride col_stride words) at ONE point: m launches in all, not m
+ * per column; scratch holds ncols * 3 * 2^m words, out[ncols][4].                              */
+int ss_p_eval_at_point_batch(ss_ctx *ctx, uint32_t m, uint32_t ncols, const uint32_t *coeffs,
+                             size_t col_stride, const uint32_t *factors_host, uint32_t *scratch,
+                             uint32_t *out, void *stream);
+
 /* DEEP quotient row of every LDE position (two batches: trace columns sampled at P, the 16
  * composition columns at 2P; row = b1 alpha^16 + b2).  hx_hy = pair x then pair y of the LDE
  * coset (2^(lde_log-1) words each); bcoef = the b line coefficient of every column already
@@ -82,6 +88,16 @@ int ss_p_quotients(ss_ctx *ctx, uint32_t lde_log, uint32_t n_cols, const uint32_
 /* One FRI fold: out[i] = (v[2i] + v[2i+1]) + alpha * (v[2i] - v[2i+1]) * coord_inv[i].       */
 int ss_p_fri_fold(ss_ctx *ctx, size_t n_out, const uint32_t *in, const uint32_t *coord_inv,
                   const uint32_t alpha[4], uint32_t *out, void *stream);
+
+/* The FRI commit loop without host round trips.  state_dev = the Fiat-Shamir channel in device
+ * memory: 8 stored digest words + the draw counter (channel.simf:31-172).
+ * ss_p_channel_fri_layer = fri_layer_commit (fri/commit.simf:34-46): digest <- H(digest || root),
+ * alpha <- channel_draw_qm31; root_dev points at the tree's root node (8 stored words), which is
+ * also copied to root_out_dev; alpha_out_dev receives the 4 words ss_p_fri_fold_dev reads.      */
+int ss_p_channel_fri_layer(ss_ctx *ctx, uint32_t hash, uint32_t *state_dev, const uint32_t *root_dev,
+                           uint32_t *alpha_out_dev, uint32_t *root_out_dev, void *stream);
+int ss_p_fri_fold_dev(ss_ctx *ctx, size_t n_out, const uint32_t *in, const uint32_t *coord_inv,
+                      const uint32_t *alpha_dev, uint32_t *out, void *stream);
 
 /* Smallest nonce >= start with LE64(last 8 bytes of H(digest || be8(nonce))) < target, searched
  * in [start, start + count); *nonce_out = UINT64_MAX if none.  digest: 8 stored words.       */

@@ -9,6 +9,7 @@
 #include <cstdio>
 
 #include "../../include/ss_prover.h"
+#include "ss_channel.h"
 #include "ss_fields.h"
 #include "ss_hash.h"
 #include "ss_layout.h"
@@ -318,6 +319,50 @@ __global__ void p_fold_qm31_kernel(size_t n_out, const uint32_t *__restrict__ in
     stq(out + 4 * j, qm31_add(ldq(in + 8 * j), qm31_mul(ldq(in + 8 * j + 4), f)));
 }
 
+// the same two folds over `ncols` columns at once (blockIdx.y = column): the OODS samples of all
+// columns of a commitment share the point, so they share the factors and the launches
+__global__ void p_fold_m31_batch_kernel(size_t n_out, const uint32_t *__restrict__ in, size_t in_stride, QM31 f,
+                                        uint32_t *__restrict__ out, size_t out_stride)
+{
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_out) return;
+    const uint32_t *src = in + (size_t)blockIdx.y * in_stride;
+    QM31 r = qm31_mul_m31(f, src[2 * j + 1]);
+    r.a = m31_add(r.a, src[2 * j]);
+    stq(out + (size_t)blockIdx.y * out_stride + 4 * j, r);
+}
+__global__ void p_fold_qm31_batch_kernel(size_t n_out, const uint32_t *__restrict__ in, size_t in_stride, QM31 f,
+                                         uint32_t *__restrict__ out, size_t out_stride)
+{
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_out) return;
+    const uint32_t *src = in + (size_t)blockIdx.y * in_stride;
+    stq(out + (size_t)blockIdx.y * out_stride + 4 * j, qm31_add(ldq(src + 8 * j), qm31_mul(ldq(src + 8 * j + 4), f)));
+}
+
+// ------------------------------------------------------------- device-side FRI commit channel
+// fri_layer_commit (fri/commit.simf:34-46) on the device: digest <- H(digest || root), alpha <-
+// draw_qm31.  state = 8 STORED digest words + the draw counter.  One lane: the channel is a
+// dependent chain of two to three compressions per layer; running it here removes the host round
+// trip (root download, hashlib, alpha upload) between a layer's Merkle tree and its fold.
+template <int HF>
+__global__ void p_channel_fri_layer_kernel(uint32_t *__restrict__ state, const uint32_t *__restrict__ root,
+                                           uint32_t *__restrict__ alpha_out, uint32_t *__restrict__ root_out)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    Channel<HF> ch;
+    for (int i = 0; i < 8; i++) ch.dig.v[i] = Hasher<HF>::native(state[i]);
+    ch.ctr = state[8];
+    uint32_t r[8];
+    for (int i = 0; i < 8; i++) { r[i] = root[i]; root_out[i] = r[i]; }
+    ch.mix(r);
+    QM31 a;
+    ch.draw_qm31(a);
+    stq(alpha_out, a);
+    for (int i = 0; i < 8; i++) state[i] = Hasher<HF>::native(ch.dig.v[i]);
+    state[8] = ch.ctr;
+}
+
 // ------------------------------------------------------------------------------ quotients
 struct QuotArgs {
     QM31 px, py, p2x, p2y, a1, c1, a2, c2, alpha16;
@@ -333,27 +378,80 @@ __device__ __forceinline__ CM31 deep_den_inv(QM31 sx, QM31 sy, uint32_t x, uint3
     return inv;
 }
 
-__global__ void p_quotients_kernel(uint32_t lde_log, uint32_t n_cols, const uint32_t *__restrict__ trace_lde,
-                                   const uint32_t *__restrict__ cp_lde, const uint32_t *__restrict__ hx,
-                                   const uint32_t *__restrict__ hy, const uint32_t *__restrict__ bcoef, QuotArgs q,
-                                   uint32_t *__restrict__ out)
+// One thread = the storage pair (2h, 2h+1): the two positions share x and have y, -y.  The column
+// sums are open 64-bit multiply-accumulates (one v_mad_u64_u32 per product, folded every third
+// product, reduced once per word); the four DEEP denominators (two sample points x two positions)
+// share ONE M31 inversion.  All operands are canonical field elements, so every re-association gives
+// the bits of the straightforward evaluation (which tools/stwo_prover.py performs).
+__global__ void __launch_bounds__(256)
+p_quotients_kernel(uint32_t lde_log, uint32_t n_cols, const uint32_t *__restrict__ trace_lde,
+                   const uint32_t *__restrict__ cp_lde, const uint32_t *__restrict__ hx,
+                   const uint32_t *__restrict__ hy, const uint32_t *__restrict__ bcoef, QuotArgs q,
+                   uint32_t *__restrict__ out)
 {
     const size_t size = (size_t)1 << lde_log;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= size) return;
-    const uint32_t x = hx[i >> 1];
-    uint32_t y = hy[i >> 1];
-    if (i & 1) y = m31_sub(0, y);
-    QM31 s1 = qm31_zero(), s2 = qm31_zero();
-    for (uint32_t k = 0; k < n_cols; k++)
-        s1 = qm31_add(s1, qm31_mul_m31(ldq(bcoef + 4 * k), trace_lde[(size_t)k * size + i]));
-    for (uint32_t k = 0; k < kCp; k++)
-        s2 = qm31_add(s2, qm31_mul_m31(ldq(bcoef + 4 * (n_cols + k)), cp_lde[(size_t)k * size + i]));
-    QM31 n1 = qm31_sub(s1, qm31_add(qm31_mul_m31(q.a1, y), q.c1));
-    QM31 n2 = qm31_sub(s2, qm31_add(qm31_mul_m31(q.a2, y), q.c2));
-    QM31 b1 = qm31_mul_cm31(n1, deep_den_inv(q.px, q.py, x, y));
-    QM31 b2 = qm31_mul_cm31(n2, deep_den_inv(q.p2x, q.p2y, x, y));
-    stq(out + 4 * i, qm31_add(qm31_mul(b1, q.alpha16), b2));
+    const size_t h = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= (size >> 1)) return;
+    const uint32_t x = hx[h], y0 = hy[h];
+    const uint32_t ys[2] = {y0, m31_sub_c(0, y0)};
+    // s[batch][position] = sum_k b_k v_k
+    auto dot = [&](const uint32_t *lde, const uint32_t *coef, uint32_t count, QM31 (&res)[2]) {
+        uint64_t acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        uint32_t open = 0;
+        for (uint32_t k = 0; k < count; k++) {
+            const uint2 v = *reinterpret_cast<const uint2 *>(lde + (size_t)k * size + 2 * h);
+            const uint4 c = *reinterpret_cast<const uint4 *>(coef + 4 * k);
+            acc[0][0] = m31_mac(acc[0][0], c.x, v.x); acc[0][1] = m31_mac(acc[0][1], c.y, v.x);
+            acc[0][2] = m31_mac(acc[0][2], c.z, v.x); acc[0][3] = m31_mac(acc[0][3], c.w, v.x);
+            acc[1][0] = m31_mac(acc[1][0], c.x, v.y); acc[1][1] = m31_mac(acc[1][1], c.y, v.y);
+            acc[1][2] = m31_mac(acc[1][2], c.z, v.y); acc[1][3] = m31_mac(acc[1][3], c.w, v.y);
+            if (++open == 3) {
+#pragma unroll
+                for (int p = 0; p < 2; p++)
+#pragma unroll
+                    for (int w = 0; w < 4; w++) acc[p][w] = m31_fold62(acc[p][w]);
+                open = 0;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+            res[p] = QM31{m31_red64(acc[p][0]), m31_red64(acc[p][1]), m31_red64(acc[p][2]), m31_red64(acc[p][3])};
+    };
+    QM31 s1[2], s2[2];
+    dot(trace_lde, bcoef, n_cols, s1);
+    dot(cp_lde, bcoef + 4 * n_cols, kCp, s2);
+    // deep_quotient_denominator_inverse (deep/quotients.simf:15-22) for (P, 2P) x (y, -y)
+    CM31 d[4];
+    uint32_t nrm[4], pre[4];
+    uint32_t run = 1;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const QM31 sx = j < 2 ? q.px : q.p2x, sy = j < 2 ? q.py : q.p2y;
+        const CM31 dx = cm31_sub_m31(q_re(sx), x), dy = cm31_sub_m31(q_re(sy), ys[j & 1]);
+        d[j] = cm31_sub(cm31_mul(dx, q_im(sy)), cm31_mul(dy, q_im(sx)));
+        nrm[j] = m31_add(m31_sqr(d[j].a), m31_sqr(d[j].b));
+        pre[j] = run;
+        run = m31_mul(run, nrm[j] ? nrm[j] : 1u);  // a zero norm inverts to 0, as cm31_inv gives
+    }
+    uint32_t inv;
+    m31_inv(run, inv);
+    CM31 dinv[4];
+#pragma unroll
+    for (int j = 3; j >= 0; j--) {
+        const uint32_t ni = nrm[j] ? m31_mul(inv, pre[j]) : 0u;
+        inv = m31_mul(inv, nrm[j] ? nrm[j] : 1u);
+        dinv[j] = cm31_mul_m31(CM31{d[j].a, m31_neg(d[j].b)}, ni);
+    }
+    const QM31 a1y = qm31_mul_m31(q.a1, y0), a2y = qm31_mul_m31(q.a2, y0);
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        // a * (-y) = -(a * y)
+        const QM31 t1 = p ? qm31_sub(q.c1, a1y) : qm31_add(a1y, q.c1);
+        const QM31 t2 = p ? qm31_sub(q.c2, a2y) : qm31_add(a2y, q.c2);
+        const QM31 b1 = qm31_mul_cm31(qm31_sub(s1[p], t1), dinv[p]);
+        const QM31 b2 = qm31_mul_cm31(qm31_sub(s2[p], t2), dinv[2 + p]);
+        stq(out + 4 * (2 * h + p), qm31_add(qm31_mul(b1, q.alpha16), b2));
+    }
 }
 
 // ------------------------------------------------------------------------------- fri fold
@@ -362,6 +460,19 @@ __global__ void p_fri_fold_kernel(size_t n_out, const uint32_t *__restrict__ in,
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_out) return;
+    const QM31 v0 = ldq(in + 8 * i), v1 = ldq(in + 8 * i + 4);
+    const QM31 f0 = qm31_add(v0, v1);
+    const QM31 f1 = qm31_mul_m31(qm31_sub(v0, v1), cinv[i]);
+    stq(out + 4 * i, qm31_add(f0, qm31_mul(f1, alpha)));
+}
+
+// the same fold with alpha read from device memory (written by p_channel_fri_layer_kernel)
+__global__ void p_fri_fold_dev_kernel(size_t n_out, const uint32_t *__restrict__ in, const uint32_t *__restrict__ cinv,
+                                      const uint32_t *__restrict__ alpha_dev, uint32_t *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    const QM31 alpha = ldq(alpha_dev);
     const QM31 v0 = ldq(in + 8 * i), v1 = ldq(in + 8 * i + 4);
     const QM31 f0 = qm31_add(v0, v1);
     const QM31 f1 = qm31_mul_m31(qm31_sub(v0, v1), cinv[i]);
@@ -525,6 +636,58 @@ extern "C" int ss_p_eval_at_point(ss_ctx *, uint32_t m, const uint32_t *coeffs, 
     return SS_OK;
 }
 
+// all `ncols` columns (stride col_stride words) at one point: m launches instead of m per column;
+// scratch: ncols * 3 * 2^m words; out[ncols][4]
+extern "C" int ss_p_eval_at_point_batch(ss_ctx *, uint32_t m, uint32_t ncols, const uint32_t *coeffs,
+                                        size_t col_stride, const uint32_t *factors_host, uint32_t *scratch,
+                                        uint32_t *out, void *stream)
+{
+    if (!coeffs || !factors_host || !scratch || !out || m < 1 || m > 28 || !ncols || ncols > 65535)
+        return ss_internal_set_err(SS_ERR_ARG, "ss_p_eval_at_point_batch: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    size_t n = (size_t)1 << (m - 1);
+    const size_t sstride = (size_t)3 << m;  // per column: a holds n QM31 (4n words), b n/2 (2n words)
+    uint32_t *a = scratch, *b = scratch + 4 * n;
+    hipLaunchKernelGGL(p_fold_m31_batch_kernel, dim3(blocks_for(n), ncols), dim3(256), 0, s, n, coeffs, col_stride,
+                       q4(factors_host), m == 1 ? out : a, m == 1 ? (size_t)4 : sstride);
+    uint32_t *src = a, *dst = b;
+    for (uint32_t lvl = 1; lvl < m; lvl++) {
+        n >>= 1;
+        const bool last = lvl + 1 == m;
+        hipLaunchKernelGGL(p_fold_qm31_batch_kernel, dim3(blocks_for(n), ncols), dim3(256), 0, s, n, src, sstride,
+                           q4(factors_host + 4 * lvl), last ? out : dst, last ? (size_t)4 : sstride);
+        uint32_t *t = src; src = dst; dst = t;
+    }
+    P_TRY(hipGetLastError());
+    return SS_OK;
+}
+
+extern "C" int ss_p_channel_fri_layer(ss_ctx *, uint32_t hash, uint32_t *state_dev, const uint32_t *root_dev,
+                                      uint32_t *alpha_out_dev, uint32_t *root_out_dev, void *stream)
+{
+    if (!state_dev || !root_dev || !alpha_out_dev || !root_out_dev || hash > 1)
+        return ss_internal_set_err(SS_ERR_ARG, "ss_p_channel_fri_layer: bad argument");
+    if (hash)
+        hipLaunchKernelGGL(p_channel_fri_layer_kernel<1>, dim3(1), dim3(64), 0, (hipStream_t)stream, state_dev, root_dev,
+                           alpha_out_dev, root_out_dev);
+    else
+        hipLaunchKernelGGL(p_channel_fri_layer_kernel<0>, dim3(1), dim3(64), 0, (hipStream_t)stream, state_dev, root_dev,
+                           alpha_out_dev, root_out_dev);
+    P_TRY(hipGetLastError());
+    return SS_OK;
+}
+
+extern "C" int ss_p_fri_fold_dev(ss_ctx *, size_t n_out, const uint32_t *in, const uint32_t *coord_inv,
+                                 const uint32_t *alpha_dev, uint32_t *out, void *stream)
+{
+    if (!in || !coord_inv || !alpha_dev || !out || !n_out)
+        return ss_internal_set_err(SS_ERR_ARG, "ss_p_fri_fold_dev: bad argument");
+    hipLaunchKernelGGL(p_fri_fold_dev_kernel, dim3(blocks_for(n_out)), dim3(256), 0, (hipStream_t)stream, n_out, in,
+                       coord_inv, alpha_dev, out);
+    P_TRY(hipGetLastError());
+    return SS_OK;
+}
+
 extern "C" int ss_p_quotients(ss_ctx *, uint32_t lde_log, uint32_t n_cols, const uint32_t *trace_lde,
                               const uint32_t *cp_lde, const uint32_t *hx_hy, const uint32_t *bcoef,
                               const uint32_t p[8], const uint32_t p2[8], const uint32_t sums_alpha16[20],
@@ -537,7 +700,7 @@ extern "C" int ss_p_quotients(ss_ctx *, uint32_t lde_log, uint32_t n_cols, const
     q.a1 = q4(sums_alpha16); q.c1 = q4(sums_alpha16 + 4); q.a2 = q4(sums_alpha16 + 8); q.c2 = q4(sums_alpha16 + 12);
     q.alpha16 = q4(sums_alpha16 + 16);
     const size_t half = (size_t)1 << (lde_log - 1);
-    hipLaunchKernelGGL(p_quotients_kernel, dim3(blocks_for((size_t)1 << lde_log)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(p_quotients_kernel, dim3(blocks_for(half)), dim3(256), 0, (hipStream_t)stream,
                        lde_log, n_cols, trace_lde, cp_lde, hx_hy, hx_hy + half, bcoef, q, out);
     P_TRY(hipGetLastError());
     return SS_OK;

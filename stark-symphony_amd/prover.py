@@ -130,6 +130,9 @@ class GpuProver:
         sig("ss_p_merkle", C.c_uint32, sz, u32p)
         sig("ss_p_composition", C.c_uint32, C.c_uint32, u32p, u32p, u32p, u32p)
         sig("ss_p_eval_at_point", C.c_uint32, u32p, u32p, u32p, u32p)
+        sig("ss_p_eval_at_point_batch", C.c_uint32, C.c_uint32, u32p, sz, u32p, u32p, u32p)
+        sig("ss_p_channel_fri_layer", C.c_uint32, u32p, u32p, u32p, u32p)
+        sig("ss_p_fri_fold_dev", sz, u32p, u32p, u32p, u32p)
         sig("ss_p_quotients", C.c_uint32, C.c_uint32, u32p, u32p, u32p, u32p, u32p, u32p, u32p, u32p)
         sig("ss_p_fri_fold", sz, u32p, u32p, u32p, u32p)
         sig("ss_p_pow", C.c_uint32, u32p, C.c_uint64, C.c_uint64, C.c_uint64, u32p)
@@ -189,29 +192,65 @@ class GpuProver:
     def _root(self, levels, n: int) -> bytes:
         return self._host(levels[2 * n - 2]).astype(">u4").tobytes()
 
-    def _paths(self, levels, n: int, indices: Sequence[int], skip: int = 0) -> List[List[int]]:
-        """Sibling hashes leaf -> root (bytes as int lists) of every index at level `skip`,
-        concatenated in query order; one gather + one download per tree."""
-        torch = self.torch
-        idxs: List[int] = []
-        for index in indices:
-            off, size, idx = 0, n, index
-            for _ in range(skip):
-                off += size
-                size >>= 1
-            while size > 1:
-                idxs.append(off + (idx ^ 1))
-                off += size
-                size >>= 1
-                idx >>= 1
-        if not idxs:
+    @staticmethod
+    def _path_rows(n: int, indices: Sequence[int], skip: int = 0) -> np.ndarray:
+        """Rows of a tree's `levels` array holding the sibling hashes leaf -> root of every index at
+        level `skip`, concatenated in query order.  Level j starts at row 2n - (2n >> j)."""
+        h = n.bit_length() - 1
+        if h <= skip or not len(indices):
+            return np.zeros(0, dtype=np.int64)
+        j = np.arange(skip, h, dtype=np.int64)
+        idx = np.asarray(indices, dtype=np.int64)[:, None] >> (j - skip)[None, :]
+        return ((2 * n - ((2 * n) >> j))[None, :] + (idx ^ 1)).reshape(-1)
+
+    class _Gather:
+        """Rows of several device arrays, fetched with ONE upload of all row indices and ONE
+        download: requests are queued, `fetch()` uploads the concatenated indices, gathers on the
+        device, concatenates and copies back (the decommitment used to cost a synchronising index
+        upload and a synchronising download per tree and per layer)."""
+
+        def __init__(self, prover):
+            self.p, self.req = prover, []
+
+        def rows(self, array, idxs) -> int:
+            self.req.append((array, np.asarray(idxs, dtype=np.int64)))
+            return len(self.req) - 1
+
+        def take(self, tensor) -> int:
+            self.req.append((tensor, None))
+            return len(self.req) - 1
+
+        def fetch(self) -> List[np.ndarray]:
+            t = self.p.torch
+            all_idx = np.concatenate([i for _, i in self.req if i is not None] or [np.zeros(0, np.int64)])
+            dev_idx = t.from_numpy(all_idx).to(self.p.dev)
+            parts, shapes, pos = [], [], 0
+            for array, idx in self.req:
+                if idx is None:
+                    sel = array
+                else:
+                    sel = array[dev_idx[pos:pos + idx.size]]
+                    pos += idx.size
+                parts.append(sel.reshape(-1))
+                shapes.append(tuple(sel.shape))
+            flat = self.p._host(t.cat(parts)) if parts else np.zeros(0, np.uint32)
+            out, pos = [], 0
+            for shp in shapes:
+                size = int(np.prod(shp))
+                out.append(flat[pos:pos + size].reshape(shp))
+                pos += size
+            return out
+
+    @staticmethod
+    def _hash_rows_to_json(rows: np.ndarray) -> List[List[int]]:
+        if rows.size == 0:
             return []
-        rows = self._host(levels[torch.tensor(idxs, device=self.dev)])
-        return rows.astype(">u4").view(np.uint8).reshape(len(idxs), 32).tolist()
+        return rows.reshape(-1, 8).astype(">u4").view(np.uint8).reshape(-1, 32).tolist()
 
     # -- the protocol ----------------------------------------------------------------------
-    def prove(self, n_cols: int = 4, trace_log: int = 9, log_blowup: int = 4, n_queries: int = 16,
-              pow_bits: int = 5, seed: int = 0, hash: str = "sha256") -> dict:
+    def prove_proof(self, n_cols: int = 4, trace_log: int = 9, log_blowup: int = 4, n_queries: int = 16,
+                    pow_bits: int = 5, seed: int = 0, hash: str = "sha256"):
+        """-> formats.StwoProof (arrays; what the verifier's record is made from)."""
         torch = self.torch
         t_start = time.perf_counter()
         marks: List[Tuple[str, float]] = []
@@ -273,15 +312,14 @@ class GpuProver:
                 cur = qsub(qadd(qmul(cur, cur), qmul(cur, cur)), ONE)
                 f.append(cur)
             return np.array(f[:m], dtype=np.uint32).reshape(-1)
-        scratch = self._empty(3 << n)
+        scratch = self._empty(max(N, 16) * (3 << n))
         samples = self._empty(N + 16, 4)
         f1, f2 = factors(px, py, n), factors(p2x, p2y, n)
-        for k in range(N):
-            self._call("ss_p_eval_at_point", n, coefs[k].data_ptr(), f1.ctypes.data, scratch.data_ptr(),
-                       samples[k].data_ptr())
-        for k in range(16):
-            self._call("ss_p_eval_at_point", n, cp_coefs[k].data_ptr(), f2.ctypes.data, scratch.data_ptr(),
-                       samples[N + k].data_ptr())
+        # all columns of a commitment are sampled at one point: one batched fold chain each
+        self._call("ss_p_eval_at_point_batch", n, N, coefs.data_ptr(), 1 << n, f1.ctypes.data, scratch.data_ptr(),
+                   samples.data_ptr())
+        self._call("ss_p_eval_at_point_batch", n, 16, cp_coefs.data_ptr(), 1 << n, f2.ctypes.data, scratch.data_ptr(),
+                   samples[N:].data_ptr())
         samp = self._host(samples).astype(np.int64)
         oods_trace = [tuple(int(x) for x in samp[k]) for k in range(N)]
         oods_cp = [tuple(int(x) for x in samp[N + k]) for k in range(16)]
@@ -313,8 +351,14 @@ class GpuProver:
                    bcoef.data_ptr(), pts, pts2, sa, layer.data_ptr())
         mark("quotients")
 
-        # ---- FRI commit
-        layers, trees, roots = [], [], []
+        # ---- FRI commit (fri/commit.simf:70-85), channel included, without a host round trip: per
+        # layer the Merkle tree, then one lane mixes the root and draws alpha ON THE DEVICE, then the
+        # fold reads alpha from device memory.  One download at the end (roots, channel, last layer).
+        state = torch.from_numpy(np.concatenate([np.frombuffer(ch.digest, dtype=">u4").astype(np.uint32),
+                                                 np.array([ch.counter], dtype=np.uint32)]).view(np.int32)).to(self.dev)
+        roots_dev = self._empty(K + 1, 8)
+        alphas_dev = self._empty(K + 1, 4)
+        layers, trees = [], []
         for l in range(K + 1):
             size = size_L >> l
             layers.append(layer)
@@ -322,16 +366,20 @@ class GpuProver:
             tree = self.merkle(hsel, lambda lv: self._call(
                 "ss_p_hash_qm31", hsel, size, cur.data_ptr(), lv.data_ptr()), size)
             trees.append(tree)
-            root = self._root(tree, size)
-            roots.append(root)
-            ch.mix(root)
-            alpha = ch.draw_qm31()
+            self._call("ss_p_channel_fri_layer", hsel, state.data_ptr(), tree[2 * size - 2].data_ptr(),
+                       alphas_dev[l].data_ptr(), roots_dev[l].data_ptr())
             nxt = self._empty(size >> 1, 4)
             off = size_L - (size_L >> l)  # inverse twiddle layer l = 1 / fold coordinate
-            self._call("ss_p_fri_fold", size >> 1, layer.data_ptr(), itw_L[off:].data_ptr(), self._q(alpha),
-                       nxt.data_ptr())
+            self._call("ss_p_fri_fold_dev", size >> 1, layer.data_ptr(), itw_L[off:].data_ptr(),
+                       alphas_dev[l].data_ptr(), nxt.data_ptr())
             layer = nxt
-        last_all = self._host(layer)
+        g = self._Gather(self)
+        k_state, k_roots, k_last = g.take(state), g.take(roots_dev), g.take(layer)
+        got = g.fetch()
+        ch.digest = got[k_state][:8].astype(">u4").tobytes()
+        ch.counter = int(got[k_state][8])
+        roots = [got[k_roots][l].astype(">u4").tobytes() for l in range(K + 1)]
+        last_all = got[k_last]
         if not (last_all == last_all[0]).all():
             raise AssertionError("last FRI layer is not constant: the quotient is not low degree")
         last = tuple(int(x) for x in last_all[0])
@@ -342,13 +390,14 @@ class GpuProver:
         target = (1 << (64 - pow_bits)) - 1
         dig = (C.c_uint32 * 8)(*np.frombuffer(ch.digest, dtype=">u4").astype(np.uint32))
         out = torch.zeros(2, dtype=torch.int32, device=self.dev)
-        start, span = 0, 1 << 22
+        start, span = 0, 1 << min(22, pow_bits + 8)  # expected 2^pow_bits tries: rarely a second pass
         while True:
             self._call("ss_p_pow", hsel, dig, target, start, span, out.data_ptr())
             nonce = int(self._host(out).view(np.uint64)[0])
             if nonce != 0xFFFFFFFFFFFFFFFF:
                 break
             start += span
+            span = min(span * 4, 1 << 22)
         ch.mix(nonce.to_bytes(8, "big"))
         mark("pow")
 
@@ -358,26 +407,36 @@ class GpuProver:
         while len(queries) < n_queries:
             queries += [w & mask for w in ch.draw_words()]
         queries = queries[:n_queries]
-        qi = torch.tensor(queries, device=self.dev)
-        tq = self._host(lde[:, qi]).T  # [Q, N]
-        cq = self._host(cp_lde[:, qi]).T
-        trace_q = [int(v) for row in tq for v in row]
-        cp_q = [int(v) for row in cq for v in row]
-        trace_hw = self._paths(trace_tree, size_L, queries)
-        cp_hw = self._paths(cp_tree, size_L, queries)
-
-        def qj(v):
-            return [[int(v[0]), int(v[1])], [int(v[2]), int(v[3])]]
-        fri_json = []
+        # every gather of the decommitment is enqueued first, then downloaded at once
+        g = self._Gather(self)
+        lde_t, cp_lde_t = lde.T, cp_lde.T  # views: row = LDE position
+        k_tq, k_cq = g.rows(lde_t, queries), g.rows(cp_lde_t, queries)  # [Q, N], [Q, 16]
+        k_thw = g.rows(trace_tree, self._path_rows(size_L, queries))
+        k_chw = g.rows(cp_tree, self._path_rows(size_L, queries))
+        k_layers = []
         cur_q = list(queries)
         for l in range(K + 1):
             size = size_L >> l
-            sib = self._host(layers[l][torch.tensor([q ^ 1 for q in cur_q], device=self.dev)])
-            hwl = self._paths(trees[l], size, [q >> 1 for q in cur_q], skip=1)
+            k_sib = g.rows(layers[l], [q ^ 1 for q in cur_q])
+            k_hw = g.rows(trees[l], self._path_rows(size, [q >> 1 for q in cur_q], skip=1))
+            k_layers.append((k_sib, k_hw))
             cur_q = [q >> 1 for q in cur_q]
-            fri_json.append({"fri_witness": [qj(w) for w in sib],
-                             "decommitment": {"hash_witness": hwl, "column_witness": []},
-                             "commitment": [int(b) for b in roots[l]]})
+        got = g.fetch()
+
+        def hashes(rows: np.ndarray, *shape) -> np.ndarray:
+            """stored words [.., 8] -> bytes [.., 32]"""
+            return np.ascontiguousarray(rows).reshape(-1, 8).astype(">u4").view(np.uint8).reshape(*shape, 32)
+        from .formats import StwoConfig, StwoProof
+        Q = n_queries
+        proof = StwoProof(
+            StwoConfig(N, n, L, Q, K, pow_bits, hash),
+            np.stack([np.frombuffer(r, dtype=np.uint8) for r in (const_root, trace_root, cp_root)]),
+            np.array(oods_trace, dtype=np.uint32).reshape(N, 4), np.array(oods_cp, dtype=np.uint32).reshape(16, 4),
+            got[k_tq].reshape(Q, N).copy(), got[k_cq].reshape(Q, 16).copy(),
+            list(hashes(got[k_thw], Q, L)), list(hashes(got[k_chw], Q, L)),
+            np.stack([np.frombuffer(r, dtype=np.uint8) for r in roots]), np.array(last, dtype=np.uint32),
+            np.stack([got[ks].reshape(Q, 4) for ks, _ in k_layers]),
+            [list(hashes(got[kh], Q, L - 1 - l)) for l, (_, kh) in enumerate(k_layers)], nonce)
         mark("decommit")
         prev = t_start
         self.timings = {}
@@ -385,21 +444,17 @@ class GpuProver:
             self.timings[name] = ts - prev
             prev = ts
         self.timings["total"] = prev - t_start
-        conf = {"pow_bits": pow_bits,
-                "fri_config": {"log_blowup_factor": log_blowup, "log_last_layer_degree_bound": 0,
-                               "n_queries": n_queries}}
-        if hash != "sha256":
-            conf["hash"] = hash
-        return {
-            "config": conf,
-            "commitments": [[int(b) for b in const_root], [int(b) for b in trace_root],
-                            [int(b) for b in cp_root]],
-            "sampled_values": [[], [[qj(v)] for v in oods_trace], [[qj(v)] for v in oods_cp]],
-            "decommitments": [{"hash_witness": [], "column_witness": []},
-                              {"hash_witness": trace_hw, "column_witness": []},
-                              {"hash_witness": cp_hw, "column_witness": []}],
-            "queried_values": [[], trace_q, cp_q],
-            "proof_of_work": nonce,
-            "fri_proof": {"first_layer": fri_json[0], "inner_layers": fri_json[1:],
-                          "last_layer_poly": {"coeffs": [qj(last)], "log_size": 0}},
-        }
+        return proof
+
+    def prove(self, n_cols: int = 4, trace_log: int = 9, log_blowup: int = 4, n_queries: int = 16,
+              pow_bits: int = 5, seed: int = 0, hash: str = "sha256") -> dict:
+        """The same proof in the reference's `proof.json` schema (format C): `prove_proof` plus the
+        conversion of 170 KB of hashes into JSON's lists of byte values (3-4 ms of pure Python at the
+        2^20 shape, reported as timings["json"])."""
+        from .formats import stwo_to_json
+        proof = self.prove_proof(n_cols, trace_log, log_blowup, n_queries, pow_bits, seed, hash)
+        t0 = time.perf_counter()
+        out = stwo_to_json(proof)
+        self.timings["json"] = time.perf_counter() - t0
+        self.timings["total"] += self.timings["json"]
+        return out
