@@ -78,6 +78,31 @@ class Pipeline:
         self.comm_stream.synchronize()
 
 
+class IndependentStreams:
+    """Every slot on its own stream, HEAD and TAIL back to back, no events between slots: for batches
+    too small to fill the chip (a stark101 x 4096 pass is 64 transcript waves, then 1 472 short Merkle
+    waves, for 1 024 SIMDs) many whole passes must overlap, and one library call per pass (two memsets
+    and three launches) is cheap enough to enqueue eagerly.  Kernel durations measured under this
+    overlap are not meaningful; take them from a Pipeline pass."""
+
+    def __init__(self, slots: Sequence["_DeviceBatch"]):
+        torch = _torch()
+        self.slots = list(slots)
+        dev = self.slots[0].ver.device
+        self.streams = [torch.cuda.Stream(device=dev) for _ in self.slots]
+        self.i = 0
+
+    def submit(self) -> int:
+        k = self.i % len(self.slots)
+        self.i += 1
+        self.slots[k].run(self.streams[k], PHASE_ALL)  # same slot, same stream: ordered by the stream
+        return k
+
+    def synchronize(self) -> None:
+        for s in self.streams:
+            s.synchronize()
+
+
 class GraphedPipeline:
     """One pipelined pass over every slot captured ONCE into a hipGraph (the head streams and the
     tail stream fork from and join the capture stream), then replayed with a single launch.

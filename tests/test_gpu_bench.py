@@ -83,13 +83,15 @@ def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
     assert r.returncode != 0 and "disagrees" in r.stderr
 
 
-def test_bench_stark101_graphed_submission():
-    """BASELINE.json configs[1] (stark101 x 4096) is launch-bound: bench.py replays hipGraphs of
-    independent slots for the timed steps and takes the kernel durations from an eager pass."""
+@pytest.mark.parametrize("how,label", [("auto", "independent streams"), ("on", "hipGraph")])
+def test_bench_stark101_small_batch_submission(how, label):
+    """BASELINE.json configs[1] (stark101 x 4096) cannot fill the chip with one pass: bench.py overlaps
+    whole passes (16 independent streams by default, hipGraph replay with --graph on) for the timed
+    steps and takes the kernel durations from a pipelined pass."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "stark101", "--steps", "24",
-                        "--warmup", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+                        "--warmup", "2", "--no-cpu-baseline", "--graph", how], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
-    assert d["steps"] == 24 and d["config"]["proofs_per_gpu"] == 4096 and "hipGraph" in d["config"]["submission"]
+    assert d["steps"] == 24 and d["config"]["proofs_per_gpu"] == 4096 and label in d["config"]["submission"]
     assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert d["roofline"]["kernel"] == "s101_merkle" and d["roofline"]["kernel_launches"] == 20
