@@ -752,8 +752,12 @@ static bool read_file(const char *path, std::string &out)
     out.clear();
     char buf[1 << 16];
     size_t k;
-    while ((k = fread(buf, 1, sizeof buf, f)) > 0) out.append(buf, k);
-    const bool ok = !ferror(f);
+    bool too_big = false;
+    while ((k = fread(buf, 1, sizeof buf, f)) > 0) {
+        out.append(buf, k);
+        if (out.size() > ((size_t)256 << 20)) { too_big = true; break; }  // no witness of a supported config is near 256 MiB
+    }
+    const bool ok = !ferror(f) && !too_big;
     fclose(f);
     return ok;
 }

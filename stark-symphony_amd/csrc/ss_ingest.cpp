@@ -21,7 +21,9 @@
 namespace ss {
 namespace {
 
-enum Kind : uint8_t { kInt, kBig, kList, kObj, kStr, kAlias, kOther };
+// kBytes32: a JSON list of exactly 32 byte values, kept as its 8 stored hash words (a list to every
+// accessor that asks for its length, a hash to get_hash)
+enum Kind : uint8_t { kInt, kBig, kList, kObj, kStr, kAlias, kOther, kBytes32 };
 
 struct Node {
     uint8_t kind = kOther, key_len = 0;
@@ -51,8 +53,8 @@ struct Tree {
         while (nodes[i].kind == kAlias) i++;
         return i;
     }
-    bool is_list(uint32_t i) const { return nodes[i].kind == kList; }
-    uint32_t count(uint32_t i) const { return nodes[i].val; }
+    bool is_list(uint32_t i) const { return nodes[i].kind == kList || nodes[i].kind == kBytes32; }
+    uint32_t count(uint32_t i) const { return nodes[i].kind == kBytes32 ? 32 : nodes[i].val; }
     // k-th child of list / object i (resolved), 0 if absent (node 0 is the root, never a child)
     uint32_t child(uint32_t i, uint32_t k) const
     {
@@ -74,6 +76,19 @@ struct Tree {
     }
 };
 
+// value of a hex digit (callers only pass characters they have classified as hex digits)
+struct HexTable {
+    uint8_t v[256];
+    constexpr HexTable() : v()
+    {
+        for (int i = 0; i < 256; i++) v[i] = 0xff;
+        for (int i = 0; i < 10; i++) v['0' + i] = (uint8_t)i;
+        for (int i = 0; i < 6; i++) { v['a' + i] = (uint8_t)(10 + i); v['A' + i] = (uint8_t)(10 + i); }
+    }
+};
+constexpr HexTable kHexTable;
+#define kHexVal kHexTable.v
+
 // ------------------------------------------------------------------------------ numbers
 // digits[0..n) decimal -> node.  Values below 2^32 are kInt, others kBig; >= 2^256 is an error.
 bool number_node(Tree &t, uint32_t idx, const char *digits, size_t n, int base)
@@ -89,11 +104,12 @@ bool number_node(Tree &t, uint32_t idx, const char *digits, size_t n, int base)
     if (base == 16) {
         while (n && *digits == '0') { digits++; n--; }
         if (n > 64) return false;
-        for (size_t i = 0; i < n; i++) {
-            const char ch = digits[n - 1 - i];
-            const uint32_t v = ch <= '9' ? ch - '0' : (ch | 0x20) - 'a' + 10;
-            limb[i / 8] |= v << (4 * (i % 8));
-        }
+        // digit i of n sits at position 64 - n + i of the zero-extended 64-digit number; word w of the
+        // big-endian 8-word form holds positions 8w .. 8w + 7
+        uint32_t be[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        size_t pos = 64 - n;
+        for (size_t i = 0; i < n; i++, pos++) be[pos >> 3] = (be[pos >> 3] << 4) | kHexVal[(unsigned char)digits[i]];
+        for (int l = 0; l < 8; l++) limb[l] = be[7 - l];
     } else {
         if (n > 78 + 16) {  // longer than any u256, allowing for leading zeros
             while (n && *digits == '0') { digits++; n--; }
@@ -161,6 +177,35 @@ struct Json {
         ws();
         if (p >= end || depth > kMaxDepth) { fail(); return 0; }
         const char ch = *p;
+        if (ch == '[') {
+            // Three quarters of a proof.json are hashes written as lists of 32 byte values: read such a
+            // list straight into one node (kind kBig, the 8 stored words) instead of 33.  Anything
+            // else -- other lengths, values above 255, nesting -- falls through to the general path.
+            const char *q = p + 1;
+            uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int k = 0;
+            bool ok = true;
+            while (ok && k < 32) {
+                while (q < end && (*q == ' ' || *q == '\n' || *q == '\t' || *q == '\r')) q++;
+                uint32_t v = 0;
+                int nd = 0;
+                while (q < end && *q >= '0' && *q <= '9' && nd < 4) { v = v * 10 + (uint32_t)(*q - '0'); q++; nd++; }
+                if (nd == 0 || nd > 3 || v > 255) { ok = false; break; }
+                w[k >> 2] = (w[k >> 2] << 8) | v;
+                k++;
+                while (q < end && (*q == ' ' || *q == '\n' || *q == '\t' || *q == '\r')) q++;
+                if (k < 32) { if (q < end && *q == ',') q++; else ok = false; }
+            }
+            if (ok && q < end && *q == ']') {
+                const uint32_t idx = t.push(kBytes32);
+                U256 b;
+                memcpy(b.w, w, 32);
+                t.nodes[idx].val = (uint32_t)t.bigs.size();
+                t.bigs.push_back(b);
+                p = q + 1;
+                return idx;
+            }
+        }
         if (ch == '[' || ch == '{') {
             const bool obj = ch == '{';
             const uint32_t idx = t.push(obj ? kObj : kList);
@@ -226,10 +271,21 @@ struct Json {
     }
 };
 
-bool parse_json(Tree &t, const char *text, size_t len)
+// Trees are per-thread scratch that keeps its capacity from one text to the next: a 2^20-row proof
+// needs a few MB of nodes, and a fresh allocation per text means fresh page faults per text.
+void tree_reset(Tree &t, const char *text)
 {
     t.text = text;
-    t.nodes.reserve(len / 4 + 16);
+    t.nodes.clear();
+    t.bigs.clear();
+    t.ok = true;
+    t.root = 0;
+}
+
+bool parse_json(Tree &t, const char *text, size_t len)
+{
+    tree_reset(t, text);
+    if (t.nodes.capacity() < len / 16 + 16) t.nodes.reserve(len / 16 + 16);
     Json j{t, text, text + len};
     j.value(0);
     j.ws();
@@ -280,23 +336,30 @@ struct Literal {
         if (*p == '(') return seq(')', depth);
         if (*p == '[') return seq(']', depth);
         const uint32_t idx = t.push(kOther);
-        std::string digits;  // '_' separators removed; short for every value of the formats
         int base = 10;
         if (end - p >= 2 && p[0] == '0' && (p[1] == 'x' || p[1] == 'X')) {
             base = 16;
             p += 2;
-            while (p < end && ((*p >= '0' && *p <= '9') || ((*p | 0x20) >= 'a' && (*p | 0x20) <= 'f') || *p == '_')) {
-                if (*p != '_') digits.push_back(*p);
-                p++;
-            }
-        } else {
-            while (p < end && ((*p >= '0' && *p <= '9') || *p == '_')) {
-                if (*p != '_') digits.push_back(*p);
-                p++;
-            }
         }
-        if (digits.empty()) { t.ok = false; return idx; }
-        if (!number_node(t, idx, digits.data(), digits.size(), base)) t.nodes[idx].kind = kOther;
+        const char *s0 = p;
+        bool sep = false;
+        if (base == 16)
+            while (p < end && (kHexVal[(unsigned char)*p] != 0xff || *p == '_')) sep |= *p++ == '_';
+        else
+            while (p < end && ((*p >= '0' && *p <= '9') || *p == '_')) sep |= *p++ == '_';
+        size_t nd = (size_t)(p - s0);
+        char buf[128];  // '_' separators removed (only then is a copy needed)
+        const char *digits = s0;
+        if (sep) {
+            size_t k = 0;
+            for (const char *c = s0; c < p; c++)
+                if (*c != '_') { if (k == sizeof buf) { k = sizeof buf + 1; break; } buf[k++] = *c; }
+            if (k > sizeof buf) return idx;  // longer than any u256 even with leading zeros: kOther
+            digits = buf;
+            nd = k;
+        }
+        if (nd == 0) { t.ok = false; return idx; }
+        if (!number_node(t, idx, digits, nd, base)) t.nodes[idx].kind = kOther;
         return idx;
     }
 };
@@ -311,8 +374,7 @@ bool wit_member(const Tree &j, const char *name, Tree &out)
     const char *s = j.text + j.nodes[v].val;
     const size_t n = j.nodes[v].len;
     if (memchr(s, '\\', n)) return false;
-    out.text = s;
-    out.nodes.reserve(n / 8 + 16);
+    tree_reset(out, s);
     out.push(kOther);
     out.root = 1;
     Literal l{out, s, s + n};
@@ -351,7 +413,7 @@ bool get_hash(const Tree &t, uint32_t i, uint32_t *out)
         out[7] = nd.val;
         return true;
     }
-    if (nd.kind == kBig) {
+    if (nd.kind == kBig || nd.kind == kBytes32) {
         memcpy(out, t.bigs[nd.val].w, 32);
         return true;
     }
@@ -401,6 +463,49 @@ bool get_path(const Tree &t, uint32_t lst, uint32_t first, uint32_t count, uint3
     plen = count;
     return true;
 }
+
+// Walks the elements of a JSON list in order, whichever way the parser kept it (kList, or the
+// packed kBytes32 whose elements are its 32 byte values).  The caller stays within count().
+struct ListIter {
+    const Tree &t;
+    uint32_t lst, c = 0, k = 0;
+    bool blob;
+    ListIter(const Tree &t_, uint32_t lst_) : t(t_), lst(lst_), blob(t_.nodes[lst_].kind == kBytes32)
+    {
+        if (!blob && t.nodes[lst].val) c = lst + 1;
+    }
+    bool u32(uint32_t &v)
+    {
+        if (blob) {
+            v = (t.bigs[t.nodes[lst].val].w[k >> 2] >> (8 * (3 - (k & 3)))) & 255;
+            k++;
+            return true;
+        }
+        const bool ok = get_u32(t, t.resolve(c), v);
+        c = t.nodes[c].next;
+        return ok;
+    }
+    bool hash(uint32_t *h)
+    {
+        if (blob) {  // a small integer read as a u256
+            uint32_t v;
+            u32(v);
+            for (int j = 0; j < 7; j++) h[j] = 0;
+            h[7] = v;
+            return true;
+        }
+        const bool ok = get_hash(t, t.resolve(c), h);
+        c = t.nodes[c].next;
+        return ok;
+    }
+    bool qm31(uint32_t *o)
+    {
+        if (blob) return false;
+        const bool ok = get_qm31(t, t.resolve(c), o);
+        c = t.nodes[c].next;
+        return ok;
+    }
+};
 
 uint64_t pow_target_of_bits(uint32_t bits) { return bits == 0 ? ~(uint64_t)0 : (((uint64_t)1 << (64 - bits)) - 1); }
 
@@ -531,28 +636,25 @@ ParseResult stwo_from_json(const ss_stwo_cfg &cfg, const Tree &t, uint32_t *rec)
     }
     // queried values: walk the two flat lists once
     {
-        uint32_t c1 = t.count(qv1) ? qv1 + 1 : 0, c2 = t.count(qv2) ? qv2 + 1 : 0;
+        ListIter i1(t, qv1), i2(t, qv2);
         for (uint32_t q = 0; q < Q; q++) {
             for (uint32_t k = 0; k < N; k++) {
-                if (!get_u32(t, t.resolve(c1), v)) return kMalformed;
+                if (!i1.u32(v)) return kMalformed;
                 if (r) m.trace_vals(r, q)[k] = v;
-                c1 = t.nodes[c1].next;
             }
             for (uint32_t k = 0; k < kCp; k++) {
-                if (!get_u32(t, t.resolve(c2), v)) return kMalformed;
+                if (!i2.u32(v)) return kMalformed;
                 if (r) m.cp_vals(r, q)[k] = v;
-                c2 = t.nodes[c2].next;
             }
         }
     }
     auto paths = [&](uint32_t hw, uint32_t len, uint32_t slot, auto dst_of, uint32_t kind) -> bool {
-        uint32_t c = t.count(hw) ? hw + 1 : 0;
+        ListIter it(t, hw);
         for (uint32_t q = 0; q < Q; q++) {
             for (uint32_t k = 0; k < len; k++) {
                 uint32_t h[8];
-                if (!get_hash(t, t.resolve(c), h)) return false;
+                if (!it.hash(h)) return false;
                 if (r && k < slot) memcpy(dst_of(q) + 8 * k, h, 32);
-                c = t.nodes[c].next;
             }
             if (r) m.plen(r, kind, q) = len;
         }
@@ -572,17 +674,15 @@ ParseResult stwo_from_json(const ss_stwo_cfg &cfg, const Tree &t, uint32_t *rec)
         if (keep) memcpy(r + 24 + 4 * m.N + 64 + 8 * l, h, 32);
         const uint32_t len = t.count(hw) / Q;
         if (len > kMaxList) return kMalformed;
-        uint32_t cw = w + 1, ch = t.count(hw) ? hw + 1 : 0;
+        ListIter iw(t, w), ih(t, hw);
         for (uint32_t q = 0; q < Q; q++) {
-            if (!get_qm31(t, t.resolve(cw), tmp)) return kMalformed;
-            cw = t.nodes[cw].next;
+            if (!iw.qm31(tmp)) return kMalformed;
             uint32_t *dst = keep ? m.fri_wit(r, l, q) : nullptr;
             if (dst) memcpy(dst, tmp, 16);
             const uint32_t slot = keep ? m.L - 1 - l : 0;
             for (uint32_t k = 0; k < len; k++) {
-                if (!get_hash(t, t.resolve(ch), h)) return kMalformed;
+                if (!ih.hash(h)) return kMalformed;
                 if (dst && k < slot) memcpy(dst + 4 + 8 * k, h, 32);
-                ch = t.nodes[ch].next;
             }
             if (keep) m.plen(r, 2 + l, q) = len;
         }
@@ -602,7 +702,7 @@ ParseResult stwo_from_wit(const ss_stwo_cfg &cfg, const Tree &j, uint32_t *rec)
 {
     const RecordMap m(cfg);
     if (j.nodes.empty() || j.nodes[0].kind != kObj) return kMalformed;
-    Tree com, dec, oods, fric, frid, non;
+    static thread_local Tree com, dec, oods, fric, frid, non;
     if (!wit_member(j, "COMMITMENTS", com) || !wit_member(j, "DECOMMITMENTS", dec) ||
         !wit_member(j, "OODS_EVALS", oods) || !wit_member(j, "FRI_COMMITMENTS", fric) ||
         !wit_member(j, "FRI_DECOMMITMENTS", frid) || !wit_member(j, "POW_NONCE", non))
@@ -701,7 +801,7 @@ ParseResult stwo_from_wit(const ss_stwo_cfg &cfg, const Tree &j, uint32_t *rec)
 
 ParseResult stwo_parse_text(const ss_stwo_cfg &cfg, const char *text, size_t len, int fmt, uint32_t *record)
 {
-    Tree j;
+    static thread_local Tree j;
     if (!parse_json(j, text, len) || j.nodes.empty() || j.nodes[0].kind != kObj) return kMalformed;
     if (fmt == SS_TEXT_AUTO) fmt = j.member(0, "COMMITMENTS") ? SS_TEXT_WIT : SS_TEXT_JSON;
     return fmt == SS_TEXT_WIT ? stwo_from_wit(cfg, j, record) : stwo_from_json(cfg, j, record);
@@ -759,13 +859,13 @@ bool s101_from_parts(const Tree &tr, uint32_t root, const Tree &te, uint32_t eva
 
 S101Parsed *s101_parse_text(const char *text, size_t len, int fmt)
 {
-    Tree j;
+    static thread_local Tree j;
     if (!parse_json(j, text, len) || j.nodes.empty() || j.nodes[0].kind != kObj) return nullptr;
     if (fmt == SS_TEXT_AUTO) fmt = j.member(0, "P_MT_ROOT") ? SS_TEXT_WIT : SS_TEXT_JSON;
     S101Parsed *p = new S101Parsed();
     bool ok;
     if (fmt == SS_TEXT_WIT) {
-        Tree a, b, c, d;
+        static thread_local Tree a, b, c, d;
         ok = wit_member(j, "P_MT_ROOT", a) && wit_member(j, "P_EVALS", b) && wit_member(j, "FRI_LAYERS", c) &&
              wit_member(j, "FRI_LAST_LAYER", d) &&
              s101_from_parts(a, a.resolve(a.root), b, b.resolve(b.root), c, c.resolve(c.root), d, d.resolve(d.root), *p);

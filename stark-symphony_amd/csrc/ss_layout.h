@@ -130,6 +130,9 @@ SS_HD inline StwoLayout stwo_layout(uint32_t N, uint32_t TL, uint32_t L, uint32_
     // levels still merge ~1.5 pairs per tree, below that almost nothing
     y.T = (dedup && Q > 1) ? (ceil_log2(Q) + 2 < L ? ceil_log2(Q) + 2 : L) : 0;
     y.top_G = kTopChains / Q;  // Q <= kMaxQueries = 64
+    // a batch that gives fewer groups than the ~1024 blocks the chip holds at once (4 per CU) is cut
+    // into smaller groups: half-empty plans cost less than half-empty CUs
+    while (y.top_G > 1 && (n + y.top_G - 1) / y.top_G < 1024) y.top_G = (y.top_G + 1) / 2;
     const uint64_t groups = (n + y.top_G - 1) / y.top_G;
     y.top_blocks = y.T ? (uint32_t)(groups < kTopMaxBlocks ? groups : kTopMaxBlocks) : 0;
     y.ws_top = w;   w += y.T ? (uint64_t)(K + 3) * y.nip * 8 : 0;

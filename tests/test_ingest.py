@@ -201,3 +201,26 @@ def test_malformed_wit_gets_the_python_outcome():
     seen = {_check(c, cfg, "wit") for c in cases}
     assert seen == {OK, MALFORMED}
     assert _check(json.dumps(wit).encode(), ss.PRODUCTION_CONFIG, "wit") == MISMATCH
+
+
+def test_packed_hash_lists_do_not_change_the_meaning_of_other_lists():
+    """The JSON reader keeps a list of exactly 32 byte values as one packed node (that is what a hash
+    looks like).  Lists that merely look like one -- 32 small queried values, a hash_witness made of
+    32 small integers -- must still read as what they are."""
+    p = _rand_stwo(7, 4, 6, 8, 1, ragged=False)          # Q * N = 32 trace values
+    p.trace_vals[:] = np.arange(32, dtype=np.uint32).reshape(8, 4) * 7
+    _check(json.dumps(ss.stwo_to_json(p)).encode(), p.cfg, "json")
+    p = _rand_stwo(8, 3, 5, 2, 1, ragged=False)          # Q * 16 = 32 composition values
+    p.cp_vals[:] = (np.arange(32, dtype=np.uint32).reshape(2, 16) * 5) % 251
+    assert _check(json.dumps(ss.stwo_to_json(p)).encode(), p.cfg, "json") == OK
+    obj = ss.stwo_to_json(p)
+    obj["decommitments"][1]["hash_witness"] = list(range(32))      # 16 nodes per query, written as integers
+    _check(json.dumps(obj).encode(), p.cfg, "json")
+    obj["decommitments"][1]["hash_witness"] = list(range(10))      # 5 per query = the tree depth
+    assert _check(json.dumps(obj).encode(), p.cfg, "json") == OK
+    obj = ss.stwo_to_json(p)
+    obj["fri_proof"]["first_layer"]["fri_witness"] = list(range(32))
+    assert _check(json.dumps(obj).encode(), p.cfg, "json") == MALFORMED
+    obj = ss.stwo_to_json(p)
+    obj["commitments"][2] = [[1] * 32]                              # a hash nested one level too deep
+    assert _check(json.dumps(obj).encode(), p.cfg, "json") == MALFORMED
