@@ -755,7 +755,7 @@ static bool read_file(const char *path, std::string &out)
     bool too_big = false;
     while ((k = fread(buf, 1, sizeof buf, f)) > 0) {
         out.append(buf, k);
-        if (out.size() > ((size_t)256 << 20)) { too_big = true; break; }  // no witness of a supported config is near 256 MiB
+        if (out.size() > ((size_t)32 << 20)) { too_big = true; break; }  // ss_ingest.cpp refuses texts above 32 MiB
     }
     const bool ok = !ferror(f) && !too_big;
     fclose(f);

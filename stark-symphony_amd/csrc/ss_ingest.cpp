@@ -799,12 +799,27 @@ ParseResult stwo_from_wit(const ss_stwo_cfg &cfg, const Tree &j, uint32_t *rec)
 
 }  // namespace
 
+// The largest witness of a supported config (1024 columns, 64 queries, LDE 2^31) is a few MB of text;
+// nothing near this bound is a proof, and a parse tree costs up to ~10 bytes per input byte.
+constexpr size_t kMaxTextBytes = (size_t)32 << 20;
+constexpr size_t kKeepNodes = (size_t)4 << 20;  // per-thread scratch above this is released after use
+
+static void tree_trim(Tree &t)
+{
+    if (t.nodes.capacity() > kKeepNodes) { std::vector<Node>().swap(t.nodes); std::vector<U256>().swap(t.bigs); }
+}
+
 ParseResult stwo_parse_text(const ss_stwo_cfg &cfg, const char *text, size_t len, int fmt, uint32_t *record)
 {
     static thread_local Tree j;
-    if (!parse_json(j, text, len) || j.nodes.empty() || j.nodes[0].kind != kObj) return kMalformed;
-    if (fmt == SS_TEXT_AUTO) fmt = j.member(0, "COMMITMENTS") ? SS_TEXT_WIT : SS_TEXT_JSON;
-    return fmt == SS_TEXT_WIT ? stwo_from_wit(cfg, j, record) : stwo_from_json(cfg, j, record);
+    if (len > kMaxTextBytes) return kMalformed;
+    ParseResult r = kMalformed;
+    if (parse_json(j, text, len) && !j.nodes.empty() && j.nodes[0].kind == kObj) {
+        if (fmt == SS_TEXT_AUTO) fmt = j.member(0, "COMMITMENTS") ? SS_TEXT_WIT : SS_TEXT_JSON;
+        r = fmt == SS_TEXT_WIT ? stwo_from_wit(cfg, j, record) : stwo_from_json(cfg, j, record);
+    }
+    tree_trim(j);
+    return r;
 }
 
 // ============================================================================= stark101
@@ -860,7 +875,8 @@ bool s101_from_parts(const Tree &tr, uint32_t root, const Tree &te, uint32_t eva
 S101Parsed *s101_parse_text(const char *text, size_t len, int fmt)
 {
     static thread_local Tree j;
-    if (!parse_json(j, text, len) || j.nodes.empty() || j.nodes[0].kind != kObj) return nullptr;
+    if (len > kMaxTextBytes) return nullptr;
+    if (!parse_json(j, text, len) || j.nodes.empty() || j.nodes[0].kind != kObj) { tree_trim(j); return nullptr; }
     if (fmt == SS_TEXT_AUTO) fmt = j.member(0, "P_MT_ROOT") ? SS_TEXT_WIT : SS_TEXT_JSON;
     S101Parsed *p = new S101Parsed();
     bool ok;

@@ -224,3 +224,33 @@ def test_packed_hash_lists_do_not_change_the_meaning_of_other_lists():
     obj = ss.stwo_to_json(p)
     obj["commitments"][2] = [[1] * 32]                              # a hash nested one level too deep
     assert _check(json.dumps(obj).encode(), p.cfg, "json") == MALFORMED
+
+
+def test_oversized_and_deeply_nested_texts_are_malformed_not_fatal():
+    cfg = ss.TESTING_CONFIG
+    assert verifier.parse_stwo_text(cfg, b"[" * 100000)[0] == MALFORMED            # nesting bound
+    assert verifier.parse_stwo_text(cfg, b"{\"a\": " + b"1," * 10)[0] == MALFORMED
+    big = b"{\"x\": [" + b"1," * (17 << 20) + b"1]}"                                  # > 32 MiB of text
+    assert len(big) > (32 << 20) and verifier.parse_stwo_text(cfg, big)[0] == MALFORMED
+    assert verifier.parse_s101_text(big)[0] == MALFORMED
+
+
+def test_native_readers_under_address_and_ub_sanitizers(tmp_path):
+    """tests/native/ingest_fuzz.cpp: csrc/ss_ingest.cpp compiled with -fsanitize=address,undefined
+    (gcc, CPU only) parses the reference's files and thousands of seeded mutants of them; the run
+    aborts on any memory error, integer overflow UB or write past the record."""
+    import subprocess
+    from conftest import ROOT
+    csrc = os.path.join(ROOT, "stark-symphony_amd", "csrc")
+    exe = str(tmp_path / "ingest_fuzz")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                    "-I" + csrc, os.path.join(ROOT, "tests", "native", "ingest_fuzz.cpp"),
+                    os.path.join(csrc, "ss_ingest.cpp"), "-o", exe, "-lpthread"], check=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    runs = [("production", [os.path.join(GOLDEN, "stwo_proof.json"), os.path.join(FORMATS, "stwo_proof.wit")], 400),
+            ("testing", [os.path.join(GOLDEN, "stwo_proof_test.json"), os.path.join(FORMATS, "stwo_proof_test.wit")], 1500),
+            ("s101", [os.path.join(GOLDEN, "stark101_proof.json"), os.path.join(FORMATS, "stark101_proof.wit")], 600)]
+    for profile, files, n in runs:
+        r = subprocess.run([exe, "20261003", str(n), profile] + files, capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, (profile, r.stdout[-500:], r.stderr[-3000:])
+        assert "parses:" in r.stdout
