@@ -229,6 +229,69 @@ def stark101_from_json(obj: Any) -> Stark101Proof:
         raise MalformedProof("missing key %s" % e) from e
 
 
+S101_P = 3 * 2 ** 30 + 1
+
+
+def stark101_from_transcript(messages: Sequence[Any]) -> Stark101Proof:
+    """The in-Python caller format: `channel.proof`, the message list that
+    fibsquare.prover.prove() returns beside `res` and that the reference's own Python verifier replays
+    (stark101/scripts/fibsquare/prover_test.py:32-104): p_mt_root, the FRI layer roots, the last
+    layer's constant, then (value, authentication path) per decommitment -- the three trace
+    evaluations and cpa / cpb of every layer -- and the constant once more.  A message is `bytes`, a
+    FieldElement (anything with `.val`) or int, or a list of `bytes` (paths, ROOT -> LEAF as the
+    prover's channel records them; `res` and the records hold them leaf -> root, prover.py:144-146).
+
+    The list carries no betas (the verifier draws them); `res` does (prover.py:150-167), so they are
+    re-drawn here exactly as prove() packs them: state = sha256(state || root), beta = state mod p,
+    state = sha256(state) (channel.py:48-83).  The GPU verifier still draws its own and compares."""
+    import hashlib
+    msgs = list(messages)
+    pos = 0
+
+    def kind(m: Any) -> str:
+        if isinstance(m, (bytes, bytearray)):
+            return "bytes"
+        if isinstance(m, (list, tuple)):
+            return "path"
+        return "felt"
+
+    def take(want: str) -> Any:
+        nonlocal pos
+        if pos >= len(msgs) or kind(msgs[pos]) != want:
+            raise MalformedProof("transcript message %d: expected %s" % (pos, want))
+        m = msgs[pos]
+        pos += 1
+        if want == "felt":
+            return _u32(getattr(m, "val", m))
+        if want == "bytes":
+            if len(m) != 32:
+                raise MalformedProof("transcript message %d: a commitment is 32 bytes" % (pos - 1))
+            return bytes(m)
+        return _path([bytes(x) for x in m][::-1])
+    root = take("bytes")
+    roots: List[bytes] = []
+    while pos < len(msgs) and kind(msgs[pos]) == "bytes":
+        roots.append(take("bytes"))
+    if len(roots) > MAX_LIST:
+        raise MalformedProof("List<FriLayer, 32> holds at most 31 layers")
+    last = take("felt")
+    evals = [Stark101Eval(take("felt"), take("path")) for _ in range(3)]
+    state = hashlib.sha256(root).digest()
+    for _ in range(3):  # the three composition coefficients (air.simf:30-35)
+        state = hashlib.sha256(state).digest()
+    layers = []
+    for r in roots:
+        state = hashlib.sha256(state + r).digest()
+        beta = int.from_bytes(state, "big") % S101_P
+        state = hashlib.sha256(state).digest()
+        cpa = Stark101Eval(take("felt"), take("path"))
+        cpb = Stark101Eval(take("felt"), take("path"))
+        layers.append(Stark101Layer(r, beta, cpa, cpb))
+    if take("felt") != last or pos != len(msgs):
+        raise MalformedProof("the transcript must end with the last layer's constant, sent twice with one value")
+    return Stark101Proof(root, evals, layers, last)
+
+
 def stark101_to_json(p: Stark101Proof) -> dict:
     def pth(a: np.ndarray) -> List[int]:
         return [bytes_to_u256(bytes(r)) for r in a]

@@ -403,3 +403,25 @@ def test_oracle_batch_groups_mixed_configs(stwo_small, stwo_prod):
     bad.trace_paths = bad.trace_paths[:-1]  # fewer paths than queries: refused before C sees a pointer
     with pytest.raises(ValueError):
         O.stwo_verify(bad)
+
+
+def test_stark101_channel_proof_transcript_reads_as_the_res_dict(s101_proof):
+    """The in-Python caller format: `channel.proof` of fibsquare.prover.prove() (59 messages, captured
+    by tests/golden/make_stark101_golden.py from the reference's own prover) gives the same proof as
+    the `res` dict of that very run, betas included."""
+    raw = json.load(open(os.path.join(ROOT, "tests", "golden", "stark101_transcript.json")))
+
+    class Felt:  # stands in for fibsquare.field.FieldElement
+        def __init__(self, v):
+            self.val = v
+    msgs = [bytes.fromhex(m["bytes"]) if "bytes" in m else Felt(m["felt"]) if "felt" in m
+            else [bytes.fromhex(x) for x in m["path"]] for m in raw]
+    assert len(msgs) == 59
+    got = ss.stark101_from_transcript(msgs)
+    assert ss.stark101_to_json(got) == ss.stark101_to_json(s101_proof)
+    assert ss.stark101_to_json(ss.stark101_from_transcript(
+        [m.val if isinstance(m, Felt) else m for m in msgs])) == ss.stark101_to_json(s101_proof)  # plain ints too
+    for bad in (msgs[:-1], msgs[:5], msgs + [Felt(1)], [msgs[11]] + msgs[1:], msgs[:-1] + [Felt(msgs[-1].val ^ 1)],
+                msgs[:12] + [msgs[13], msgs[12]] + msgs[14:], [b"short"] + msgs[1:]):
+        with pytest.raises(ss.MalformedProof):
+            ss.stark101_from_transcript(bad)
