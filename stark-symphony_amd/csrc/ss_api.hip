@@ -211,7 +211,7 @@ static bool cfg_ok(const ss_stwo_cfg *c)
 static StwoLayout lay_of(const ss_stwo_cfg *c, size_t n)
 {
     return stwo_layout(c->n_cols, c->trace_log, c->lde_log, c->n_queries, c->n_layers, c->mode,
-                       c->pow_target, n, !(c->flags & SS_FLAG_NO_DEDUP));
+                       c->pow_target, n, !(c->flags & SS_FLAG_NO_DEDUP), c->hash == SS_HASH_BLAKE2S);
 }
 
 extern "C" size_t ss_stwo_record_words(const ss_stwo_cfg *c)

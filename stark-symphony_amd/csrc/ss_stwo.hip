@@ -867,13 +867,13 @@ stwo_merkle_kernel_b2s(StwoLayout lay, const uint32_t *__restrict__ batch, uint3
 {
     stwo_merkle_body<1>(lay, batch, ws, status);
 }
-__global__ void __launch_bounds__(kTopChains, 4)
+__global__ void __launch_bounds__(kTopChains, 3)
 stwo_top_kernel_sha(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,
                     uint32_t *__restrict__ status)
 {
     stwo_top_body<0>(lay, batch, ws, status);
 }
-__global__ void __launch_bounds__(kTopChains, 4)
+__global__ void __launch_bounds__(kTopChains, 3)
 stwo_top_kernel_b2s(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,
                     uint32_t *__restrict__ status)
 {

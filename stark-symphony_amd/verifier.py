@@ -244,7 +244,7 @@ def merkle_node_hashes(cfg: StwoConfig, queries: Sequence[int], levels: Optional
     has position query >> (lde_log - d)."""
     L, Q, K = cfg.lde_log, cfg.n_queries, cfg.n_layers
     if levels is None:
-        levels = min((Q - 1).bit_length() + 2, L) if Q > 1 else 0
+        levels = min((Q - 1).bit_length() + (1 if cfg.hash == "blake2s" else 2), L) if Q > 1 else 0
     lens = [L, L] + [L - 1 - l for l in range(K + 1)]
     full = Q * sum(lens)
     done = 0
