@@ -18,11 +18,15 @@ def short(name: str) -> str:
     return m.group(1) if m else name.split("(")[0][-40:]
 
 
-def summarise(dirs):
+def summarise(dirs, newest_only=False):
+    """newest_only: of several runs merged into one directory, read only the latest file"""
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     dur = collections.defaultdict(list)
     for d in dirs:
-        for path in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+        paths = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
+        if newest_only and paths:
+            paths = [max(paths, key=os.path.getmtime)]
+        for path in paths:
             seen = set()
             for row in csv.DictReader(open(path)):
                 k = short(row["Kernel_Name"])

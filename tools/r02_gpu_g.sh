@@ -11,8 +11,8 @@ for w in stwo_2p20 stwo_2p16 stwo_2p16_blake2s; do
   python bench.py --workload $w --steps 40 --warmup 4 --no-cpu-baseline --no-dedup --e2e 0 > $O/bench_${w}_nodedup.json 2>> $O/bench_$w.err
 done
 python bench.py --proofs-per-gpu 8192 --steps 100 --warmup 6 --no-cpu-baseline --e2e 0 > $O/bench_stwo_2p20_8192.json 2> $O/bench_8192.err
-python bench.py --workload stark101 --steps 96 --warmup 6 --cpu-seconds 3 > $O/bench_stark101_4096.json 2> $O/bench_stark101.err
-python bench.py --workload stark101 --proofs-per-gpu 8192 --steps 96 --warmup 6 --no-cpu-baseline > $O/bench_stark101_8192.json 2>> $O/bench_stark101.err
+python bench.py --workload stark101 --steps 1920 --warmup 6 --cpu-seconds 3 > $O/bench_stark101_4096.json 2> $O/bench_stark101.err
+python bench.py --workload stark101 --proofs-per-gpu 8192 --steps 960 --warmup 6 --no-cpu-baseline > $O/bench_stark101_8192.json 2>> $O/bench_stark101.err
 build/sha_bench 512 > $O/sha_bench.txt 2>&1
 python tools/host_path_bench.py 2048 > $O/host_path.txt 2>&1
 cd /tmp; export TMPDIR=/tmp
