@@ -645,3 +645,38 @@ def test_stark101_text_ingestion(ver, tmp_path, s101_proof):
     st, _ = ver.verify_stark101_files([os.path.join(GOLDEN, "stark101_proof.json"),
                                        os.path.join(GOLDEN, "formats", "stark101_proof.wit"), str(tmp_path / "none")])
     assert st.tolist() == [0, 0, 2]
+
+
+def test_simfony_run_shim_in_c(tmp_path):
+    """examples/ss_run.c on the GPU: the reference's `make run` with the binary swapped.  Exit 0 / 1 and the
+    stderr prefix of simfony-cli/src/main.rs:205-206,254-257, no Python in the verifying process."""
+    import json
+    import os
+    import subprocess
+    from conftest import GOLDEN
+    from test_host import _build_c_example
+    exe = _build_c_example(tmp_path, "ss_run")
+    F = os.path.join(GOLDEN, "formats")
+
+    def run(*args):
+        r = subprocess.run([exe, "run", *args], capture_output=True, text=True, timeout=300)
+        r.stderr = "".join(l for l in r.stderr.splitlines(True) if "amdgpu.ids" not in l)
+        return r
+    r = run("../target/main.out.simf", "--witness", os.path.join(F, "stark101_proof.wit"))   # family from the witness
+    assert r.returncode == 0 and "ACCEPT" in r.stdout and r.stderr == ""
+    r = run("stwo-verifier/main.simf", "--witness", os.path.join(F, "stwo_proof.wit"))
+    assert r.returncode == 0 and "ACCEPT" in r.stdout
+    r = run("main.simf", "--config", "testing", "--witness", os.path.join(F, "stwo_proof_test.wit"))
+    assert r.returncode == 0
+    r = run("main.simf", "--witness", os.path.join(F, "stwo_proof_test.wit"))                  # production program, test witness
+    assert r.returncode == 1 and r.stderr.startswith("Error: Failed to run program")
+    r = run("main.simf", "--mode", "literal", "--witness", os.path.join(F, "stwo_proof.wit"))
+    assert r.returncode == 1 and "0x07000001" in r.stderr
+    wit = json.load(open(os.path.join(F, "stwo_proof.wit")))
+    v = wit["POW_NONCE"]["value"]
+    wit["POW_NONCE"]["value"] = str(int(v) + 1)
+    bad = tmp_path / "bad.wit"
+    bad.write_text(json.dumps(wit))
+    r = run("main.simf", "--witness", os.path.join(F, "stwo_proof.wit"), "--witness", str(bad))
+    assert r.returncode == 1 and r.stdout.count("ACCEPT") == 1 and "assertion failed" in r.stderr
+    assert run("main.simf", "--witness", str(tmp_path / "absent.wit")).returncode == 1

@@ -307,13 +307,29 @@ def test_cli_convert_prints_what_the_reference_adapters_print():
                          os.path.join(FORMATS, "stwo_proof_test.wit")]) == 1  # needs --trace-log
 
 
-def _build_c_example(tmp_path):
-    exe = str(tmp_path / "ss_verify_file")
+def _build_c_example(tmp_path, name="ss_verify_file"):
+    exe = str(tmp_path / name)
     libdir = os.path.join(ROOT, "stark-symphony_amd")
     subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
-                    os.path.join(ROOT, "examples", "ss_verify_file.c"), "-o", exe, "-L" + libdir,
+                    os.path.join(ROOT, "examples", name + ".c"), "-o", exe, "-L" + libdir,
                     "-lss_verify", "-Wl,-rpath," + libdir], check=True)
     return exe
+
+
+def test_simfony_run_shim_in_c_builds_and_refuses_to_invent_a_verdict(tmp_path):
+    """examples/ss_run.c (`simfony run <program> --witness <wit>` over the C ABI): without a GPU it
+    exits 2 with the library's error, never 0 or 1; bad usage is 2 as well."""
+    import torch
+    exe = _build_c_example(tmp_path, "ss_run")
+    wit = os.path.join(FORMATS, "stark101_proof.wit")
+    r = subprocess.run([exe, "run", "stark101/main.simf", "--witness", wit], capture_output=True, text=True)
+    if torch.cuda.is_available():
+        assert r.returncode == 0 and "ACCEPT" in r.stdout
+    else:
+        assert r.returncode == 2 and "libss_verify" in r.stderr and "ACCEPT" not in r.stdout
+    assert subprocess.run([exe, "build", "x"], capture_output=True).returncode == 2
+    assert subprocess.run([exe, "run", "x.simf", "--bogus", "1"], capture_output=True).returncode == 2
+    assert subprocess.run([exe, "run", "x.simf"], capture_output=True).returncode == 1  # no witness
 
 
 def test_c_abi_consumer_builds_and_fails_loudly_without_a_gpu(tmp_path, s101_proof):
