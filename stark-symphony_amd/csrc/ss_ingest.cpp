@@ -946,6 +946,20 @@ unsigned effective_cpus()
             if (cores >= 1 && cores < n) n = cores;
         }
         fclose(f);
+    } else {  // cgroup v1
+        long quota = -1, period = 0;
+        if (FILE *q = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            if (fscanf(q, "%ld", &quota) != 1) quota = -1;
+            fclose(q);
+        }
+        if (FILE *q = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (fscanf(q, "%ld", &period) != 1) period = 0;
+            fclose(q);
+        }
+        if (quota > 0 && period > 0) {
+            const unsigned cores = (unsigned)((quota + period - 1) / period);
+            if (cores >= 1 && cores < n) n = cores;
+        }
     }
     return n ? n : 1;
 }
