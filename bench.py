@@ -101,7 +101,7 @@ def pmc_traffic(wname: str, n_local: int):
         except (OSError, ValueError):
             continue
         if d.get("workload") == wname:
-            src = "%s (rocprofv3 --pmc passes at commit %s; kernels changed since = stale)" % (
+            src = "%s (rocprofv3 --pmc passes taken at commit %s; stale if the Merkle kernels changed after it)" % (
                 os.path.relpath(path, ROOT), d.get("commit", "unrecorded"))
             return d["hbm_bytes_per_proof"] * n_local, src
     return None, "no PMC profile of this workload under profiles/"

@@ -680,3 +680,24 @@ def test_simfony_run_shim_in_c(tmp_path):
     r = run("main.simf", "--witness", os.path.join(F, "stwo_proof.wit"), "--witness", str(bad))
     assert r.returncode == 1 and r.stdout.count("ACCEPT") == 1 and "assertion failed" in r.stderr
     assert run("main.simf", "--witness", str(tmp_path / "absent.wit")).returncode == 1
+
+
+def test_independent_streams_match_single_stream(ver, s101_proof, stwo_prod):
+    """verifier.IndependentStreams (whole passes on their own streams, what bench.py uses for small
+    batches): every slot ends with the oracle's status words and accept count, also when a slot is
+    reused many times."""
+    rng = np.random.default_rng(SEED + 51)
+    d101 = [s101_proof] + [formats.stark101_corrupt(s101_proof, rng)[0] for _ in range(5)]
+    dstw = [stwo_prod] + [formats.stwo_corrupt(stwo_prod, rng)[0] for _ in range(5)]
+    for batch, want_d in ((ver.stark101_batch([d101[i % 6] for i in range(300)]), O.s101_verify_batch(d101)),
+                          (ver.stwo_batch([dstw[i % 6] for i in range(150)]), O.stwo_verify_batch(dstw))):
+        want = [int(want_d[i % 6]) for i in range(batch.n)]
+        slots = [batch.sibling() for _ in range(5)]
+        ind = verifier.IndependentStreams(slots)
+        for s in slots:
+            s.status_dev.fill_(0x55)
+        used = [ind.submit() for _ in range(23)]
+        ind.synchronize()
+        assert used == [i % 5 for i in range(23)]
+        for s in slots:
+            assert s.status().tolist() == want and s.accepted() == sum(1 for w in want if w == 0)
