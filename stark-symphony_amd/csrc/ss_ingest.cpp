@@ -67,12 +67,12 @@ struct Tree {
     {
         if (nodes[obj].kind != kObj) return 0;
         const size_t kl = strlen(key);
-        uint32_t c = nodes[obj].val ? obj + 1 : 0;
-        while (c) {
-            if (nodes[c].key_len == kl && memcmp(text + nodes[c].key_off, key, kl) == 0) return resolve(c);
+        uint32_t c = nodes[obj].val ? obj + 1 : 0, found = 0;
+        while (c) {  // the LAST member of that name, as Python's json.loads keeps it
+            if (nodes[c].key_len == kl && memcmp(text + nodes[c].key_off, key, kl) == 0) found = resolve(c);
             c = nodes[c].next;
         }
-        return 0;
+        return found;
     }
 };
 
@@ -218,6 +218,8 @@ struct Json {
                 if (obj) {
                     ws();
                     if (p >= end || *p != '"' || !string(ko, kl)) { fail(); break; }
+                    // an escaped key could spell a member name this reader would not recognise: refused
+                    if (memchr(t.text + ko, '\\', kl)) { fail(); break; }
                     ws();
                     if (p >= end || *p != ':') { fail(); break; }
                     p++;

@@ -254,3 +254,17 @@ def test_native_readers_under_address_and_ub_sanitizers(tmp_path):
         r = subprocess.run([exe, "20261003", str(n), profile] + files, capture_output=True, text=True, env=env, timeout=900)
         assert r.returncode == 0, (profile, r.stdout[-500:], r.stderr[-3000:])
         assert "parses:" in r.stdout
+
+
+def test_duplicate_and_escaped_member_names():
+    """Python's json.loads keeps the LAST of duplicate members; so does the native reader (a proof that
+    declares its config twice is judged by the same declaration in both).  A member name written with
+    an escape is refused by the native reader rather than silently not recognised."""
+    text = open(os.path.join(GOLDEN, "stwo_proof.json"), "rb").read()
+    dup_bad_last = text[:-1] + b', "config": {"pow_bits": 0, "fri_config": {"log_blowup_factor": 4, "n_queries": 16}}}'
+    dup_good_last = b'{"config": {"pow_bits": 0}, ' + text[1:]
+    assert _check(dup_bad_last, ss.PRODUCTION_CONFIG, "json") == MISMATCH
+    assert _check(dup_good_last, ss.PRODUCTION_CONFIG, "json") == OK
+    escaped = text.replace(b'"config"', b'"\\u0063onfig"', 1)
+    assert json.loads(escaped)["config"]["pow_bits"] == 5
+    assert verifier.parse_stwo_text(ss.PRODUCTION_CONFIG, escaped)[0] == MALFORMED
