@@ -335,6 +335,37 @@ struct Literal {
             if (p >= end || *p != '[') { t.ok = false; return 0; }
             return seq(']', depth);
         }
+        if (end - p >= 4 && memcmp(p, "qm31", 4) == 0) {
+            // qm31(a, b, c, d) of the .simf snippets (formats.parse_literal accepts it anywhere):
+            // the value ((a, b), (c, d)), built in place
+            p += 4;
+            ws();
+            if (p >= end || *p != '(') { t.ok = false; return 0; }
+            p++;
+            const uint32_t outer = t.push(kList), in1 = t.push(kList);
+            uint32_t in2 = 0, prev = 0, n = 0;
+            while (t.ok) {
+                ws();
+                if (p >= end) { t.ok = false; break; }
+                if (*p == ')') { p++; break; }
+                if (n == 4) { t.ok = false; break; }
+                if (n == 2) { in2 = t.push(kList); prev = 0; }
+                const uint32_t c = value(depth + 1);
+                if (!t.ok) break;
+                if (prev) t.nodes[prev].next = c;
+                prev = c;
+                n++;
+                ws();
+                if (p < end && *p == ',') p++;
+            }
+            if (n != 4) t.ok = false;
+            if (!t.ok) return outer;
+            t.nodes[outer].val = 2;
+            t.nodes[in1].val = 2;
+            t.nodes[in2].val = 2;
+            t.nodes[in1].next = in2;
+            return outer;
+        }
         if (*p == '(') return seq(')', depth);
         if (*p == '[') return seq(']', depth);
         const uint32_t idx = t.push(kOther);

@@ -532,7 +532,7 @@ def stwo_from_json(data: Any, trace_log: int | None = None, hash: str | None = N
         nonce = _uint(data.get("proof_of_work", 0), 64)
         return StwoProof(cfg, roots.copy(), oods_trace, oods_cp, trace_vals, cp_vals, trace_paths,
                          cp_paths, fri_roots.copy(), last, fri_witness, fri_paths, nonce)
-    except (KeyError, IndexError, TypeError) as e:
+    except (KeyError, IndexError, TypeError, AttributeError) as e:  # wrong nesting, a list where an object belongs
         raise MalformedProof(str(e)) from e
 
 

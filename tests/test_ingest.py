@@ -4,6 +4,7 @@ grammar of stark-symphony_amd/formats.py: same records for everything the refere
 accept / malformed / other-config outcome for broken inputs.  No GPU needed: parsing is host code."""
 import json
 import os
+import re
 
 import numpy as np
 import pytest
@@ -191,6 +192,12 @@ def test_malformed_wit_gets_the_python_outcome():
         with_value("OODS_EVALS", lambda v: v.replace("((1, 0), (0, 0))", "[[((1, 0), (0, 0))]]", 1)),
         with_value("OODS_EVALS", lambda v: v.replace("((1, 0), (0, 0))", "((1, 0, 0), (0,))", 1)),
         with_value("OODS_EVALS", lambda v: v.replace("(1, 0)", "(4294967296, 0)", 1)),
+        with_value("OODS_EVALS", lambda v: v.replace("((1, 0), (0, 0))", "qm31(1, 0, 0, 0)", 1)),    # .simf constructor
+        with_value("OODS_EVALS", lambda v: v.replace("((1, 0), (0, 0))", "qm31 ( 1 0 0 0 )", 1)),
+        with_value("OODS_EVALS", lambda v: v.replace("((1, 0), (0, 0))", "qm31(1, 0, 0)", 1)),
+        with_value("OODS_EVALS", lambda v: v.replace("((1, 0), (0, 0))", "qm31(1, 0, 0, 0, 0)", 1)),
+        with_value("OODS_EVALS", lambda v: v.replace("((1, 0), (0, 0))", "qm31[1, 0, 0, 0]", 1)),
+        with_value("FRI_COMMITMENTS", lambda v: re.sub(r"\(\((\d+), (\d+)\), \((\d+), (\d+)\)\)\)$", r"qm31(\1, \2, \3, \4))", v)),
         with_value("FRI_COMMITMENTS", lambda v: v.replace("[", "list![", 1)),
         with_value("FRI_DECOMMITMENTS", lambda v: v.replace("list![", "list![" + "1, " * 31, 1)),  # 32+ siblings
         with_value("FRI_DECOMMITMENTS", lambda v: v.replace("list![", "list![7, ", 1)),           # one sibling more
