@@ -38,7 +38,7 @@ static std::string mutate(const std::string &s)
         case 4: m[at] = "0123456789"[rnd() % 10]; break;
         case 5: m[at] = "[](){},:\" x_"[rnd() % 12]; break;
         case 6: m.insert(at, std::string(1 + rnd() % 90, (char)('0' + rnd() % 10))); break;
-        default: m.insert(at, rnd() % 2 ? "list![" : "0x"); break;
+        default: { static const char *ins[3] = {"list![", "0x", "qm31("}; m.insert(at, ins[rnd() % 3]); break; }
         }
     }
     return m;
