@@ -35,7 +35,50 @@ struct Node {
 
 struct U256 { uint32_t w[8]; };  // w[0] most significant = word 0 of a stored hash
 
+// JSON string body (already validated by Json::string) -> the bytes json.loads would give, UTF-8.
+// Lone surrogates come out as their 3-byte form (they cannot equal any name or digit of the formats).
+static void json_unescape(const char *s, size_t n, std::string &out)
+{
+    out.clear();
+    auto hex4 = [](const char *p) {
+        uint32_t v = 0;
+        for (int k = 0; k < 4; k++) {
+            const char c = p[k];
+            v = v * 16 + (uint32_t)(c <= '9' ? c - '0' : (c | 0x20) - 'a' + 10);
+        }
+        return v;
+    };
+    auto put = [&](uint32_t cp) {
+        if (cp < 0x80) out.push_back((char)cp);
+        else if (cp < 0x800) { out.push_back((char)(0xc0 | (cp >> 6))); out.push_back((char)(0x80 | (cp & 63))); }
+        else if (cp < 0x10000) {
+            out.push_back((char)(0xe0 | (cp >> 12))); out.push_back((char)(0x80 | ((cp >> 6) & 63)));
+            out.push_back((char)(0x80 | (cp & 63)));
+        } else {
+            out.push_back((char)(0xf0 | (cp >> 18))); out.push_back((char)(0x80 | ((cp >> 12) & 63)));
+            out.push_back((char)(0x80 | ((cp >> 6) & 63))); out.push_back((char)(0x80 | (cp & 63)));
+        }
+    };
+    for (size_t i = 0; i < n;) {
+        if (s[i] != '\\') { out.push_back(s[i++]); continue; }
+        const char e = s[i + 1];
+        if (e == 'u') {
+            uint32_t cp = hex4(s + i + 2);
+            i += 6;
+            if (cp >= 0xd800 && cp < 0xdc00 && i + 6 <= n && s[i] == '\\' && s[i + 1] == 'u') {
+                const uint32_t lo = hex4(s + i + 2);
+                if (lo >= 0xdc00 && lo < 0xe000) { cp = 0x10000 + ((cp - 0xd800) << 10) + (lo - 0xdc00); i += 6; }
+            }
+            put(cp);
+        } else {
+            out.push_back(e == 'b' ? '\b' : e == 'f' ? '\f' : e == 'n' ? '\n' : e == 'r' ? '\r' : e == 't' ? '\t' : e);
+            i += 2;
+        }
+    }
+}
+
 struct Tree {
+    std::string owned;  // the text itself when it had to be un-escaped first (a .wit value with escapes)
     const char *text = nullptr;
     std::vector<Node> nodes;
     std::vector<U256> bigs;
@@ -68,8 +111,16 @@ struct Tree {
         if (nodes[obj].kind != kObj) return 0;
         const size_t kl = strlen(key);
         uint32_t c = nodes[obj].val ? obj + 1 : 0, found = 0;
+        std::string tmp;
         while (c) {  // the LAST member of that name, as Python's json.loads keeps it
-            if (nodes[c].key_len == kl && memcmp(text + nodes[c].key_off, key, kl) == 0) found = resolve(c);
+            const char *k = text + nodes[c].key_off;
+            size_t n = nodes[c].key_len;
+            if (memchr(k, '\\', n)) {  // an escaped spelling: compare what it decodes to
+                json_unescape(k, n, tmp);
+                k = tmp.data();
+                n = tmp.size();
+            }
+            if (n == kl && memcmp(k, key, kl) == 0) found = resolve(c);
             c = nodes[c].next;
         }
         return found;
@@ -155,20 +206,77 @@ struct Json {
     void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++; }
     bool fail() { t.ok = false; return false; }
 
-    // a string body up to the closing quote; escapes are skipped over, never decoded (no key or
-    // literal of the formats contains one; a value with an escape simply matches nothing)
+    // A string body up to the closing quote, held to the JSON grammar (what json.loads enforces):
+    // no raw control characters, only the defined escapes, well-formed UTF-8.  Escapes are validated,
+    // never decoded: no key or literal of the formats contains one.
     bool string(uint32_t &off, uint32_t &len)
     {
         p++;  // opening quote
         const char *s = p;
         while (p < end && *p != '"') {
-            if (*p == '\\') p++;
+            const unsigned char c = (unsigned char)*p;
+            if (c < 0x20) return fail();
+            if (c == '\\') {
+                if (p + 1 >= end) return fail();
+                const char e = p[1];
+                if (e == 'u') {
+                    if (end - p < 6) return fail();
+                    for (int k = 2; k < 6; k++)
+                        if (kHexVal[(unsigned char)p[k]] == 0xff) return fail();
+                    p += 6;
+                } else if (e == '"' || e == '\\' || e == '/' || e == 'b' || e == 'f' || e == 'n' || e == 'r' || e == 't') {
+                    p += 2;
+                } else {
+                    return fail();
+                }
+                continue;
+            }
+            if (c >= 0x80) {  // UTF-8: lead byte, continuation count, no overlongs / surrogates / > U+10FFFF
+                int n = c >= 0xf0 ? 3 : c >= 0xe0 ? 2 : c >= 0xc2 ? 1 : -1;
+                if (n < 0 || c > 0xf4 || end - p <= n) return fail();
+                const unsigned char c1 = (unsigned char)p[1];
+                if ((c1 & 0xc0) != 0x80) return fail();
+                if ((c == 0xe0 && c1 < 0xa0) || (c == 0xed && c1 > 0x9f) || (c == 0xf0 && c1 < 0x90) || (c == 0xf4 && c1 > 0x8f))
+                    return fail();
+                for (int k = 2; k <= n; k++)
+                    if (((unsigned char)p[k] & 0xc0) != 0x80) return fail();
+                p += n + 1;
+                continue;
+            }
             p++;
         }
         if (p >= end) return fail();
         off = (uint32_t)(s - t.text);
         len = (uint32_t)(p - s);
         p++;
+        return true;
+    }
+
+    // the rest of a number after its integer digits: optional fraction and exponent, each with at
+    // least one digit (JSON grammar); returns false on a malformed tail
+    bool number_tail(bool &is_float)
+    {
+        is_float = false;
+        if (p < end && *p == '.') {
+            is_float = true;
+            p++;
+            if (p >= end || *p < '0' || *p > '9') return false;
+            while (p < end && *p >= '0' && *p <= '9') p++;
+        }
+        if (p < end && (*p == 'e' || *p == 'E')) {
+            is_float = true;
+            p++;
+            if (p < end && (*p == '+' || *p == '-')) p++;
+            if (p >= end || *p < '0' || *p > '9') return false;
+            while (p < end && *p >= '0' && *p <= '9') p++;
+        }
+        return true;
+    }
+    bool word(const char *w)
+    {
+        const size_t n = strlen(w);
+        if ((size_t)(end - p) < n || memcmp(p, w, n) != 0) return false;
+        p += n;
         return true;
     }
 
@@ -189,8 +297,9 @@ struct Json {
                 while (q < end && (*q == ' ' || *q == '\n' || *q == '\t' || *q == '\r')) q++;
                 uint32_t v = 0;
                 int nd = 0;
+                const char first = q < end ? *q : 0;
                 while (q < end && *q >= '0' && *q <= '9' && nd < 4) { v = v * 10 + (uint32_t)(*q - '0'); q++; nd++; }
-                if (nd == 0 || nd > 3 || v > 255) { ok = false; break; }
+                if (nd == 0 || nd > 3 || v > 255 || (nd > 1 && first == '0')) { ok = false; break; }
                 w[k >> 2] = (w[k >> 2] << 8) | v;
                 k++;
                 while (q < end && (*q == ' ' || *q == '\n' || *q == '\t' || *q == '\r')) q++;
@@ -218,8 +327,6 @@ struct Json {
                 if (obj) {
                     ws();
                     if (p >= end || *p != '"' || !string(ko, kl)) { fail(); break; }
-                    // an escaped key could spell a member name this reader would not recognise: refused
-                    if (memchr(t.text + ko, '\\', kl)) { fail(); break; }
                     ws();
                     if (p >= end || *p != ':') { fail(); break; }
                     p++;
@@ -227,9 +334,8 @@ struct Json {
                 const uint32_t c = value(depth + 1);
                 if (!t.ok) break;
                 if (obj) {
-                    if (kl > 255) { fail(); break; }
                     t.nodes[c].key_off = ko;
-                    t.nodes[c].key_len = (uint8_t)kl;
+                    t.nodes[c].key_len = kl > 255 ? 0 : (uint8_t)kl;  // no member name is that long: matches nothing
                 }
                 if (prev) t.nodes[prev].next = c;
                 prev = c;
@@ -253,21 +359,30 @@ struct Json {
         if (ch >= '0' && ch <= '9') {
             const char *s = p;
             while (p < end && *p >= '0' && *p <= '9') p++;
+            const size_t nd = (size_t)(p - s);
             const uint32_t idx = t.push(kOther);
-            if (p < end && (*p == '.' || *p == 'e' || *p == 'E')) {  // a float: never a witness word
-                while (p < end && (*p == '.' || *p == 'e' || *p == 'E' || *p == '+' || *p == '-' || (*p >= '0' && *p <= '9'))) p++;
-                return idx;
-            }
-            if (!number_node(t, idx, s, (size_t)(p - s), 10)) t.nodes[idx].kind = kOther;
+            if (nd > 1 && *s == '0') { fail(); return idx; }  // JSON: no leading zeros
+            bool is_float;
+            if (!number_tail(is_float)) { fail(); return idx; }
+            if (is_float) return idx;  // a float: never a witness word
+            if (!number_node(t, idx, s, nd, 10)) t.nodes[idx].kind = kOther;
             return idx;
         }
-        // true / false / null / negative numbers: syntactically fine, never a witness value
+        // true / false / null, negative numbers, and json.loads' NaN / Infinity: syntactically fine,
+        // never a witness value
         const uint32_t idx = t.push(kOther);
-        if (ch == '-' || (ch >= 'a' && ch <= 'z')) {
+        if (ch == '-') {
             p++;
-            while (p < end && ((*p >= 'a' && *p <= 'z') || (*p >= '0' && *p <= '9') || *p == '.' || *p == 'e' || *p == 'E' || *p == '+' || *p == '-')) p++;
+            if (word("Infinity")) return idx;
+            const char *s = p;
+            while (p < end && *p >= '0' && *p <= '9') p++;
+            const size_t nd = (size_t)(p - s);
+            bool is_float;
+            if (nd == 0 || (nd > 1 && *s == '0') || !number_tail(is_float)) { fail(); return idx; }
+            if (!is_float && nd == 1 && *s == '0') { t.nodes[idx].kind = kInt; t.nodes[idx].val = 0; }  // json.loads("-0") == 0
             return idx;
         }
+        if (word("true") || word("false") || word("null") || word("NaN") || word("Infinity")) return idx;
         fail();
         return idx;
     }
@@ -405,8 +520,12 @@ bool wit_member(const Tree &j, const char *name, Tree &out)
     const uint32_t v = j.member(m, "value");
     if (!v || j.nodes[v].kind != kStr) return false;
     const char *s = j.text + j.nodes[v].val;
-    const size_t n = j.nodes[v].len;
-    if (memchr(s, '\\', n)) return false;
+    size_t n = j.nodes[v].len;
+    if (memchr(s, '\\', n)) {  // escapes in the literal: parse what they decode to
+        json_unescape(s, n, out.owned);
+        s = out.owned.data();
+        n = out.owned.size();
+    }
     tree_reset(out, s);
     out.push(kOther);
     out.root = 1;

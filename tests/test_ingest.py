@@ -266,12 +266,60 @@ def test_native_readers_under_address_and_ub_sanitizers(tmp_path):
 def test_duplicate_and_escaped_member_names():
     """Python's json.loads keeps the LAST of duplicate members; so does the native reader (a proof that
     declares its config twice is judged by the same declaration in both).  A member name written with
-    an escape is refused by the native reader rather than silently not recognised."""
+    an escape is decoded first, in member names and in the literals of a .wit alike."""
     text = open(os.path.join(GOLDEN, "stwo_proof.json"), "rb").read()
     dup_bad_last = text[:-1] + b', "config": {"pow_bits": 0, "fri_config": {"log_blowup_factor": 4, "n_queries": 16}}}'
     dup_good_last = b'{"config": {"pow_bits": 0}, ' + text[1:]
     assert _check(dup_bad_last, ss.PRODUCTION_CONFIG, "json") == MISMATCH
     assert _check(dup_good_last, ss.PRODUCTION_CONFIG, "json") == OK
-    escaped = text.replace(b'"config"', b'"\\u0063onfig"', 1)
-    assert json.loads(escaped)["config"]["pow_bits"] == 5
-    assert verifier.parse_stwo_text(ss.PRODUCTION_CONFIG, escaped)[0] == MALFORMED
+    escaped = text.replace(b'"config"', b'"\\u0063onfig"', 1).replace(b'"pow_bits":5', b'"pow\\u005Fbits":0', 1)
+    assert json.loads(escaped)["config"]["pow_bits"] == 0          # an escaped spelling is still that member
+    assert _check(escaped, ss.PRODUCTION_CONFIG, "json") == MISMATCH
+    wit = json.load(open(os.path.join(FORMATS, "stwo_proof_test.wit")))
+    w = json.dumps(wit).replace('"value": "185"', '"value": "1\\u00385"').encode()   # POW_NONCE 185 with an escaped digit
+    assert b"\\u0038" in w and _check(w, ss.TESTING_CONFIG, "wit") == OK
+    assert _check(b'{"' + b"k" * 300 + b'": 1, ' + text[1:], ss.PRODUCTION_CONFIG, "json") == OK   # a very long member name
+
+
+def _text_mutant(rnd, s: bytes) -> bytes:
+    m = bytearray(s)
+    for _ in range(1 + rnd.randrange(3)):
+        if not m:
+            break
+        at, k = rnd.randrange(len(m)), rnd.randrange(9)
+        if k == 0: m[at] ^= 1 << rnd.randrange(8)
+        elif k == 1: del m[at:at + 1 + rnd.randrange(40)]
+        elif k == 2: m[at:at] = m[at:at + 1 + rnd.randrange(60)]
+        elif k == 3: del m[at:]
+        elif k == 4: m[at] = ord("0123456789"[rnd.randrange(10)])
+        elif k == 5: m[at] = ord("[](){},:\" x_-.eE\\"[rnd.randrange(17)])
+        elif k == 6: m[at:at] = bytes(ord("0") + rnd.randrange(10) for _ in range(1 + rnd.randrange(90)))
+        elif k == 7: m[at:at] = [b"list![", b"0x", b"qm31(", b"null", b"1e3", b"-1", b"\\u0041", b"\xc3\xa9", b"NaN"][rnd.randrange(9)]
+        else: m[at] = rnd.randrange(256)
+    return bytes(m)
+
+
+@pytest.mark.parametrize("kind", ["json", "wit"])
+def test_differential_text_fuzz_native_against_python(kind):
+    """Seeded byte-level mutants of the reference's small proof in both text formats: the native
+    reader and formats.py agree on every one -- parsed (same record), other config, or malformed --
+    down to json.loads' strictness (leading zeros, control characters, escapes, UTF-8)."""
+    import random
+    rnd = random.Random(20261003 + len(kind))
+    path = os.path.join(GOLDEN, "stwo_proof_test.json") if kind == "json" else os.path.join(FORMATS, "stwo_proof_test.wit")
+    base = open(path, "rb").read()
+    cfg = ss.TESTING_CONFIG
+    fmt = 1 if kind == "json" else 2
+    seen = {OK: 0, MISMATCH: 0, MALFORMED: 0}
+    for i in range(3000):
+        text = _text_mutant(rnd, base)
+        try:
+            want, rec = _python_outcome(text, cfg, kind)
+        except (UnicodeDecodeError, RecursionError):
+            want, rec = MALFORMED, None
+        got, grec = verifier.parse_stwo_text(cfg, text, fmt=fmt)
+        assert got == want, (i, got, want)
+        if want == OK:
+            assert np.array_equal(grec, rec), i
+        seen[want] += 1
+    assert seen[OK] > 100 and seen[MALFORMED] > 1000
