@@ -210,10 +210,10 @@ def _s101_from_parts(root: Any, evals: Any, layers: Any, last: Any) -> Stark101P
         for l in layers:
             if len(l) != 6:
                 raise MalformedProof("FriLayer has six fields")
-            ls.append(Stark101Layer(u256_to_bytes(int(l[0])), _u32(l[1]),
+            ls.append(Stark101Layer(u256_to_bytes(_uint(l[0], 256)), _u32(l[1]),
                                     Stark101Eval(_u32(l[2]), _path(l[3])),
                                     Stark101Eval(_u32(l[4]), _path(l[5]))))
-        return Stark101Proof(u256_to_bytes(int(root)), ev, ls, _u32(last))
+        return Stark101Proof(u256_to_bytes(_uint(root, 256)), ev, ls, _u32(last))
     except (TypeError, IndexError, KeyError) as e:  # wrong nesting
         raise MalformedProof(str(e)) from e
 

@@ -323,3 +323,26 @@ def test_differential_text_fuzz_native_against_python(kind):
             assert np.array_equal(grec, rec), i
         seen[want] += 1
     assert seen[OK] > 100 and seen[MALFORMED] > 1000
+
+
+@pytest.mark.parametrize("kind", ["json", "wit"])
+def test_differential_text_fuzz_stark101(kind):
+    """The same for the stark101 readers (shape, record or malformed)."""
+    import random
+    rnd = random.Random(777 + len(kind))
+    path = os.path.join(GOLDEN, "stark101_proof.json") if kind == "json" else os.path.join(FORMATS, "stark101_proof.wit")
+    base = open(path, "rb").read()
+    parsed = 0
+    for i in range(1500):
+        text = _text_mutant(rnd, base)
+        try:
+            p = ss.stark101_from_json(json.loads(text)) if kind == "json" else ss.stark101_from_wit(text.decode())
+            want = (0, verifier.s101_shape_of([p]))
+        except (ss.MalformedProof, ValueError, UnicodeDecodeError, RecursionError):
+            p, want = None, (MALFORMED, None)
+        rc, shape, rec = verifier.parse_s101_text(text, fmt=1 if kind == "json" else 2)
+        assert (rc, shape) == want, i
+        if p is not None:
+            assert np.array_equal(rec, verifier.s101_record(p, *shape)), i
+            parsed += 1
+    assert parsed > 50
