@@ -529,9 +529,10 @@ __device__ __forceinline__ void stwo_merkle_body(const StwoLayout &lay, const ui
 // One block = top_G proofs (top_G * Q <= 256 chains), persistent over groups.  The plan of all depths
 // (leaders, slots, followers, sibling-position leaders) is made once per group in LDS.  The checks
 // are 64 bytes of loads and a compare each and depend on the proof bytes only, so they form one queue
-// per group that the hash loop drains two per iteration: their loads are issued before a SHA-256
-// pair hash and compared after it, which hides their latency behind ALU work of the same wave (blocks
-// sharing a CU run in lockstep, so nothing else would).  Nodes of two consecutive depths live in the
+// per group, cut by depth, that the hash loop of the matching depth drains two per iteration: their
+// loads are issued before a SHA-256 pair hash and compared after it, which hides their latency behind
+// ALU work of the same wave (blocks sharing a CU run in lockstep, so nothing else would); what a
+// shallow depth has beyond two per hash iteration is drained four in flight before its barrier.  Nodes of two consecutive depths live in the
 // block's slice of ws_vals.
 constexpr uint32_t kTopMaxT = 8;  // ceil_log2(kMaxQueries) + 2
 
@@ -555,7 +556,7 @@ __device__ __forceinline__ void stwo_top_body(const StwoLayout &lay, const uint3
     __shared__ uint32_t s_seg_start[kMaxSeg + 1], s_seg_entries[kMaxSeg], s_seg_t0[kMaxSeg], s_seg_nt[kMaxSeg];
     __shared__ uint32_t s_seg_kind_dd[kMaxSeg];  // kind << 8 | depth ; kind 0 same, 1 cross at the edge, 2 edge
     __shared__ uint32_t s_seg_magic[kMaxSeg];    // floor(2^32 / entries) + 1: exact quotients below 2^16
-    __shared__ uint32_t s_nseg, s_grp;
+    __shared__ uint32_t s_grp;
     __shared__ uint8_t s_g[kTopChains];            // chain -> proof of the group
     __shared__ uint8_t s_bad[NT][kTopChains / 2];  // [tree][proof of the group] (Q >= 2: <= 128 proofs)
     __shared__ uint64_t s_path[NT];                // word offset of the tree's path tiles
@@ -699,10 +700,8 @@ __device__ __forceinline__ void stwo_top_body(const StwoLayout &lay, const uint3
                 ns++;
             }
             s_seg_start[ns] = at;
-            s_nseg = ns;
         }
         __syncthreads();
-        const uint32_t nseg = s_nseg, n_light = s_seg_start[nseg];
 
         // node of chain c at depth dd: from stwo_merkle_kernel where the tree enters, else the stored
         // node of its leader (written at depth dd's step, parity dd & 1)
@@ -717,10 +716,11 @@ __device__ __forceinline__ void stwo_top_body(const StwoLayout &lay, const uint3
         // one light check: the loads now, the compare later (after the hash they hide behind)
         struct Light { H8 a, b; uint32_t ti, g; };
         uint32_t seg = 0;  // each lane walks the queue in increasing order
+        uint32_t light_end = 0;  // end of the part of the queue that belongs to the current depth step
         auto light_issue = [&](uint32_t i, Light &x) {
             x.ti = NT;
             x.a = x.b = zero8;
-            if (i >= n_light) return;
+            if (i >= light_end) return;
             while (i >= s_seg_start[seg + 1]) seg++;
             const uint32_t ent = s_seg_entries[seg], kd = s_seg_kind_dd[seg], dd = kd & 0xff, kind = kd >> 8;
             const uint32_t r = i - s_seg_start[seg];
@@ -753,6 +753,12 @@ __device__ __forceinline__ void stwo_top_body(const StwoLayout &lay, const uint3
 
         for (uint32_t d = Tmax; d-- > 0;) {
             const uint32_t par = d & 1;
+            // The checks of depth d + 1 read the sibling level this step's hashes read, so they run in this
+            // step: the users of a 128-byte line of the proof stay close in time.  (The resident blocks'
+            // working sets exceed the 4 MB L2 of an XCD either way: 13.1 GB of L2 misses per 65 536-proof
+            // launch against 13.4 GB with one queue per group drained at its own pace; same run time.)
+            li = s_seg_start[3 * (Tmax - d - 1)] + tid;
+            light_end = s_seg_start[3 * (Tmax - d)];
             const uint32_t nlead = s_nlead[d];
             const uint32_t fri = L - 1 - d < K + 1 ? L - 1 - d : K + 1;  // FRI trees deeper than d
             const uint32_t total = nlead * (2 + fri);
@@ -800,19 +806,18 @@ __device__ __forceinline__ void stwo_top_body(const StwoLayout &lay, const uint3
                 light_settle(x1);
                 nd = nd2; sb = sb2; ys = ys2; ti = ti2; k = k2; flags = flags2;
             }
+            // what this step's hash iterations did not carry (the shallow depths have more checks than
+            // hashes), four in flight
+            while (li - tid < light_end) {  // uniform over the block: li - tid is the same in every lane
+                Light x[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) light_issue(li + u * kTopChains, x[u]);
+#pragma unroll
+                for (int u = 0; u < 4; u++) light_settle(x[u]);
+                li += 4 * kTopChains;
+            }
             __syncthreads();
         }
-        // ---- whatever is left of the queue, four in flight
-        while (true) {
-            Light x[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) light_issue(li + u * kTopChains, x[u]);
-#pragma unroll
-            for (int u = 0; u < 4; u++) light_settle(x[u]);
-            li += 4 * kTopChains;
-            if (li - tid >= n_light) break;  // uniform over the block: li - tid is the same in every lane
-        }
-        __syncthreads();
 
         // ---- roots: at depth 0 proof g's only leader is its first chain, slot g
         for (uint32_t i = tid; i < gp * n_types; i += kTopChains) {
