@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Random stwo shapes through GPU prover -> GPU verifier against the oracle (run on the GPU box).
+
+    python tools/shape_sweep.py [shapes] [seed]
+
+For every random configuration (columns, trace size, blow-up, queries incl. non powers of two up to 64,
+PoW bits, hash family) the GPU prover makes a proof; the valid proof and seeded mutants of it
+(tools/fuzz_parity.mutate_stwo) must get the oracle's status word from the GPU verifier in both
+modes, with the pair memoisation on and off."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import fuzz_parity as fz  # noqa: E402
+from stark_symphony_amd import prover, verifier  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+shapes = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+ver = verifier.Verifier(0)
+plain = verifier.Verifier(0)
+plain.stwo_flags = verifier.FLAG_NO_DEDUP
+gp = prover.GpuProver(ver)
+bad = 0
+for i in range(shapes):
+    q_choices = [1, 2, 3, 5, 7, 8, 13, 16, 17, 24, 31, 32, 33, 48, 63, 64]
+    kw = dict(n_cols=int(rng.integers(3, 41)), trace_log=int(rng.integers(2, 12)), log_blowup=int(rng.integers(1, 5)),
+              n_queries=int(q_choices[int(rng.integers(len(q_choices)))]), pow_bits=int(rng.integers(0, 9)),
+              seed=int(rng.integers(0, 1000)), hash=("sha256", "blake2s")[int(rng.integers(2))])
+    proof = gp.prove_proof(**kw)
+    batch = [proof] * 3 + [fz.mutate_stwo(proof, rng) for _ in range(61)]
+    for mode in (verifier.MODE_FIXTURE, verifier.MODE_LITERAL):
+        want = O.stwo_verify_batch(batch, mode)
+        for v, name in ((ver, "memo"), (plain, "full")):
+            got = v.verify_stwo(batch, mode, cfg=proof.cfg)
+            m = int((got != want).sum())
+            if m:
+                j = int(np.nonzero(got != want)[0][0])
+                print("MISMATCH", kw, "mode", mode, name, "at", j, hex(got[j]), hex(want[j]), flush=True)
+                bad += m
+    if mode == verifier.MODE_LITERAL and i % 10 == 9:
+        print("%d shapes done, last %s" % (i + 1, kw), flush=True)
+print("shapes %d, total mismatches %d" % (shapes, bad))
+sys.exit(1 if bad else 0)
