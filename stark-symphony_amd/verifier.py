@@ -508,6 +508,8 @@ class Verifier:
         return S101DeviceBatch(self, ml, pm, recs * replicate)
 
     def verify_stark101(self, proofs: Sequence[Stark101Proof]) -> np.ndarray:
+        if len(proofs) == 0:  # the C ABI rejects empty batches; an empty list has an empty answer
+            return np.empty(0, dtype=np.uint32)
         b = self.stark101_batch(proofs)
         b.run()
         return b.status()
@@ -549,6 +551,8 @@ class Verifier:
         for r in records:  # the library memcpy's `want` words from every pointer
             if r.dtype != np.uint32 or r.size != want or not r.flags["C_CONTIGUOUS"]:
                 raise ValueError("record must be %d contiguous uint32 words" % want)
+        if len(records) == 0:
+            return np.empty(0, dtype=np.uint32)
         status = np.full(len(records), 0xFFFFFFFF, dtype=np.uint32)  # unwritten = REJECT
         B.check(B.lib().ss_stwo_verify_records(self.ctx, C.byref(cs), len(records), _ptr_array(records),
                                                status.ctypes.data))
@@ -559,6 +563,8 @@ class Verifier:
         n = len(items)
         status = np.full(n, 0xFFFFFFFF, dtype=np.uint32)
         stats = B.IngestStats()
+        if n == 0:
+            return status, {k: 0 for k, _ in B.IngestStats._fields_ if k != "reserved"}
         if items and isinstance(items[0], (bytes, bytearray, memoryview)):
             bufs = [bytes(t) for t in items]
             arr = (C.c_char_p * n)(*bufs)

@@ -701,3 +701,15 @@ def test_independent_streams_match_single_stream(ver, s101_proof, stwo_prod):
         assert used == [i % 5 for i in range(23)]
         for s in slots:
             assert s.status().tolist() == want and s.accepted() == sum(1 for w in want if w == 0)
+
+
+def test_empty_batches_have_empty_answers(ver, stwo_prod):
+    """An empty list of witnesses is not an error at the Python boundary (the C ABI itself rejects
+    n == 0, include/ss_verify.h): every entry point returns an empty status array."""
+    assert ver.verify_stark101([]).shape == (0,)
+    assert ver.verify_stwo([], cfg=stwo_prod.cfg).shape == (0,)
+    assert ver.verify_stwo_records(stwo_prod.cfg, []).shape == (0,)
+    st, stats = ver.verify_stwo_texts(stwo_prod.cfg, [])
+    assert st.shape == (0,) and stats["text_bytes"] == 0
+    st, stats = ver.verify_stark101_files([])
+    assert st.shape == (0,)
