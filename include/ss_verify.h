@@ -46,7 +46,7 @@ extern "C" {
 
 /* return codes (all < 0 are errors; verdicts live in the status array) */
 #define SS_OK 0
-#define SS_ERR_ARG (-1)       /* null pointer, bad size, unsupported config */
+#define SS_ERR_ARG (-1)       /* null pointer, bad size, unsupported config, n == 0 (an empty batch is the caller's no-op) */
 #define SS_ERR_HIP (-2)       /* a HIP call failed; see ss_last_error() */
 #define SS_ERR_NO_DEVICE (-3) /* no usable gfx950 device */
 #define SS_ERR_WORKSPACE (-4) /* workspace too small */
