@@ -100,5 +100,12 @@ for name, src in (("r02_sha_lds_ab.txt", "sha_bench.txt"), ("r02_fuzz_parity.txt
         tail = ["", "schedule window in LDS = the first compression's 16-word rolling schedule in LDS (volatile column per lane)",
                 "instead of VGPRs.  North-star asked for the LDS staging by name; an LDS round trip per schedule word only adds",
                 "instructions to a loop whose cost is its instruction count."]
-    open(os.path.join(P, name), "w").write("\n".join([head] + body + tail) + "\n")
+    text = "\n".join([head] + body + tail) + "\n"
+    dst = os.path.join(P, name)
+    if name == "r02_fuzz_parity.txt" and os.path.exists(dst):
+        # the file also holds the long runs of tools/r02_gpu_fuzz.sh: keep them, replace only an earlier
+        # section made by this script at the same commit, append otherwise
+        sections = [sec for sec in open(dst).read().split("\n\n") if sec.strip() and not sec.startswith(head)]
+        text = "\n\n".join([sec.rstrip("\n") for sec in sections] + [text])
+    open(dst, "w").write(text)
 print("profiles written at", commit)
