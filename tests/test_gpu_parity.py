@@ -588,6 +588,33 @@ def test_pair_memoisation_equals_full_hashing(stwo_small, stwo_prod, name):
     assert (want[:3] == 0).all() and (want != 0).sum() > 50
 
 
+def test_pair_memoisation_with_guided_group_sizes(ver, stwo_prod):
+    """The top kernel hands its last groups out in quarters (16, 12, 8, 4 proofs at Q = 16).  A batch
+    big enough to run through all of those sizes (20 000 proofs of the reference shape: 1 250 groups
+    for at most 768 resident blocks), made of valid proofs and mutants in random order plus a ragged
+    tail, must get the oracle's status words, and the same ones as with every path hashed in full."""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_parity as fz
+    rng = np.random.default_rng(SEED + 33)
+    pool = [stwo_prod] + [fz.mutate_stwo(stwo_prod, rng) for _ in range(399)]
+    for n in (20000, 16387):
+        pick = rng.integers(0, len(pool), size=n)
+        batch = [pool[i] for i in pick]
+        want_pool = O.stwo_verify_batch(pool)
+        want = want_pool[pick]
+        got = ver.verify_stwo(batch, cfg=stwo_prod.cfg)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (n, int(bad[0]), hex(got[bad[0]]), hex(want[bad[0]]))
+    plain = verifier.Verifier(0)
+    plain.stwo_flags = verifier.FLAG_NO_DEDUP
+    assert plain.verify_stwo(batch, cfg=stwo_prod.cfg).tolist() == want.tolist()
+    plain.close()
+    assert (want == 0).sum() > 20 and (want != 0).sum() > n // 2
+
+
 # --------------------------------------------------------- text ingestion (native readers)
 def test_text_ingestion_gives_the_record_path_verdicts(ver, tmp_path, stwo_small, stwo_prod):
     """ss_stwo_verify_texts / _files: proof.json and proof.wit texts parsed by the library, verified
