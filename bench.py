@@ -4,10 +4,15 @@
     python bench.py --gpus N --steps K --warmup W
 
 One process per GPU (for N > 1 launched by torch.distributed.run; RANK / LOCAL_RANK /
-WORLD_SIZE / MASTER_* come from the environment).  A "step" verifies one batch of
-`--proofs-per-gpu` stwo circle-STARK proofs that is already resident in HBM, then all-reduces
-the accept count over RCCL (the only exchange of the path).  Weak scaling: every rank owns
-its own batch, total work grows with N.  Rank 0 prints ONE JSON line.
+WORLD_SIZE / MASTER_* come from the environment).  A "step" verifies one batch of stwo
+circle-STARK proofs that is already resident in HBM, then all-reduces the accept count over RCCL
+(the only exchange of the path).  Rank 0 prints ONE JSON line.
+
+`--scaling strong` (default): the step is ONE batch of `--batch` proofs (65 536 for the metric
+config, BASELINE.json configs[3]: "batch of 65536 proofs sharded across 8 x MI355X") split
+`distributed.shard_range`-wise over the N ranks -- 8 192 proofs per GPU at N = 8, the whole batch
+on the one GPU at N = 1.  `--scaling weak`: every rank owns its own `--proofs-per-gpu` batch
+(65 536 by default), total work grows with N.  The JSON line says which.
 
 Workloads (`--workload`):
   stwo_2p20      2^20-row wide-Fibonacci trace, blowup 2^4 (LDE 2^24), 16 queries, 19 inner FRI
@@ -19,7 +24,7 @@ Workloads (`--workload`):
                  16 queries) replicated -- used when the 2^20 fixture is absent.
   stwo_2p16      BASELINE.json configs[2]: 2^16 trace, 32 queries.
   stwo_wide256   BASELINE.json configs[4]: 256 columns, LDE 2^18.
-  stwo_2p16_blake2s, stwo_wide256_blake2s  configs[2] / configs[4] with Blake2s; proofs made at start-up.
+  stwo_2p16_blake2s, stwo_wide256_blake2s  configs[2] / configs[4] with Blake2s, as BASELINE.json names them.
   stwo_2p20_blake2s  the metric config with Blake2s-256 as the hash (BASELINE.json says "Blake2s
                  Merkle"; the reference has no Blake2s, so this variant's parity is unpinned).
   stark101       BASELINE.json configs[1]: the stark101 proof x 4096.
@@ -46,14 +51,11 @@ SHA_CALIBRATED_PEAK = 34.7e9
 B2S_CALIBRATED_PEAK = 38.9e9  # Blake2s-256 compressions/s, same tool (one compression per node)
 
 
-# BASELINE.json configs[2] / configs[4] with the hash they name (Blake2s): no committed fixture,
-# every proof of the batch is made by the GPU prover at start-up (parity unpinned).
-GEN_ONLY = {
-    "stwo_2p16_blake2s": dict(n_cols=4, trace_log=16, lde_log=20, n_queries=32, n_layers=15, pow_bits=5,
-                              hash="blake2s"),
-    "stwo_wide256_blake2s": dict(n_cols=256, trace_log=14, lde_log=18, n_queries=16, n_layers=13, pow_bits=5,
-                                 hash="blake2s"),
-}
+# Workloads without a committed fixture (none at present): every proof of the batch is then made by the
+# GPU prover at start-up.  BASELINE.json configs[2] / configs[4] with the hash they name (Blake2s) have
+# fixtures since round 3 (tests/golden/stwo_trace16_blake2s.npz, stwo_wide256_blake2s.npz; parity unpinned,
+# DESIGN.md section 2) and `-m gpu` parity tests behind them.
+GEN_ONLY: dict = {}
 
 
 def load_workload(name: str):
@@ -67,10 +69,11 @@ def load_workload(name: str):
         from stark_symphony_amd import records
         proofs = records.load_stwo_npz(big)
         return name, "stwo", proofs, "wide-Fibonacci 2^20 x 4, LDE 2^24, Q=16, K=19, SHA-256"
-    if name in ("stwo_2p16", "stwo_wide256", "stwo_2p20_blake2s"):
+    if name in ("stwo_2p16", "stwo_wide256", "stwo_2p20_blake2s", "stwo_2p16_blake2s", "stwo_wide256_blake2s"):
         from stark_symphony_amd import records
         fn = {"stwo_2p16": "stwo_trace16.npz", "stwo_wide256": "stwo_wide256.npz",
-              "stwo_2p20_blake2s": "stwo_trace20_blake2s.npz"}[name]
+              "stwo_2p20_blake2s": "stwo_trace20_blake2s.npz", "stwo_2p16_blake2s": "stwo_trace16_blake2s.npz",
+              "stwo_wide256_blake2s": "stwo_wide256_blake2s.npz"}[name]
         proofs = records.load_stwo_npz(os.path.join(GOLDEN, fn))
         c = proofs[0].cfg
         return name, "stwo", proofs, "wide-Fibonacci 2^%d x %d, LDE 2^%d, Q=%d, K=%d, %s" % (
@@ -221,11 +224,14 @@ def spawn_ranks(n: int) -> int:
             s.bind(("127.0.0.1", 0))
             env["MASTER_PORT"] = str(s.getsockname()[1])
     env["WORLD_SIZE"] = env["LOCAL_WORLD_SIZE"] = str(n)
+    import tempfile
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
-    kids = []
+    kids, errs = [], []
     for r in range(n):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        kids.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+        errs.append(tempfile.TemporaryFile())  # every rank's stderr is kept: a failing rank must be readable
+        kids.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                     stderr=errs[r]))
     import threading
     out = []
     reader = threading.Thread(target=lambda: out.append(kids[0].stdout.read()), daemon=True)
@@ -242,9 +248,19 @@ def spawn_ranks(n: int) -> int:
     for k in kids:
         k.wait()
     reader.join(timeout=10)
+
+    def tail(r: int, limit: int = 4000) -> str:
+        f = errs[r]
+        f.seek(0, os.SEEK_END)
+        size = f.tell()
+        f.seek(max(0, size - limit))
+        return f.read().decode("utf-8", "replace")
     if bad:
         print("bench.py: ranks failed (rank, exit status): %s" % bad, file=sys.stderr)
+        for r, code in bad:  # what the rank said before it died (the others were stopped by this launcher)
+            print("---- rank %d (exit %s), end of its stderr:\n%s" % (r, code, tail(r)), file=sys.stderr)
         return 1
+    sys.stderr.write(tail(0))  # warnings of rank 0 stay visible
     sys.stdout.write(b"".join(out).decode())
     sys.stdout.flush()
     return 0
@@ -256,7 +272,14 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--workload", default="auto")
-    ap.add_argument("--proofs-per-gpu", type=int, default=0)
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="strong: one --batch-proof batch split over the ranks (BASELINE.json configs[3]); "
+                         "weak: --proofs-per-gpu proofs on every rank")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="proofs of the whole job per step under --scaling strong (default 65536 for the 2^20 "
+                         "shape, 32768 for the smaller ones, 4096 for stark101)")
+    ap.add_argument("--proofs-per-gpu", type=int, default=0,
+                    help="proofs per rank and step; giving it selects --scaling weak")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--distinct", type=int, default=16,
@@ -274,6 +297,8 @@ def main() -> None:
                     help="SS_FLAG_NO_DEDUP: hash every query's Merkle path in full (A/B of the pair memoisation)")
     args = ap.parse_args()
 
+    if args.proofs_per_gpu:
+        args.scaling = "weak"
     if args.workload == "stark101" and args.graph in ("auto", "streams"):
         # The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and
         # streams that share a queue serialize: 16 overlapping passes need their own queues.  Must be
@@ -333,24 +358,44 @@ def main() -> None:
 
     if not proofs:
         raise SystemExit("workload %s has no committed proof: needs --distinct >= 1" % wname)
+    from stark_symphony_amd import distributed
+
+    def local_share(default_total: int) -> int:
+        """Proofs this rank verifies per step.  strong: its shard_range slice of the one batch."""
+        if args.scaling == "weak":
+            return args.proofs_per_gpu or default_total
+        lo, hi = distributed.shard_range(args.batch or default_total, rank, world)
+        if hi <= lo:
+            raise SystemExit("--batch %d leaves rank %d of %d without a proof" % (args.batch, rank, world))
+        return hi - lo
+
     if family == "stwo":
         cfg = proofs[0].cfg
         # BASELINE.json configs[3] is "batch of 65536 proofs": 11.2 GB of records, which fits one
-        # GPU, so that batch is the step at N=1 and (weak scaling) on every rank at N>1.
-        per_gpu = args.proofs_per_gpu or (65536 if cfg.lde_log >= 24 else 32768)
+        # GPU, so that batch is the step at N=1; at N>1 it is split over the ranks (strong) or every
+        # rank gets one of its own (weak).
+        per_gpu = local_share(65536 if cfg.lde_log >= 24 else 32768)
         reps = (per_gpu + len(proofs) - 1) // len(proofs)
-        batch = ver.stwo_batch(proofs, verifier.MODE_FIXTURE, replicate=reps)
+        index = [i % len(proofs) for i in range(per_gpu)]
+        batch = verifier.StwoDeviceBatch(ver, cfg, verifier.MODE_FIXTURE, [verifier.stwo_record(p) for p in proofs],
+                                         index=index)
         bytes_per_proof, compr_per_proof = cfg.packed_bytes, cfg.compressions
         dominant = "stwo_merkle"  # + "stwo_top": the Merkle stage is these two kernels
         hash_name = cfg.hash
         alu_peak = B2S_CALIBRATED_PEAK if cfg.hash == "blake2s" else SHA_CALIBRATED_PEAK
     else:
-        per_gpu = args.proofs_per_gpu or 4096
+        per_gpu = local_share(4096)
         batch = ver.stark101_batch(proofs, replicate=per_gpu)
         bytes_per_proof, compr_per_proof = 7176, 480  # BASELINE.md section 3
         dominant = "s101_merkle"
         hash_name, alu_peak = "sha256", SHA_CALIBRATED_PEAK
     n_local = batch.n
+    if args.scaling == "strong":  # the whole job's proofs per step: the one batch
+        job_proofs = sum(b - a for a, b in (distributed.shard_range(
+            args.batch or (4096 if family != "stwo" else 65536 if cfg.lde_log >= 24 else 32768), r, world)
+            for r in range(world)))
+    else:
+        job_proofs = n_local * world
 
     # `--inflight` run slots over the same resident batch, pipelined on a head and a tail stream:
     # the latency-bound transcript kernel of step i+1 overlaps the ALU-bound Merkle kernel of
@@ -449,10 +494,10 @@ def main() -> None:
         total_accept = int(acc.item())
     else:
         total_accept = batch.accepted()
-    assert total_accept == n_local * world, "accept-reduce mismatch"
+    assert total_accept == job_proofs, "accept-reduce mismatch (%d of %d)" % (total_accept, job_proofs)
 
     if rank == 0:
-        total = n_local * world * args.steps
+        total = job_proofs * args.steps
         value = total / elapsed
         k_ms, k_n = timing.get(dominant, (0.0, 0))
         k_avg_s = (k_ms / max(k_n, 1)) * 1e-3
@@ -486,9 +531,13 @@ def main() -> None:
                       if family == "stwo" else "proofs verified/sec (batch), stark101",
             "value": value, "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": wname, "note": note, "proofs_per_gpu": n_local,
+                       "proofs_per_step": job_proofs,
+                       "batch": ("one batch of %d proofs split over %d GPU(s) (distributed.shard_range), %d on rank 0"
+                                 % (job_proofs, world, n_local)) if args.scaling == "strong" else
+                                ("%d proofs on each of %d GPU(s)" % (n_local, world)),
                        "distinct_proofs": len(proofs), "bytes_per_proof": bytes_per_proof,
                        "hash_compressions_per_proof": compr_per_proof,
                        "hash_compressions_executed_per_proof": executed,

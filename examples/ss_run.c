@@ -8,8 +8,12 @@
  * 205-206,254-257).  This program takes the same arguments, hands the .wit file to the library's native
  * reader (ss_*_verify_files) and returns the same exit status -- a one-line change in a Makefile.  The
  * program file is not executed (the verifier it contains is the library's kernels); it only selects
- * the witness family when --family is not given (a path containing "stark101" or a witness with a
- * P_MT_ROOT member = stark101).  For stwo the config is the one the program was compiled for:
+ * the witness family when --family is not given: from its path ("stark101" / "stwo"), else from its
+ * text (`witness::P_MT_ROOT` is read by stark101/src/main.simf:13, `witness::COMMITMENTS` by
+ * stwo-verifier/src/main.simf:10).  The family is NEVER taken from a witness -- that is the untrusted
+ * input -- and a witness of the other family is malformed (exit 1), as it fails typing in the reference.
+ * If the family cannot be determined the exit status is 2.  For stwo the config is the one the program
+ * was compiled for:
  * production by default, --config testing for `mcpp -DTESTING` builds (config.simf:10-51), or explicit
  * --n-cols / --trace-log / --lde-log / --n-queries / --n-layers / --pow-bits overrides.
  *
@@ -26,17 +30,38 @@
 
 #include "ss_verify.h"
 
-#define MAX_WIT 4096
-
+/* Does the (trusted) program text contain `needle`?  Reads the whole file in 64 KiB pieces. */
 static int file_mentions(const char *path, const char *needle)
 {
     FILE *f = fopen(path, "rb");
     if (!f) return 0;
-    char buf[4096];
-    const size_t n = fread(buf, 1, sizeof buf - 1, f);
+    static char buf[(1 << 16) + 64];
+    const size_t nl = strlen(needle);
+    size_t keep = 0, n;
+    int found = 0;
+    while (!found && (n = fread(buf + keep, 1, (1 << 16), f)) > 0) {
+        const size_t have = keep + n;
+        buf[have] = 0;
+        for (size_t i = 0; i < have; i++)  /* NUL bytes would end strstr early */
+            if (!buf[i]) buf[i] = ' ';
+        found = strstr(buf, needle) != NULL;
+        keep = have < nl - 1 ? have : nl - 1;  /* a needle may straddle two reads */
+        memmove(buf, buf + have - keep, keep);
+    }
     fclose(f);
-    buf[n] = 0;
-    return strstr(buf, needle) != NULL;
+    return found;
+}
+
+/* 1 = stark101, 0 = stwo, -1 = cannot tell.  Only trusted input decides: --family, the program's
+ * path, the program's text.  (The witness is the untrusted input and never selects the statement.) */
+static int family_of(const char *family, const char *program)
+{
+    if (family) return !strcmp(family, "stark101") ? 1 : !strcmp(family, "stwo") ? 0 : -1;
+    const int p101 = strstr(program, "stark101") != NULL, pstwo = strstr(program, "stwo") != NULL;
+    if (p101 != pstwo) return p101;
+    const int t101 = file_mentions(program, "witness::P_MT_ROOT"), tstwo = file_mentions(program, "witness::COMMITMENTS");
+    if (t101 != tstwo) return t101;
+    return -1;
 }
 
 int main(int argc, char **argv)
@@ -46,7 +71,8 @@ int main(int argc, char **argv)
         return 2;
     }
     const char *program = argv[2], *family = NULL, *profile = "production", *mode = "fixture";
-    const char *wits[MAX_WIT];
+    const char **wits = (const char **)malloc((size_t)argc * sizeof *wits);  /* every --witness is verified */
+    if (!wits) { fprintf(stderr, "Error: out of memory\n"); return 2; }
     size_t n = 0;
     int device = 0;
     long over[6] = {-1, -1, -1, -1, -1, -1};  /* n_cols trace_log lde_log n_queries n_layers pow_bits */
@@ -55,7 +81,7 @@ int main(int argc, char **argv)
         const char *a = argv[i];
         const char *v = i + 1 < argc ? argv[i + 1] : NULL;
         int taken = 0;
-        if (!strcmp(a, "--witness") && v) { if (n < MAX_WIT) wits[n++] = v; taken = 1; }
+        if (!strcmp(a, "--witness") && v) { wits[n++] = v; taken = 1; }
         else if (!strcmp(a, "--family") && v) { family = v; taken = 1; }
         else if (!strcmp(a, "--config") && v) { profile = v; taken = 1; }
         else if (!strcmp(a, "--mode") && v) { mode = v; taken = 1; }
@@ -64,12 +90,16 @@ int main(int argc, char **argv)
             for (int k = 0; k < 6; k++)
                 if (!strcmp(a, over_names[k]) && v) { over[k] = atol(v); taken = 1; }
         }
-        if (!taken) { fprintf(stderr, "Error: unknown or incomplete argument %s\n", a); return 2; }
+        if (!taken) { fprintf(stderr, "Error: unknown or incomplete argument %s\n", a); free(wits); return 2; }
         i++;
     }
-    if (!n) { fprintf(stderr, "Error: no --witness given\n"); return 1; }
-    const int s101 = family ? !strcmp(family, "stark101")
-                            : (strstr(program, "stark101") != NULL || file_mentions(wits[0], "\"P_MT_ROOT\""));
+    if (!n) { fprintf(stderr, "Error: no --witness given\n"); free(wits); return 1; }
+    const int s101 = family_of(family, program);
+    if (s101 < 0) {
+        fprintf(stderr, "Error: cannot tell which verifier %s is (stark101 or stwo): pass --family\n", program);
+        free(wits);
+        return 2;
+    }
 
     ss_stwo_cfg cfg;
     memset(&cfg, 0, sizeof cfg);
@@ -89,12 +119,16 @@ int main(int argc, char **argv)
     if (ss_abi_sizeof_cfg() != sizeof cfg) { fprintf(stderr, "Error: libss_verify ABI mismatch\n"); return 2; }
     ss_ctx *ctx = NULL;
     uint32_t *status = (uint32_t *)malloc(n * sizeof *status);
+    if (!status) { fprintf(stderr, "Error: out of memory\n"); free(wits); return 2; }
     int rc = ss_ctx_create(device, &ctx);
     if (rc == SS_OK)
         rc = s101 ? ss_s101_verify_files(ctx, n, wits, SS_TEXT_WIT, status, NULL)
                   : ss_stwo_verify_files(ctx, &cfg, n, wits, SS_TEXT_WIT, status, NULL);
     if (rc != SS_OK) {  /* no GPU, unsupported config: an error, never a verdict */
         fprintf(stderr, "Error: libss_verify: %s (code %d)\n", ss_last_error(), rc);
+        ss_ctx_destroy(ctx);
+        free(status);
+        free(wits);
         return 2;
     }
     size_t bad = 0;
@@ -110,5 +144,6 @@ int main(int argc, char **argv)
     }
     ss_ctx_destroy(ctx);
     free(status);
+    free(wits);
     return bad ? 1 : 0;
 }

@@ -525,6 +525,9 @@ def stwo_from_json(data: Any, trace_log: int | None = None, hash: str | None = N
             tl = trace_log
         else:
             tl = lde_log - declared(fri_conf, "log_blowup_factor", expect and expect.log_blowup)
+        if "hash" in conf:  # declared: must be one of the two names (a present null / 0 / "" is not "absent")
+            if not isinstance(conf["hash"], str) or conf["hash"] not in ("sha256", "blake2s"):
+                raise MalformedProof("unknown hash %r" % (conf["hash"],))
         hname = hash or conf.get("hash") or (expect.hash if expect else "sha256")  # the reference: SHA-256 only
         if hname not in ("sha256", "blake2s"):
             raise MalformedProof("unknown hash %r" % (hname,))

@@ -23,6 +23,7 @@ CASES = {
     "trace16": (dict(n_cols=4, trace_log=16, log_blowup=4, n_queries=32, pow_bits=5), (0, 1)),
     "trace16_blake2s": (dict(n_cols=4, trace_log=16, log_blowup=4, n_queries=32, pow_bits=5, hash="blake2s"), (0, 1)),
     "wide256": (dict(n_cols=256, trace_log=14, log_blowup=4, n_queries=16, pow_bits=5), (0,)),
+    "wide256_blake2s": (dict(n_cols=256, trace_log=14, log_blowup=4, n_queries=16, pow_bits=5, hash="blake2s"), (0,)),
     "trace20": (dict(n_cols=4, trace_log=20, log_blowup=4, n_queries=16, pow_bits=5), (0,)),
     "trace20_blake2s": (dict(n_cols=4, trace_log=20, log_blowup=4, n_queries=16, pow_bits=5, hash="blake2s"), (0,)),
 }

@@ -1,6 +1,6 @@
 """bench.py end to end on the GPU box: the JSON contract at N=1 and the multi-rank control flow
-(two ranks sharing the one GPU over gloo -- RCCL refuses two ranks on one device, so the nccl backend
-itself is the only part of `--gpus N` this cannot cover)."""
+(two ranks sharing the one GPU over gloo -- RCCL refuses two ranks on one device; the nccl backend
+itself is covered by test_rccl_two_ranks_*, which enables itself on any box with two GPUs)."""
 import json
 import os
 import socket
@@ -68,12 +68,89 @@ def test_bench_spawns_its_own_ranks(n):
     assert abs(d["value"] - n * 256 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
 
 
+@pytest.mark.parametrize("n,batch", [(2, 1024), (3, 1000)])
+def test_bench_strong_scaling_splits_one_batch(n, batch):
+    """--scaling strong (the default): ONE batch of --batch proofs split shard_range-wise over the ranks
+    (BASELINE.json configs[3]: 65 536 proofs over 8 GPUs); value counts the batch once per step.  An
+    uneven split (1000 over 3) leaves ranks with 334 / 333 / 333 proofs."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SS_BENCH_SHARE_GPU="1", SS_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--workload",
+                        "stwo_fixture", "--batch", str(batch), "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=1200, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == n and d["scaling"] == "strong" and d["config"]["proofs_per_step"] == batch
+    assert d["config"]["proofs_per_gpu"] == (batch + n - 1) // n
+    assert abs(d["value"] - batch / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
 def test_bench_launcher_reports_a_failing_rank():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(SS_BENCH_SHARE_GPU="1", SS_BENCH_BACKEND="gloo")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "no_such"],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "end of its stderr" in r.stderr and "unknown workload" in r.stderr  # the failed rank's own words
+
+
+def _gpu_count() -> int:
+    import torch
+    return torch.cuda.device_count()  # does not initialise the GPU on this image
+
+
+_RCCL_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+rank, local = int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"])
+torch.cuda.set_device(local)
+dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+import stark_symphony_amd as ss
+from stark_symphony_amd import distributed, formats, records, verifier
+from oracle import oracle as O
+import json
+g = os.path.join({root!r}, "tests", "golden")
+base = ss.stwo_from_json(json.load(open(os.path.join(g, "stwo_proof.json"))))
+rng = np.random.default_rng(0x5EED2025 + 77)
+proofs = [base if i % 3 else formats.stwo_corrupt(base, rng)[0] for i in range(37)]   # uneven split
+ver = verifier.Verifier(local)
+local_st, acc, tot, all_st = distributed.verify_sharded(
+    proofs, lambda sl: ver.verify_stwo(sl, cfg=base.cfg), gather_status=True)
+want = O.stwo_verify_batch(proofs)
+assert tot == 37 and acc == int((want == 0).sum()), (acc, tot)
+assert all_st.tolist() == want.tolist()
+lo, hi = distributed.shard_range(37, rank, dist.get_world_size())
+assert local_st.tolist() == want[lo:hi].tolist()
+dist.barrier()
+dist.destroy_process_group()
+print("rank %d ok: %d of %d accepted" % (rank, acc, tot))
+"""
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs: the first RCCL evidence comes from a multi-GPU box")
+def test_rccl_two_ranks_verify_sharded_and_bench(tmp_path):
+    """Two ranks on two devices over the nccl backend (RCCL over xGMI): distributed.verify_sharded with
+    the status all-gather on a mixed batch against the oracle, then bench.py --gpus 2 in both scaling
+    modes.  Skipped on the single-GPU test box."""
+    worker = tmp_path / "rccl_worker.py"
+    worker.write_text(_RCCL_WORKER.format(root=ROOT))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(worker)],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and r.stdout.count("ok:") == 2, (r.stdout[-2000:], r.stderr[-3000:])
+    for extra in (["--proofs-per-gpu", "2048"], ["--batch", "4096"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "stwo_fixture",
+                            "--steps", "5", "--warmup", "2"] + extra, capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        d = _last_json(r.stdout)
+        assert d["n_gpus"] == 2 and d["config"]["proofs_per_gpu"] == 2048 and d["config"]["proofs_per_step"] == 4096
+        assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
 
 
 def test_bench_refuses_a_world_size_that_disagrees_with_gpus():

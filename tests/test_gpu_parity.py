@@ -236,7 +236,7 @@ def _load_npz(name):
 
 
 @pytest.mark.parametrize("name", ["stwo_trace16.npz", "stwo_trace16_blake2s.npz", "stwo_wide256.npz",
-                                  "stwo_trace20.npz", "stwo_trace20_blake2s.npz"])
+                                  "stwo_wide256_blake2s.npz", "stwo_trace20.npz", "stwo_trace20_blake2s.npz"])
 def test_stwo_baseline_configs(ver, name):
     """configs[2] (2^16 trace, 32 queries; SHA-256 = the pinned hash, and Blake2s = the config as
     BASELINE.json names it), configs[4] (256 columns, LDE 2^18) and configs[3] (2^20 trace, both
@@ -326,6 +326,36 @@ def test_stwo_full_size_batch_2p20(ver):
     got = b.status()
     assert got.tolist() == [int(want_d[i]) for i in idx]
     assert b.accepted() == sum(1 for i in idx if want_d[i] == 0) >= n // 2
+
+
+def test_stwo_full_size_batch_65536(ver):
+    """BASELINE.json configs[3] at its full size on one GPU: ONE batch of 65 536 proofs of the 2^20-trace
+    shape (11.2 GB resident) = 64 distinct records (32 valid, 32 seeded corruptions) x 1 024, built through
+    the device replication map as bench.py builds its batch.  The status vector must equal the oracle's
+    64 verdicts gathered through the map and the accept count must be 32 768 -- with the pair
+    memoisation on and with every path hashed in full (SS_FLAG_NO_DEDUP)."""
+    import torch
+    base = _load_npz("stwo_trace20.npz")[0]
+    rng = np.random.default_rng(SEED + 18)
+    distinct = [base] * 32 + [formats.stwo_corrupt(base, rng)[0] for _ in range(32)]
+    order = rng.permutation(64)
+    distinct = [distinct[i] for i in order]
+    want_d = O.stwo_verify_batch(distinct)
+    assert int((want_d == 0).sum()) == 32
+    want = np.tile(want_d, 1024)
+    for flags in (0, verifier.FLAG_NO_DEDUP):
+        v = verifier.Verifier(0)
+        v.stwo_flags = flags
+        b = v.stwo_batch(distinct, replicate=1024)
+        assert b.n == 65536
+        b.run()
+        got = b.status()
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (flags, int(bad[0]), hex(got[bad[0]]), hex(want[bad[0]]))
+        assert b.accepted() == 32768
+        del b
+        v.close()
+        torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("concurrent", [False, True])
@@ -565,7 +595,8 @@ def test_pair_memoisation_when_queries_disagree_about_a_node(ver, stwo_prod):
     assert want[0] != 0 or mode == verifier.MODE_FIXTURE
 
 
-@pytest.mark.parametrize("name", ["prod", "small", "stwo_trace16.npz", "stwo_trace16_blake2s.npz", "stwo_wide256.npz"])
+@pytest.mark.parametrize("name", ["prod", "small", "stwo_trace16.npz", "stwo_trace16_blake2s.npz", "stwo_wide256.npz",
+                                  "stwo_wide256_blake2s.npz"])
 def test_pair_memoisation_equals_full_hashing(stwo_small, stwo_prod, name):
     """SS_FLAG_NO_DEDUP (every path hashed in full, as the reference does) and the default give the
     same status words, and both equal the oracle's, on valid proofs and seeded mutants."""
@@ -689,24 +720,38 @@ def test_simfony_run_shim_in_c(tmp_path):
         r = subprocess.run([exe, "run", *args], capture_output=True, text=True, timeout=300)
         r.stderr = "".join(l for l in r.stderr.splitlines(True) if "amdgpu.ids" not in l)
         return r
-    r = run("../target/main.out.simf", "--witness", os.path.join(F, "stark101_proof.wit"))   # family from the witness
+    # the family comes from trusted input only: --family, the program's path, or the program's text
+    p101 = tmp_path / "main.out.simf"   # what `mcpp -P src/main.simf` leaves in target/ (stark101/Makefile:4-5)
+    p101.write_text("fn main() {\n    let root: u256 = witness::P_MT_ROOT;\n}\n")
+    pstwo = tmp_path / "other" / "main.simf"
+    pstwo.parent.mkdir()
+    pstwo.write_text("fn main() {\n    let c: Commitments = witness::COMMITMENTS;\n}\n")
+    r = run(str(p101), "--witness", os.path.join(F, "stark101_proof.wit"))                    # family from the program text
     assert r.returncode == 0 and "ACCEPT" in r.stdout and r.stderr == ""
-    r = run("stwo-verifier/main.simf", "--witness", os.path.join(F, "stwo_proof.wit"))
+    r = run("stwo-verifier/main.simf", "--witness", os.path.join(F, "stwo_proof.wit"))         # from the path
     assert r.returncode == 0 and "ACCEPT" in r.stdout
-    r = run("main.simf", "--config", "testing", "--witness", os.path.join(F, "stwo_proof_test.wit"))
+    # a witness never selects the statement: a valid stark101 witness handed to the stwo program is a typing
+    # failure (exit 1), and a program of unknown family is an error (exit 2), not a verdict
+    r = run("stwo-verifier/main.simf", "--witness", os.path.join(F, "stark101_proof.wit"))
+    assert r.returncode == 1 and "malformed witness" in r.stderr and "ACCEPT" not in r.stdout
+    r = run("stark101/main.simf", "--witness", os.path.join(F, "stwo_proof.wit"))
+    assert r.returncode == 1 and "ACCEPT" not in r.stdout
+    r = run("main.simf", "--witness", os.path.join(F, "stark101_proof.wit"))
+    assert r.returncode == 2 and "--family" in r.stderr and "ACCEPT" not in r.stdout
+    r = run(str(pstwo), "--config", "testing", "--witness", os.path.join(F, "stwo_proof_test.wit"))
     assert r.returncode == 0
-    r = run("main.simf", "--witness", os.path.join(F, "stwo_proof_test.wit"))                  # production program, test witness
+    r = run(str(pstwo), "--witness", os.path.join(F, "stwo_proof_test.wit"))                  # production program, test witness
     assert r.returncode == 1 and r.stderr.startswith("Error: Failed to run program")
-    r = run("main.simf", "--mode", "literal", "--witness", os.path.join(F, "stwo_proof.wit"))
+    r = run("main.simf", "--family", "stwo", "--mode", "literal", "--witness", os.path.join(F, "stwo_proof.wit"))
     assert r.returncode == 1 and "0x07000001" in r.stderr
     wit = json.load(open(os.path.join(F, "stwo_proof.wit")))
     v = wit["POW_NONCE"]["value"]
     wit["POW_NONCE"]["value"] = str(int(v) + 1)
     bad = tmp_path / "bad.wit"
     bad.write_text(json.dumps(wit))
-    r = run("main.simf", "--witness", os.path.join(F, "stwo_proof.wit"), "--witness", str(bad))
+    r = run(str(pstwo), "--witness", os.path.join(F, "stwo_proof.wit"), "--witness", str(bad))
     assert r.returncode == 1 and r.stdout.count("ACCEPT") == 1 and "assertion failed" in r.stderr
-    assert run("main.simf", "--witness", str(tmp_path / "absent.wit")).returncode == 1
+    assert run(str(pstwo), "--witness", str(tmp_path / "absent.wit")).returncode == 1
 
 
 def test_independent_streams_match_single_stream(ver, s101_proof, stwo_prod):

@@ -330,6 +330,15 @@ def test_simfony_run_shim_in_c_builds_and_refuses_to_invent_a_verdict(tmp_path):
     assert subprocess.run([exe, "build", "x"], capture_output=True).returncode == 2
     assert subprocess.run([exe, "run", "x.simf", "--bogus", "1"], capture_output=True).returncode == 2
     assert subprocess.run([exe, "run", "x.simf"], capture_output=True).returncode == 1  # no witness
+    # the witness never selects the verifier: a program of unknown family is an error before any verdict
+    r = subprocess.run([exe, "run", "x.simf", "--witness", wit], capture_output=True, text=True)
+    assert r.returncode == 2 and "--family" in r.stderr and "ACCEPT" not in r.stdout
+    many = [a for _ in range(5000) for a in ("--witness", wit)]  # more witnesses than any fixed table: none dropped
+    r = subprocess.run([exe, "run", "stark101/main.simf"] + many, capture_output=True, text=True)
+    if torch.cuda.is_available():
+        assert r.returncode == 0 and r.stdout.count("ACCEPT") == 5000
+    else:
+        assert r.returncode == 2
 
 
 def test_c_abi_consumer_builds_and_fails_loudly_without_a_gpu(tmp_path, s101_proof):

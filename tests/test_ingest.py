@@ -136,6 +136,9 @@ def _json_mutants(obj):
     out.append(("declares 1 query", edit(lambda o: o["config"]["fri_config"].__setitem__("n_queries", 1))))
     out.append(("declares blake2s", edit(lambda o: o["config"].__setitem__("hash", "blake2s"))))
     out.append(("declares md5", edit(lambda o: o["config"].__setitem__("hash", "md5"))))
+    for falsy in (None, 0, "", False, []):  # a present non-name is not "absent" (ADVICE r2): malformed in both readers
+        out.append(("declares hash %r" % (falsy,), edit(lambda o, v=falsy: o["config"].__setitem__("hash", v))))
+    out.append(("declares sha256", edit(lambda o: o["config"].__setitem__("hash", "sha256"))))
     out.append(("declares blow-up 3", edit(lambda o: o["config"]["fri_config"].__setitem__("log_blowup_factor", 3))))
     out.append(("one inner layer less", edit(lambda o: o["fri_proof"]["inner_layers"].pop())))
     out.append(("nonce 2^64", edit(lambda o: o.__setitem__("proof_of_work", 2 ** 64))))
@@ -240,6 +243,44 @@ def test_oversized_and_deeply_nested_texts_are_malformed_not_fatal():
     big = b"{\"x\": [" + b"1," * (17 << 20) + b"1]}"                                  # > 32 MiB of text
     assert len(big) > (32 << 20) and verifier.parse_stwo_text(cfg, big)[0] == MALFORMED
     assert verifier.parse_s101_text(big)[0] == MALFORMED
+
+
+def test_attacker_sized_lists_parse_in_linear_time():
+    """N and Q come from the untrusted text; the schema walkers iterate with cursors, so a
+    ~1.5 MB text with one huge list costs milliseconds, not minutes (child(i, k) inside a loop was
+    quadratic: 49 s at N = 80 000)."""
+    import time
+    obj = json.load(open(os.path.join(GOLDEN, "stwo_proof_test.json")))
+    big_n = 120000
+    obj["sampled_values"][1] = [[[[1, 2], [3, 4]]]] * big_n             # N = 120 000 columns
+    obj["queried_values"][1] = [7] * big_n
+    text = json.dumps(obj).encode()
+    assert len(text) > 1_000_000
+    t0 = time.perf_counter()
+    got = verifier.parse_stwo_text(ss.TESTING_CONFIG, text)[0]
+    assert got == MISMATCH and time.perf_counter() - t0 < 1.0
+    # .wit: Q = 60 000 decommitment entries, each of the wrong shape deep inside; N = 60 000 OODS columns
+    wit = json.loads(open(os.path.join(FORMATS, "stwo_proof_test.wit")).read())
+    one = wit["DECOMMITMENTS"]["value"][1:-1]
+    wit["DECOMMITMENTS"]["value"] = "[" + ", ".join([one] * 3000) + "]"
+    col = "[((1, 0), (0, 0))]"
+    oods = wit["OODS_EVALS"]["value"]
+    wit["OODS_EVALS"]["value"] = "([" + ", ".join([col] * 60000) + "], " + oods[oods.index("], [((") + 3:]
+    text = json.dumps(wit).encode()
+    assert len(text) > 1_000_000
+    t0 = time.perf_counter()
+    got = verifier.parse_stwo_text(ss.TESTING_CONFIG, text, fmt=2)[0]
+    assert got in (MISMATCH, MALFORMED) and time.perf_counter() - t0 < 1.0
+    assert got == _python_outcome(text, ss.TESTING_CONFIG, "wit")[0]
+    # FRI layer lists as long as the text allows
+    wit = json.loads(open(os.path.join(FORMATS, "stwo_proof_test.wit")).read())
+    fd = wit["FRI_DECOMMITMENTS"]["value"]
+    first = fd[2:fd.index(")], [[") + 1]
+    wit["FRI_DECOMMITMENTS"]["value"] = "([" + ", ".join([first] * 8000) + "]" + fd[fd.index(")], [[") + 2:]
+    text = json.dumps(wit).encode()
+    t0 = time.perf_counter()
+    got = verifier.parse_stwo_text(ss.TESTING_CONFIG, text, fmt=2)[0]
+    assert got == _python_outcome(text, ss.TESTING_CONFIG, "wit")[0] and time.perf_counter() - t0 < 1.0
 
 
 def test_native_readers_under_address_and_ub_sanitizers(tmp_path):
