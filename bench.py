@@ -183,17 +183,26 @@ def end_to_end(ver, proofs, n: int):
     from stark_symphony_amd import binding, verifier
     cfg = proofs[0].cfg
     distinct = proofs[:8]
-    texts = {"json": [json.dumps(ss.stwo_to_json(p)).encode() for p in distinct],
+    # proof.json as the external prover prints it (compact separators, tests/data/proof.json) and proof.wit as
+    # generate_wit.py prints it
+    texts = {"json": [json.dumps(ss.stwo_to_json(p), separators=(",", ":")).encode() for p in distinct],
              "wit": [ss.stwo_to_wit(p).encode() for p in distinct]}
-    out = {"proofs": n, "note": "proof text -> verdict through ss_stwo_verify_texts (csrc/ss_ingest.cpp), host "
-                                "parse + PCIe included; parse-bound, not what `value` measures"}
+    out = {"proofs": n, "note": "proof text -> verdict through ss_stwo_verify_texts: raw bytes staged into pinned memory, "
+                                "uploaded, turned into records by the GPU reader (csrc/ss_textdev.hip), re-tiled, verified; "
+                                "bound by the host link, not what `value` measures"}
     for kind, fmt in (("json", binding.TEXT_JSON), ("wit", binding.TEXT_WIT)):
         batch = [texts[kind][i % len(distinct)] for i in range(n)]
-        ver.verify_stwo_texts(cfg, batch[:32], fmt=fmt)  # warm-up: scratch allocation
-        t0 = time.perf_counter()
-        status, st = ver.verify_stwo_texts(cfg, batch, fmt=fmt)
-        dt = time.perf_counter() - t0
-        assert (status == 0).all(), "e2e: a benchmark proof was not accepted"
+        ver.verify_stwo_texts(cfg, batch[:64], fmt=fmt)  # warm-up: scratch allocation, templates
+        ver.verify_stwo_texts(cfg, batch, fmt=fmt)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            status, st = ver.verify_stwo_texts(cfg, batch, fmt=fmt)
+            dt = time.perf_counter() - t0
+            assert (status == 0).all(), "e2e: a benchmark proof was not accepted"
+            if best is None or dt < best[0]:
+                best = (dt, st)
+        dt, st = best
         t1 = time.perf_counter()
         k = 0
         while k < 3 or time.perf_counter() - t1 < 0.5:
@@ -203,10 +212,10 @@ def end_to_end(ver, proofs, n: int):
             verifier.stwo_record(p)
             k += 1
         py = k / (time.perf_counter() - t1)
-        out[kind] = {"proofs_per_s": n / dt, "total_s": dt, "parse_s": st["parse_s"],
-                     "parse_share": st["parse_s"] / st["total_s"], "host_threads": st["threads"],
-                     "text_bytes_per_proof": st["text_bytes"] // n,
-                     "parse_MB_per_s_per_thread": st["text_bytes"] / st["parse_s"] / st["threads"] / 1e6,
+        out[kind] = {"proofs_per_s": n / dt, "total_s": dt, "text_GB_per_s": st["text_bytes"] / dt / 1e9,
+                     "stage_s": st["read_s"], "host_reader_s": st["parse_s"],
+                     "parse_share": st["parse_s"] / st["total_s"], "host_parsed_texts": st["host_parsed"],
+                     "host_threads": st["threads"], "text_bytes_per_proof": st["text_bytes"] // n,
                      "python_reader_proofs_per_s_one_thread": py}
     return out
 

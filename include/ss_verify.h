@@ -42,7 +42,8 @@
 extern "C" {
 #endif
 
-#define SS_VERSION 0x00020000 /* 2.0: stwo records carry their Merkle path lengths; shape_status is gone */
+#define SS_VERSION 0x00020001 /* 2.0: stwo records carry their Merkle path lengths; shape_status is gone.
+                                 2.1: GPU text reader behind the text entry points, ss_stwo_write_text, thread rules */
 
 /* return codes (all < 0 are errors; verdicts live in the status array) */
 #define SS_OK 0
@@ -145,7 +146,14 @@ int ss_stwo_pack(const ss_stwo_cfg *cfg, size_t n, const uint32_t *const *record
                  uint32_t *batch_host);
 
 /* ======================================================================= execution
- * One context per process and GPU (one process per GPU is the intended deployment).   */
+ * One context per process and GPU (one process per GPU is the intended deployment).
+ * Threads.  A context may be shared by threads.  Entry points that use the context's own scratch
+ * -- ss_*_verify_records, ss_*_verify_texts / _files, ss_selftest -- serialize on a lock inside the
+ * context: concurrent calls are safe and run one after the other.  The device entry points
+ * (ss_*_verify_batch_dev / _phase_dev, ss_stwo_pack_dev) take caller-owned buffers and a caller-owned
+ * stream and run concurrently from any number of threads (the timing list has its own lock); what they
+ * require is the usual HIP rule that the buffers of two in-flight calls are distinct.  Functions
+ * without a context (sizes, packers, parsers, writers) are pure.                          */
 typedef struct ss_ctx ss_ctx;
 int ss_ctx_create(int device, ss_ctx **out);
 void ss_ctx_destroy(ss_ctx *ctx);
@@ -222,17 +230,23 @@ int ss_stwo_parse(const ss_stwo_cfg *cfg, const char *text, size_t len, int fmt,
 int ss_s101_parse(const char *text, size_t len, int fmt, ss_s101_shape *shape_inout, uint32_t *record_out);
 
 typedef struct ss_ingest_stats {
-    double read_s;    /* wall time reading files (0 for the *_texts entry points)      */
-    double parse_s;   /* wall time in the parallel text -> record phases              */
-    double total_s;   /* the whole call: read + parse + upload + verify + download    */
+    double read_s;    /* wall time staging the raw bytes (copy / file read into pinned memory)  */
+    double parse_s;   /* wall time in the host reader (texts the GPU reader did not take)       */
+    double total_s;   /* the whole call: stage + upload + GPU read + verify + download          */
     uint64_t text_bytes, record_bytes;
     uint32_t threads; /* host threads used (scheduler affinity capped by the cgroup quota) */
-    uint32_t reserved;
+    uint32_t host_parsed; /* texts that went through the host reader (0 for canonical texts) */
 } ss_ingest_stats;
 
-/* Texts / files -> verdicts, synchronous: chunks are parsed by host threads into pinned staging
- * while the previous chunk uploads, then re-tiled and verified on the GPU.  status_host[i] is the
- * verdict of input i (stage-0 codes above included).  stats may be NULL.                         */
+/* Texts / files -> verdicts, synchronous.  stwo: the raw bytes are uploaded in pinned chunks and turned
+ * into records ON THE GPU (csrc/ss_textdev.hip): a text that is, byte for byte, what the reference's
+ * producers write for the expected config -- proof.json as the external prover / json.dumps prints it
+ * (tests/data/proof.json), proof.wit as generate_wit.py:218-243 prints it -- except for its numbers and
+ * for whitespace outside JSON strings, is read without a parse tree; every other text (other key
+ * order, escapes, non-canonical numbers, another shape, not a witness at all) is handed to the host
+ * reader behind ss_stwo_parse, which alone decides parsed / SS_STATUS_CONFIG_MISMATCH /
+ * SS_STATUS_MALFORMED.  Chunks are staged, uploaded, read, re-tiled and verified in a pipeline.
+ * status_host[i] is the verdict of input i (stage-0 codes above included).  stats may be NULL.      */
 int ss_stwo_verify_texts(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const char *const *texts,
                          const size_t *lens, int fmt, uint32_t *status_host, ss_ingest_stats *stats);
 int ss_stwo_verify_files(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const char *const *paths, int fmt,
@@ -241,6 +255,25 @@ int ss_s101_verify_texts(ss_ctx *ctx, size_t n, const char *const *texts, const 
                          uint32_t *status_host, ss_ingest_stats *stats);
 int ss_s101_verify_files(ss_ctx *ctx, size_t n, const char *const *paths, int fmt, uint32_t *status_host,
                          ss_ingest_stats *stats);
+
+/* Record -> text, byte for byte what the reference's adapter prints for that proof
+ * (stwo-verifier/scripts/generate_wit.py:218-243 for SS_TEXT_WIT; the proof.json schema it reads, :106-245,
+ * for SS_TEXT_JSON with `python_separators` 0 = "," ":" as in tests/data/proof.json, 1 = ", " ": " as
+ * json.dumps prints).  Returns the text's length; the text is written when it fits `cap` (no terminator).
+ * 0 = not writable: unsupported config, a Merkle path whose length is not the config's, or (JSON) a
+ * pow_target that is no 2^(64-bits) - 1.  No GPU involved.                                           */
+size_t ss_stwo_write_text(const ss_stwo_cfg *cfg, const uint32_t *record, int fmt, int python_separators,
+                          char *buf, size_t cap);
+/* Diagnostic: would ss_stwo_verify_texts read this text on the GPU (1) or hand it to the host reader (0)?
+ * fmt is SS_TEXT_JSON or SS_TEXT_WIT.  Scalar statement of the GPU reader's rule (ss_text.h); when it
+ * returns 1 and record_out is not NULL, record_out holds the record.  No GPU involved.              */
+int ss_stwo_text_is_canonical(const ss_stwo_cfg *cfg, const char *text, size_t len, int fmt, uint32_t *record_out);
+
+/* The GPU reader alone (diagnostic): n texts of format fmt (SS_TEXT_JSON / SS_TEXT_WIT) -> records_host
+ * (n * ss_stwo_record_words words) and outcome_host[i] = 0 (canonical: record i written by the GPU) or 1
+ * (left to the host reader; record i unspecified).  Synchronous; outcome equals ss_stwo_text_is_canonical. */
+int ss_stwo_read_texts(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const char *const *texts, const size_t *lens,
+                       int fmt, uint32_t *records_host, uint32_t *outcome_host);
 
 /* Per-stage intermediates of one proof after a verify call (the reference's counterpart is the
  * debug tracker of `simfony run`, simfony-cli/src/tracker.rs:48-80, which prints the values a

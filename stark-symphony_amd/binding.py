@@ -46,7 +46,7 @@ class IngestStats(C.Structure):
     """ss_ingest_stats"""
     _fields_ = [("read_s", C.c_double), ("parse_s", C.c_double), ("total_s", C.c_double),
                 ("text_bytes", C.c_uint64), ("record_bytes", C.c_uint64), ("threads", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("host_parsed", C.c_uint32)]
 
 
 TEXT_AUTO, TEXT_JSON, TEXT_WIT = 0, 1, 2
@@ -61,7 +61,7 @@ EXPORTS = [
     "ss_ctx_create", "ss_ctx_destroy", "ss_s101_verify_batch_dev", "ss_stwo_verify_batch_dev",
     "ss_s101_verify_phase_dev", "ss_stwo_verify_phase_dev", "ss_stwo_pack_dev",
     "ss_s101_verify_records", "ss_stwo_verify_records", "ss_ctx_set_timing", "ss_ctx_collect_timing",
-    "ss_selftest",
+    "ss_selftest", "ss_stwo_write_text", "ss_stwo_text_is_canonical", "ss_stwo_read_texts",
 ]
 
 _lib = None
@@ -122,9 +122,12 @@ def lib() -> C.CDLL:
     sig("ss_stwo_verify_files", C.c_int, vp, cp, sz, cpp, C.c_int, vp, stp)
     sig("ss_s101_verify_texts", C.c_int, vp, sz, cpp, szp, C.c_int, vp, stp)
     sig("ss_s101_verify_files", C.c_int, vp, sz, cpp, C.c_int, vp, stp)
+    sig("ss_stwo_read_texts", C.c_int, vp, cp, sz, cpp, szp, C.c_int, vp, vp)
     sig("ss_stwo_ws_layout_of", C.c_int, cp, sz, C.POINTER(StwoWsLayout))
     sig("ss_stwo_read_intermediates", C.c_int, vp, cp, sz, vp, sz, vp, vp, vp, vp, vp, vp)
     sig("ss_selftest", C.c_int, vp, C.c_int, sz, vp, vp)
+    sig("ss_stwo_write_text", sz, cp, vp, C.c_int, C.c_int, vp, sz)
+    sig("ss_stwo_text_is_canonical", C.c_int, cp, C.c_char_p, sz, C.c_int, vp)
     _lib = L
     return L
 

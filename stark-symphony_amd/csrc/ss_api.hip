@@ -12,6 +12,7 @@
 #include <string>
 
 #include "../../include/ss_verify.h"
+#include "ss_ctx.h"
 #include "ss_fields.h"
 #include "ss_ingest.h"
 #include "ss_kernels.h"
@@ -23,7 +24,7 @@ using namespace ss;
 // ------------------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
 
-static int set_err(int code, const char *fmt, ...)
+int ss::set_err(int code, const char *fmt, ...)
 {
     va_list ap;
     va_start(ap, fmt);
@@ -31,13 +32,6 @@ static int set_err(int code, const char *fmt, ...)
     va_end(ap);
     return code;
 }
-
-#define HIP_TRY(expr)                                                                     \
-    do {                                                                                  \
-        hipError_t e_ = (expr);                                                           \
-        if (e_ != hipSuccess)                                                             \
-            return set_err(SS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));    \
-    } while (0)
 
 extern "C" int ss_internal_set_err(int code, const char *msg) { return set_err(code, "%s", msg); }
 
@@ -56,34 +50,24 @@ extern "C" int ss_device_count(void)
 }
 
 // ----------------------------------------------------------------------------- context
-struct TimedSpan {
-    const char *name;
-    hipEvent_t start, stop;
-};
-
-// Grow-only scratch of the host-buffer entry points (ss_*_verify_records): pinned staging for
-// the chunked upload and the device buffers, so repeated calls do not pay hipMalloc /
-// hipHostMalloc again.
-struct HostPath {
-    void *pinned[2] = {nullptr, nullptr};
-    size_t pinned_bytes = 0;
-    hipEvent_t pinned_free[2] = {nullptr, nullptr};
-    void *dev[4] = {nullptr, nullptr, nullptr, nullptr};  // records, batch, ws, status
-    size_t dev_bytes[4] = {0, 0, 0, 0};
-    hipStream_t stream = nullptr;
-};
-
-struct ss_ctx {
-    int device;
-    int timing;
-    int cus;                 // compute units of the device
-    int top_blocks_per_cu[2];  // resident stwo_top_kernel blocks per CU, per hash family (0 = not yet asked)
-    std::vector<TimedSpan> spans;   // recorded since the last collect
-    std::vector<hipEvent_t> pool;   // recycled events
-    HostPath hp;
-};
-
 static constexpr size_t kMaxSpans = 1 << 16;
+
+// Blocks of the persistent top kernel that are resident at once: from the kernel's own register and
+// LDS footprint (512 VGPRs per SIMD lane in granules of 8, 160 KB LDS per CU; a block's
+// kTopChains / 64 waves go to different SIMDs of the CU).  The grid must not exceed this, or the surplus blocks
+// run after the others at a fraction of the occupancy.  Asked once, when the context is created.
+static int top_blocks_per_cu(int hf)
+{
+    hipFuncAttributes a;
+    const void *fn = hf ? (const void *)stwo_top_kernel_b2s : (const void *)stwo_top_kernel_sha;
+    int per_cu = 4;
+    if (hipFuncGetAttributes(&a, fn) == hipSuccess && a.numRegs > 0) {
+        const int by_regs = 512 / ((a.numRegs + 7) / 8 * 8);
+        const int by_lds = a.sharedSizeBytes ? (int)((160u << 10) / a.sharedSizeBytes) : 8;
+        per_cu = std::max(1, std::min(16, std::min(by_regs * 4 / (int)(kTopChains / 64), by_lds)));
+    }
+    return per_cu;
+}
 
 extern "C" int ss_ctx_create(int device, ss_ctx **out)
 {
@@ -101,7 +85,8 @@ extern "C" int ss_ctx_create(int device, ss_ctx **out)
     c->device = device;
     c->timing = 0;
     c->cus = prop.multiProcessorCount;
-    c->top_blocks_per_cu[0] = c->top_blocks_per_cu[1] = 0;
+    c->top_blocks_per_cu[0] = top_blocks_per_cu(0);
+    c->top_blocks_per_cu[1] = top_blocks_per_cu(1);
     *out = c;
     return SS_OK;
 }
@@ -118,6 +103,7 @@ extern "C" void ss_ctx_destroy(ss_ctx *ctx)
     for (auto &d : ctx->hp.dev)
         if (d) (void)hipFree(d);
     if (ctx->hp.stream) (void)hipStreamDestroy(ctx->hp.stream);
+    text_path_destroy(ctx->tp);
     delete ctx;
 }
 
@@ -142,6 +128,7 @@ extern "C" int ss_ctx_collect_timing(ss_ctx *ctx, int cap, const char **names, f
                                      uint32_t *launches)
 {
     if (!ctx || !names || !total_ms || !launches) return set_err(SS_ERR_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(ctx->span_mu);
     int k = 0;
     for (auto &sp : ctx->spans) {
         float ms = 0.f;
@@ -162,48 +149,31 @@ extern "C" int ss_ctx_collect_timing(ss_ctx *ctx, int cap, const char **names, f
     return k;
 }
 
-// Records one (start, stop) event pair around each kernel launch on the launch stream.
-struct Timer {
-    ss_ctx *c;
-    hipStream_t s;
-    hipEvent_t cur = nullptr;
-    Timer(ss_ctx *c_, hipStream_t s_) : c(c_), s(s_) {}
-    void begin()
-    {
-        if (!c->timing || c->spans.size() >= kMaxSpans) return;
-        cur = take_event(c);
-        if (cur && hipEventRecord(cur, s) != hipSuccess) { c->pool.push_back(cur); cur = nullptr; }
-    }
-    void end(const char *name)
-    {
-        if (!cur) return;
-        hipEvent_t stop = take_event(c);
-        if (!stop || hipEventRecord(stop, s) != hipSuccess) {
-            if (stop) c->pool.push_back(stop);
-            c->pool.push_back(cur);
-        } else {
-            c->spans.push_back({name, cur, stop});
-        }
-        cur = nullptr;
-    }
-};
-
-// ------------------------------------------------------------------------ host threads
-// `max_threads` bounds the fan-out: a thread is only worth starting for a few MiB of copying.
-template <class F>
-static void parallel_for(size_t n, F f, size_t max_threads = 16)
+void ss::Timer::begin()
 {
-    unsigned hw = std::thread::hardware_concurrency();
-    size_t nt = std::max<size_t>(1, std::min<size_t>(hw ? hw : 1, std::min<size_t>(n, max_threads)));
-    if (nt == 1) { for (size_t i = 0; i < n; i++) f(i); return; }
-    std::vector<std::thread> th;
-    for (size_t t = 0; t < nt; t++)
-        th.emplace_back([=]() { for (size_t i = t; i < n; i += nt) f(i); });
-    for (auto &x : th) x.join();
+    if (!c->timing) return;
+    std::lock_guard<std::mutex> lk(c->span_mu);
+    if (c->spans.size() >= kMaxSpans) return;
+    cur = take_event(c);
+    if (cur && hipEventRecord(cur, s) != hipSuccess) { c->pool.push_back(cur); cur = nullptr; }
+}
+
+void ss::Timer::end(const char *name)
+{
+    if (!cur) return;
+    std::lock_guard<std::mutex> lk(c->span_mu);
+    hipEvent_t stop = take_event(c);
+    if (!stop || hipEventRecord(stop, s) != hipSuccess) {
+        if (stop) c->pool.push_back(stop);
+        c->pool.push_back(cur);
+    } else {
+        c->spans.push_back({name, cur, stop});
+    }
+    cur = nullptr;
 }
 
 // ================================================================================ stwo
-static bool cfg_ok(const ss_stwo_cfg *c)
+bool ss::cfg_ok(const ss_stwo_cfg *c)
 {
     return c && c->hash <= SS_HASH_BLAKE2S && c->flags <= SS_FLAG_NO_DEDUP &&
            stwo_cfg_ok(c->n_cols, c->trace_log, c->lde_log, c->n_queries, c->n_layers, c->mode);
@@ -311,26 +281,6 @@ extern "C" int ss_stwo_pack(const ss_stwo_cfg *c, size_t n, const uint32_t *cons
     return SS_OK;
 }
 
-// Blocks of the persistent top kernel that are resident at once: from the kernel's own register and
-// LDS footprint (512 VGPRs per SIMD lane in granules of 8, 160 KB LDS per CU; a block's
-// kTopChains / 64 waves go to different SIMDs of the CU).  The grid must not exceed this, or the surplus blocks
-// run after the others at a fraction of the occupancy.
-static int top_resident_blocks(ss_ctx *ctx, int hf)
-{
-    if (!ctx->top_blocks_per_cu[hf]) {
-        hipFuncAttributes a;
-        const void *fn = hf ? (const void *)stwo_top_kernel_b2s : (const void *)stwo_top_kernel_sha;
-        int per_cu = 4;
-        if (hipFuncGetAttributes(&a, fn) == hipSuccess && a.numRegs > 0) {
-            const int by_regs = 512 / ((a.numRegs + 7) / 8 * 8);
-            const int by_lds = a.sharedSizeBytes ? (int)((160u << 10) / a.sharedSizeBytes) : 8;
-            per_cu = std::max(1, std::min(16, std::min(by_regs * 4 / (int)(kTopChains / 64), by_lds)));
-        }
-        ctx->top_blocks_per_cu[hf] = per_cu;
-    }
-    return ctx->top_blocks_per_cu[hf] * ctx->cus;
-}
-
 extern "C" int ss_stwo_verify_phase_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n,
                                         const uint32_t *batch, void *workspace, size_t workspace_bytes,
                                         uint32_t *status, uint32_t *accept_count, int phases,
@@ -369,7 +319,7 @@ extern "C" int ss_stwo_verify_phase_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_
         if (y.T) {
             t.begin();
             const int hf = c->hash == SS_HASH_BLAKE2S;
-            const uint32_t blocks = std::min<uint32_t>(y.top_blocks, (uint32_t)top_resident_blocks(ctx, hf));
+            const uint32_t blocks = std::min<uint32_t>(y.top_blocks, (uint32_t)(ctx->top_blocks_per_cu[hf] * ctx->cus));
             HIP_TRY(hipMemsetAsync(ws + y.ws_counter, 0, 4, s));  // the kernel's group counter
             hipLaunchKernelGGL(hf ? stwo_top_kernel_b2s : stwo_top_kernel_sha, dim3(blocks), dim3(kTopChains), 0, s,
                                y, batch, ws, status);
@@ -654,6 +604,7 @@ extern "C" int ss_stwo_verify_records(ss_ctx *ctx, const ss_stwo_cfg *c, size_t 
     if (!cfg_ok(c)) return set_err(SS_ERR_ARG, "unsupported stwo config");
     if (!n) return set_err(SS_ERR_ARG, "empty batch");
     if (n * (size_t)c->n_queries > 0x7fffffffu) return set_err(SS_ERR_ARG, "batch too large");
+    std::lock_guard<std::mutex> lock(ctx->mu);  // the context's scratch: one such call at a time
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t W = ss_stwo_record_words(c), words = ss_stwo_batch_words(c, n);
     const size_t wsb = ss_stwo_workspace_bytes(c, n);
@@ -695,6 +646,7 @@ extern "C" int ss_s101_verify_records(ss_ctx *ctx, const ss_s101_shape *sh, size
     if (!shape_ok(sh)) return set_err(SS_ERR_ARG, "unsupported stark101 shape");
     if (!n) return set_err(SS_ERR_ARG, "empty batch");
     if (n > 0x7fffffffu) return set_err(SS_ERR_ARG, "batch too large");
+    std::lock_guard<std::mutex> lock(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t words = ss_s101_batch_words(sh, n), wsb = ss_s101_workspace_bytes(sh, n);
     int rc;
@@ -740,12 +692,36 @@ extern "C" int ss_s101_parse(const char *text, size_t len, int fmt, ss_s101_shap
     return 0;
 }
 
-static double now_s()
+extern "C" size_t ss_stwo_write_text(const ss_stwo_cfg *c, const uint32_t *record, int fmt, int python_separators,
+                                     char *buf, size_t cap)
+{
+    if (!cfg_ok(c) || !record || (fmt != SS_TEXT_JSON && fmt != SS_TEXT_WIT)) { set_err(SS_ERR_ARG, "bad argument"); return 0; }
+    std::string out;
+    const bool ok = fmt == SS_TEXT_JSON ? stwo_write_json(*c, record, python_separators ? kStylePython : kStyleCompact, out)
+                                        : stwo_write_wit(*c, record, out);
+    if (!ok) { set_err(SS_ERR_ARG, "record cannot be written in this format (path lengths / pow_target)"); return 0; }
+    if (buf && out.size() <= cap) memcpy(buf, out.data(), out.size());
+    return out.size();
+}
+
+extern "C" int ss_stwo_text_is_canonical(const ss_stwo_cfg *c, const char *text, size_t len, int fmt, uint32_t *record_out)
+{
+    if (!cfg_ok(c) || !text || (fmt != SS_TEXT_JSON && fmt != SS_TEXT_WIT)) return set_err(SS_ERR_ARG, "bad argument");
+    TextTemplateHost h;
+    stwo_build_template(*c, fmt, h);
+    if (!h.ok) return 0;
+    std::vector<uint32_t> scratch;
+    uint32_t *rec = record_out;
+    if (!rec) { scratch.resize(h.record_words); rec = scratch.data(); }
+    return text_scan_reference(h.view(), text, len, rec) ? 1 : 0;
+}
+
+double ss::now_s()
 {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-static bool read_file(const char *path, std::string &out)
+bool ss::read_file(const char *path, std::string &out)
 {
     FILE *f = fopen(path, "rb");
     if (!f) return false;
@@ -762,91 +738,22 @@ static bool read_file(const char *path, std::string &out)
     return ok;
 }
 
-// texts (or files, read inside the worker threads) -> records in pinned staging -> GPU
-static int stwo_ingest(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *const *texts, const size_t *lens,
-                       const char *const *paths, int fmt, uint32_t *status_host, ss_ingest_stats *stats)
-{
-    if (!ctx || !status_host || (!texts && !paths) || (texts && !lens)) return set_err(SS_ERR_ARG, "null argument");
-    if (!cfg_ok(c)) return set_err(SS_ERR_ARG, "unsupported stwo config");
-    if (!n) return set_err(SS_ERR_ARG, "empty batch");
-    if (fmt < SS_TEXT_AUTO || fmt > SS_TEXT_WIT) return set_err(SS_ERR_ARG, "unknown text format");
-    if (n * (size_t)c->n_queries > 0x7fffffffu) return set_err(SS_ERR_ARG, "batch too large");
-    const double t0 = now_s();
-    HIP_TRY(hipSetDevice(ctx->device));
-    const size_t W = ss_stwo_record_words(c), words = ss_stwo_batch_words(c, n);
-    const size_t wsb = ss_stwo_workspace_bytes(c, n);
-    int rc;
-    if ((rc = hp_reserve(ctx, 0, n * W * 4))) return rc;
-    if ((rc = hp_reserve(ctx, 1, words * 4))) return rc;
-    if ((rc = hp_reserve(ctx, 2, wsb))) return rc;
-    if ((rc = hp_reserve(ctx, 3, n * 4))) return rc;
-    const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, (64u << 20) / (W * 4)));
-    if ((rc = hp_pinned(ctx, chunk * W * 4))) return rc;
-    HostPath &hp = ctx->hp;
-    hipStream_t s = hp.stream;
-    uint32_t *rec_dev = (uint32_t *)hp.dev[0];
-    const unsigned threads = effective_cpus();
-    std::vector<uint8_t> outcome(n, 0);
-    std::vector<uint64_t> tbytes(n, 0);
-    double parse_s = 0;
-    int buf = 0;
-    for (size_t lo = 0; lo < n; lo += chunk, buf ^= 1) {
-        const size_t cnt = std::min(chunk, n - lo);
-        HIP_TRY(hipEventSynchronize(hp.pinned_free[buf]));  // previous upload from this buffer done
-        uint32_t *stage = (uint32_t *)hp.pinned[buf];
-        const double tp = now_s();
-        parallel_for(cnt, [&](size_t i) {
-            uint32_t *dst = stage + i * W;
-            ParseResult r;
-            if (paths) {
-                std::string text;
-                r = read_file(paths[lo + i], text) ? stwo_parse_text(*c, text.data(), text.size(), fmt, dst) : kMalformed;
-                tbytes[lo + i] = text.size();
-            } else {
-                r = stwo_parse_text(*c, texts[lo + i], lens[lo + i], fmt, dst);
-                tbytes[lo + i] = lens[lo + i];
-            }
-            if (r != kParsed) memset(dst, 0, W * 4);
-            outcome[lo + i] = (uint8_t)r;
-        }, threads);
-        parse_s += now_s() - tp;
-        HIP_TRY(hipMemcpyAsync(rec_dev + lo * W, stage, cnt * W * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipEventRecord(hp.pinned_free[buf], s));
-    }
-    if ((rc = ss_stwo_pack_dev(ctx, c, n, rec_dev, (uint32_t *)hp.dev[1], s))) return rc;
-    rc = ss_stwo_verify_batch_dev(ctx, c, n, (const uint32_t *)hp.dev[1], hp.dev[2], wsb, (uint32_t *)hp.dev[3],
-                                  nullptr, s);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(status_host, hp.dev[3], n * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    uint64_t tb = 0;
-    for (size_t i = 0; i < n; i++) {
-        if (outcome[i] == kMalformed) status_host[i] = SS_STATUS_MALFORMED;
-        else if (outcome[i] == kConfigMismatch) status_host[i] = SS_STATUS_CONFIG_MISMATCH;
-        tb += tbytes[i];
-    }
-    if (stats) {
-        stats->read_s = 0;  // files are read inside the parse workers
-        stats->parse_s = parse_s;
-        stats->total_s = now_s() - t0;
-        stats->text_bytes = tb;
-        stats->record_bytes = (uint64_t)n * W * 4;
-        stats->threads = threads;
-        stats->reserved = 0;
-    }
-    return SS_OK;
-}
-
 extern "C" int ss_stwo_verify_texts(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *const *texts,
                                     const size_t *lens, int fmt, uint32_t *status_host, ss_ingest_stats *stats)
 {
-    return stwo_ingest(ctx, c, n, texts, lens, nullptr, fmt, status_host, stats);
+    return stwo_ingest_dev(ctx, c, n, texts, lens, nullptr, fmt, status_host, stats);
+}
+
+extern "C" int ss_stwo_read_texts(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *const *texts,
+                                  const size_t *lens, int fmt, uint32_t *records_host, uint32_t *outcome_host)
+{
+    return stwo_read_texts_dev(ctx, c, n, texts, lens, fmt, records_host, outcome_host);
 }
 
 extern "C" int ss_stwo_verify_files(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *const *paths, int fmt,
                                     uint32_t *status_host, ss_ingest_stats *stats)
 {
-    return stwo_ingest(ctx, c, n, nullptr, nullptr, paths, fmt, status_host, stats);
+    return stwo_ingest_dev(ctx, c, n, nullptr, nullptr, paths, fmt, status_host, stats);
 }
 
 // stark101: parse everything (the shape of the batch is the largest proof's), then records -> GPU
@@ -901,7 +808,7 @@ static int s101_ingest(ss_ctx *ctx, size_t n, const char *const *texts, const si
         stats->text_bytes = tb;
         stats->record_bytes = (uint64_t)n * W * 4;
         stats->threads = threads;
-        stats->reserved = 0;
+        stats->host_parsed = (uint32_t)n;  // stark101 texts are read by the host reader
     }
     return SS_OK;
 }
@@ -985,6 +892,7 @@ extern "C" int ss_selftest(ss_ctx *ctx, int op, size_t n, const uint32_t *in_hos
 {
     static const int in_w[6] = {16, 2, 8, 1, 2, 8}, out_w[6] = {8, 4, 8, 2, 4, 16};
     if (!ctx || !in_host || !out_host || op < 0 || op > 5 || !n) return set_err(SS_ERR_ARG, "bad argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     DevBuf a, b;
     HIP_TRY(hipMalloc(&a.p, n * in_w[op] * 4));

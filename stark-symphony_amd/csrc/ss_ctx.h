@@ -1,0 +1,115 @@
+// Private definitions shared by the translation units behind include/ss_verify.h: the context, its
+// grow-only scratch, error reporting and kernel timing.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/ss_verify.h"
+#include "ss_pool.h"
+#include "ss_text.h"
+
+namespace ss {
+
+int set_err(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return ss::set_err(SS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));    \
+    } while (0)
+
+struct TimedSpan {
+    const char *name;
+    hipEvent_t start, stop;
+};
+
+// Grow-only scratch of the host-buffer entry points (ss_*_verify_records): pinned staging for
+// the chunked upload and the device buffers, so repeated calls do not pay hipMalloc /
+// hipHostMalloc again.
+struct HostPath {
+    void *pinned[2] = {nullptr, nullptr};
+    size_t pinned_bytes = 0;
+    hipEvent_t pinned_free[2] = {nullptr, nullptr};
+    void *dev[4] = {nullptr, nullptr, nullptr, nullptr};  // records, batch, ws, status
+    size_t dev_bytes[4] = {0, 0, 0, 0};
+    hipStream_t stream = nullptr;
+};
+
+// A config's text template resident on the device (ss_text.h), kept per (config, format).
+struct DevTemplate {
+    ss_stwo_cfg cfg;
+    int fmt;
+    bool ok;            // false: no fast path for this config / format
+    void *skel = nullptr, *slots = nullptr, *trailer = nullptr;
+    TextTemplate view;  // device pointers
+};
+
+// Scratch of the text entry points (ss_stwo_verify_texts / _files): double-buffered pinned staging and
+// device buffers for the raw text, the records the GPU reader writes, its outcomes.
+struct GrowBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    bool pinned = false;
+};
+struct TextPath {
+    GrowBuf text_pin[2], text_dev[2];  // texts + their offsets / lengths / formats behind them
+    GrowBuf rec_dev[2], out_dev[2], out_pin[2];
+    GrowBuf fix_pin[2];                // records re-made by the host reader, on their way up
+    GrowBuf batch_dev, ws_dev, status_dev;
+    GrowBuf win_dev;                   // per-window scratch of the GPU reader (ss_textdev.h)
+    hipStream_t up = nullptr, cx = nullptr;
+    hipEvent_t uploaded[2] = {nullptr, nullptr};  // H2D of buffer b complete (its pinned side is free again)
+    hipEvent_t parsed[2] = {nullptr, nullptr};    // GPU reader + outcome download of buffer b complete
+    hipEvent_t fixed[2] = {nullptr, nullptr};     // fix-up uploads from fix_pin[b] complete
+    std::vector<DevTemplate> templates;
+};
+
+}  // namespace ss
+
+struct ss_ctx {
+    int device;
+    int timing;
+    int cus;                   // compute units of the device
+    int top_blocks_per_cu[2];  // resident stwo_top_kernel blocks per CU, per hash family (0 = not yet asked)
+    std::vector<ss::TimedSpan> spans;  // recorded since the last collect
+    std::vector<hipEvent_t> pool;      // recycled events
+    ss::HostPath hp;
+    ss::TextPath tp;
+    // Entry points that use the context's own scratch (hp, tp) or its timing list hold this lock for
+    // their whole duration: one such call runs at a time per context (include/ss_verify.h, "threads").
+    std::mutex mu;
+    std::mutex span_mu;  // spans / pool (the device entry points record into them when timing is on)
+};
+
+namespace ss {
+
+// Records one (start, stop) event pair around each kernel launch on the launch stream.
+struct Timer {
+    ss_ctx *c;
+    hipStream_t s;
+    hipEvent_t cur = nullptr;
+    Timer(ss_ctx *c_, hipStream_t s_) : c(c_), s(s_) {}
+    void begin();
+    void end(const char *name);
+};
+
+int grow(GrowBuf &b, size_t bytes, bool pinned);  // (re)allocates when too small; contents are not kept
+void release(GrowBuf &b);
+
+bool cfg_ok(const ss_stwo_cfg *c);
+double now_s();
+bool read_file(const char *path, std::string &out);
+
+// texts (or files) -> verdicts through the GPU reader (csrc/ss_ingest_dev.hip)
+int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *const *texts, const size_t *lens,
+                    const char *const *paths, int fmt, uint32_t *status_host, ss_ingest_stats *stats);
+int stwo_read_texts_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *const *texts, const size_t *lens,
+                        int fmt, uint32_t *records_host, uint32_t *outcome_host);
+void text_path_destroy(TextPath &tp);
+
+}  // namespace ss

@@ -1,0 +1,445 @@
+// Texts / files -> verdicts (ss_stwo_verify_texts / _files of include/ss_verify.h), bound by the host link.
+//
+// The reference's callers hand the verifier text (stwo-verifier/scripts/generate_wit.py:106-245,218-243;
+// `simfony run --witness`, simfony-cli/src/main.rs:163-209).  Per chunk of ~64 MiB of text:
+//   host threads   copy (or read) the raw bytes into pinned staging -- no parsing;
+//   upload stream  one H2D copy of the chunk (one stream only: two concurrent H2D streams share the link
+//                  badly on this platform, profiles/r03_pcie_probe.txt);
+//   compute stream GPU reader (ss_textdev.hip) -> records + one outcome word per text, outcomes downloaded;
+//   host           texts the GPU reader did not take (outcome 1: not byte-for-byte canonical) go through the
+//                  tree parser of ss_ingest.cpp -- the arbiter for parsed / other config / malformed -- and
+//                  their records are uploaded over the GPU's;
+//   compute stream re-tile (ss_stwo_pack_dev) + verify the chunk.
+// Chunk c+1 is staged and uploaded while chunk c is read and verified.
+#include <hip/hip_runtime.h>
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ss_ctx.h"
+#include "ss_ingest.h"
+#include "ss_layout.h"
+#include "ss_textdev.h"
+
+namespace ss {
+
+int grow(GrowBuf &b, size_t bytes, bool pinned)
+{
+    if (b.p && b.bytes >= bytes) return SS_OK;
+    release(b);
+    bytes = (bytes + (bytes >> 2) + 4095) & ~(size_t)4095;  // 25 % headroom: chunks of one call differ a little
+    if (pinned) HIP_TRY(hipHostMalloc(&b.p, bytes, hipHostMallocDefault));
+    else HIP_TRY(hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    b.pinned = pinned;
+    return SS_OK;
+}
+
+void release(GrowBuf &b)
+{
+    if (b.p) { if (b.pinned) (void)hipHostFree(b.p); else (void)hipFree(b.p); }
+    b.p = nullptr;
+    b.bytes = 0;
+}
+
+void text_path_destroy(TextPath &tp)
+{
+    for (int i = 0; i < 2; i++) {
+        release(tp.text_pin[i]); release(tp.text_dev[i]); release(tp.rec_dev[i]); release(tp.out_dev[i]);
+        release(tp.out_pin[i]); release(tp.fix_pin[i]);
+        if (tp.uploaded[i]) (void)hipEventDestroy(tp.uploaded[i]);
+        if (tp.parsed[i]) (void)hipEventDestroy(tp.parsed[i]);
+        if (tp.fixed[i]) (void)hipEventDestroy(tp.fixed[i]);
+    }
+    release(tp.batch_dev); release(tp.ws_dev); release(tp.status_dev); release(tp.win_dev);
+    for (auto &t : tp.templates) {
+        if (t.skel) (void)hipFree(t.skel);
+        if (t.slots) (void)hipFree(t.slots);
+        if (t.trailer) (void)hipFree(t.trailer);
+    }
+    tp.templates.clear();
+    if (tp.up) (void)hipStreamDestroy(tp.up);
+    if (tp.cx) (void)hipStreamDestroy(tp.cx);
+    tp.up = tp.cx = nullptr;
+}
+
+namespace {
+
+bool same_text_cfg(const ss_stwo_cfg &a, const ss_stwo_cfg &b)
+{
+    return a.n_cols == b.n_cols && a.trace_log == b.trace_log && a.lde_log == b.lde_log &&
+           a.n_queries == b.n_queries && a.n_layers == b.n_layers && a.pow_target == b.pow_target && a.hash == b.hash;
+}
+
+// the device copy of (cfg, fmt)'s template, built on first use
+int template_of(ss_ctx *ctx, const ss_stwo_cfg &cfg, int fmt, hipStream_t s, TextTemplate &view)
+{
+    TextPath &tp = ctx->tp;
+    for (auto &t : tp.templates)
+        if (t.fmt == fmt && same_text_cfg(t.cfg, cfg)) { view = t.ok ? t.view : TextTemplate(); return SS_OK; }
+    if (tp.templates.size() >= 8) {  // a caller that cycles through many configs: drop the oldest
+        DevTemplate &o = tp.templates.front();
+        HIP_TRY(hipStreamSynchronize(s));
+        if (o.skel) (void)hipFree(o.skel);
+        if (o.slots) (void)hipFree(o.slots);
+        if (o.trailer) (void)hipFree(o.trailer);
+        tp.templates.erase(tp.templates.begin());
+    }
+    TextTemplateHost h;
+    stwo_build_template(cfg, fmt, h);
+    DevTemplate d{};
+    d.cfg = cfg; d.fmt = fmt; d.ok = h.ok;
+    if (h.ok) {
+        HIP_TRY(hipMalloc(&d.skel, h.skel.size()));
+        HIP_TRY(hipMalloc(&d.slots, h.slots.size() * sizeof(TextSlot)));
+        HIP_TRY(hipMalloc(&d.trailer, h.trailer.size() * 4));
+        HIP_TRY(hipMemcpy(d.skel, h.skel.data(), h.skel.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d.slots, h.slots.data(), h.slots.size() * sizeof(TextSlot), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d.trailer, h.trailer.data(), h.trailer.size() * 4, hipMemcpyHostToDevice));
+        d.view = h.view();
+        d.view.skel = (const uint8_t *)d.skel;
+        d.view.slots = (const TextSlot *)d.slots;
+        d.view.trailer = (const uint32_t *)d.trailer;
+    }
+    tp.templates.push_back(d);
+    view = d.ok ? d.view : TextTemplate();
+    return SS_OK;
+}
+
+int ensure_streams(TextPath &tp)
+{
+    if (!tp.up) HIP_TRY(hipStreamCreateWithFlags(&tp.up, hipStreamNonBlocking));
+    if (!tp.cx) HIP_TRY(hipStreamCreateWithFlags(&tp.cx, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+        if (!tp.uploaded[i]) HIP_TRY(hipEventCreateWithFlags(&tp.uploaded[i], hipEventDisableTiming));
+        if (!tp.parsed[i]) HIP_TRY(hipEventCreateWithFlags(&tp.parsed[i], hipEventDisableTiming));
+        if (!tp.fixed[i]) HIP_TRY(hipEventCreateWithFlags(&tp.fixed[i], hipEventDisableTiming));
+    }
+    return SS_OK;
+}
+
+constexpr size_t kChunkTextBytes = (size_t)64 << 20;    // text per chunk (one H2D copy)
+constexpr size_t kChunkRecordBytes = (size_t)256 << 20;  // records per chunk
+constexpr size_t kMaxTextBytes = (size_t)32 << 20;       // ss_ingest.cpp refuses longer texts
+
+struct Chunk {
+    size_t lo = 0, cnt = 0;
+    size_t text_bytes = 0;  // aligned text area
+};
+
+// read a whole file into dst (cap bytes); returns its length, or -1 (absent, unreadable, longer than cap)
+long read_into(const char *path, uint8_t *dst, size_t cap)
+{
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return -1;
+    size_t got = 0;
+    for (;;) {
+        if (got == cap) {  // exactly full: one more byte means the file grew past its stat size
+            char extra;
+            const ssize_t k = read(fd, &extra, 1);
+            close(fd);
+            return k == 0 ? (long)got : -1;
+        }
+        const ssize_t k = read(fd, dst + got, cap - got);
+        if (k < 0) { close(fd); return -1; }
+        if (k == 0) break;
+        got += (size_t)k;
+    }
+    close(fd);
+    return (long)got;
+}
+
+}  // namespace
+
+int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *const *texts, const size_t *lens,
+                    const char *const *paths, int fmt, uint32_t *status_host, ss_ingest_stats *stats)
+{
+    if (!ctx || !status_host || (!texts && !paths) || (texts && !lens)) return set_err(SS_ERR_ARG, "null argument");
+    if (!cfg_ok(c)) return set_err(SS_ERR_ARG, "unsupported stwo config");
+    if (!n) return set_err(SS_ERR_ARG, "empty batch");
+    if (fmt < SS_TEXT_AUTO || fmt > SS_TEXT_WIT) return set_err(SS_ERR_ARG, "unknown text format");
+    if (n * (size_t)c->n_queries > 0x7fffffffu) return set_err(SS_ERR_ARG, "batch too large");
+    std::lock_guard<std::mutex> lock(ctx->mu);  // the context's scratch: one such call at a time
+    const double t0 = now_s();
+    HIP_TRY(hipSetDevice(ctx->device));
+    TextPath &tp = ctx->tp;
+    int rc;
+    if ((rc = ensure_streams(tp))) return rc;
+    const size_t W = ss_stwo_record_words(c);
+    TextParseArgs args{};
+    if ((rc = template_of(ctx, *c, SS_TEXT_JSON, tp.cx, args.tmpl[0]))) return rc;
+    if ((rc = template_of(ctx, *c, SS_TEXT_WIT, tp.cx, args.tmpl[1]))) return rc;
+    args.record_words = (uint32_t)W;
+    const unsigned threads = effective_cpus();
+
+    // ---- sizes (files: stat) and the chunk plan
+    std::vector<uint32_t> tlen(n, 0);
+    std::vector<uint8_t> unreadable(n, 0);
+    if (paths) {
+        parallel_for(n, [&](size_t i) {
+            struct stat st;
+            if (stat(paths[i], &st) != 0 || !S_ISREG(st.st_mode) || (uint64_t)st.st_size > kMaxTextBytes) unreadable[i] = 1;
+            else tlen[i] = (uint32_t)st.st_size;
+        }, threads);
+    } else {
+        for (size_t i = 0; i < n; i++) {
+            if (!texts[i] || lens[i] > kMaxTextBytes) unreadable[i] = 1;  // longer than any witness: malformed by rule
+            else tlen[i] = (uint32_t)lens[i];
+        }
+    }
+    auto aligned = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    std::vector<Chunk> chunks;
+    {
+        Chunk cur;
+        for (size_t i = 0; i < n; i++) {
+            const size_t a = aligned(tlen[i]);
+            if (cur.cnt && (cur.text_bytes + a > kChunkTextBytes || (cur.cnt + 1) * W * 4 > kChunkRecordBytes)) {
+                chunks.push_back(cur);
+                cur = Chunk{i, 0, 0};
+            }
+            cur.cnt++;
+            cur.text_bytes += a;
+        }
+        chunks.push_back(cur);
+    }
+    size_t max_cnt = 0, max_text = 0;
+    for (auto &ch : chunks) { max_cnt = std::max(max_cnt, ch.cnt); max_text = std::max(max_text, ch.text_bytes); }
+    // staging layout of a chunk:
+    //   [texts, 16-byte aligned each][slack][offs u64 x cnt][lens u32 x cnt][win_base u32 x (cnt + 1)][fmt u8 x cnt]
+    auto meta_off = [&](const Chunk &ch) { return aligned(ch.text_bytes + kTextSlack); };
+    auto stage_bytes = [&](const Chunk &ch) { return meta_off(ch) + ch.cnt * 17 + 4 + 16; };
+    const size_t stage_cap = aligned(max_text + kTextSlack) + max_cnt * 17 + 4 + 16;
+    const size_t max_windows = (max_text / 1024 + max_cnt + 4) & ~(size_t)3;  // ceil(len / 1024) per text; keeps WinSum 16-byte aligned
+    ss_stwo_cfg cv = *c;
+    size_t words = 0, wsb = 0;  // (the workspace is not monotone in the batch size: smaller batches get smaller groups)
+    for (auto &ch : chunks) {
+        words = std::max(words, ss_stwo_batch_words(&cv, ch.cnt));
+        wsb = std::max(wsb, ss_stwo_workspace_bytes(&cv, ch.cnt));
+    }
+    for (int b = 0; b < 2; b++) {
+        if ((rc = grow(tp.text_pin[b], stage_cap, true))) return rc;
+        if ((rc = grow(tp.text_dev[b], stage_cap, false))) return rc;
+        if ((rc = grow(tp.rec_dev[b], max_cnt * W * 4, false))) return rc;
+        if ((rc = grow(tp.out_dev[b], max_cnt * 4, false))) return rc;
+        if ((rc = grow(tp.out_pin[b], max_cnt * 4, true))) return rc;
+    }
+    if ((rc = grow(tp.win_dev, max_windows * (4 + sizeof(WinSum) + sizeof(WinIn)), false))) return rc;
+    if ((rc = grow(tp.batch_dev, words * 4, false))) return rc;
+    if ((rc = grow(tp.ws_dev, wsb, false))) return rc;
+    if ((rc = grow(tp.status_dev, n * 4, false))) return rc;
+
+    std::vector<uint8_t> outcome(n, 0);  // ParseResult of the texts the host reader handled (0 = verified as parsed)
+    double stage_s = 0, parse_s = 0;
+    uint64_t text_total = 0, fallbacks = 0;
+    uint32_t *status_dev = (uint32_t *)tp.status_dev.p;
+
+    // what the host has to do once the GPU reader of chunk k is through: re-read what it did not take,
+    // then re-tile and verify the chunk
+    auto finish = [&](size_t k) -> int {
+        const Chunk &ch = chunks[k];
+        const int b = (int)(k & 1);
+        HIP_TRY(hipEventSynchronize(tp.parsed[b]));
+        const uint32_t *oc = (const uint32_t *)tp.out_pin[b].p;
+        std::vector<uint32_t> todo;
+        for (size_t i = 0; i < ch.cnt; i++)
+            if (oc[i] != 0) todo.push_back((uint32_t)i);
+        if (!todo.empty()) {
+            const double tp0 = now_s();
+            fallbacks += todo.size();
+            HIP_TRY(hipEventSynchronize(tp.fixed[b]));  // fix_pin[b]'s previous uploads are through
+            if ((rc = grow(tp.fix_pin[b], todo.size() * W * 4, true))) return rc;
+            uint32_t *fix = (uint32_t *)tp.fix_pin[b].p;
+            const uint8_t *stage = (const uint8_t *)tp.text_pin[b].p;
+            const uint64_t *offs = (const uint64_t *)(stage + meta_off(ch));
+            parallel_for(todo.size(), [&](size_t j) {
+                const size_t i = todo[j], g = ch.lo + i;
+                uint32_t *dst = fix + j * W;
+                ParseResult r = kMalformed;
+                if (!unreadable[g]) r = stwo_parse_text(*c, (const char *)stage + offs[i], tlen[g], fmt, dst);
+                if (r != kParsed) memset(dst, 0, W * 4);
+                outcome[g] = (uint8_t)r;
+            }, threads);
+            uint32_t *rec = (uint32_t *)tp.rec_dev[b].p;
+            for (size_t j = 0; j < todo.size(); j++)
+                HIP_TRY(hipMemcpyAsync(rec + (size_t)todo[j] * W, fix + j * W, W * 4, hipMemcpyHostToDevice, tp.cx));
+            HIP_TRY(hipEventRecord(tp.fixed[b], tp.cx));
+            parse_s += now_s() - tp0;
+        }
+        if ((rc = ss_stwo_pack_dev(ctx, c, ch.cnt, (const uint32_t *)tp.rec_dev[b].p, (uint32_t *)tp.batch_dev.p, tp.cx))) return rc;
+        return ss_stwo_verify_batch_dev(ctx, c, ch.cnt, (const uint32_t *)tp.batch_dev.p, tp.ws_dev.p, tp.ws_dev.bytes,
+                                        status_dev + ch.lo, nullptr, tp.cx);
+    };
+
+    for (size_t k = 0; k < chunks.size(); k++) {
+        const Chunk &ch = chunks[k];
+        const int b = (int)(k & 1);
+        // ---- stage: raw bytes into pinned memory (the previous upload from this buffer is through, and the
+        // host reader no longer needs its texts: finish(k - 2) ran before stage(k))
+        HIP_TRY(hipEventSynchronize(tp.uploaded[b]));
+        const double ts0 = now_s();
+        uint8_t *stage = (uint8_t *)tp.text_pin[b].p;
+        uint64_t *offs = (uint64_t *)(stage + meta_off(ch));
+        uint32_t *lens32 = (uint32_t *)(offs + ch.cnt);
+        uint32_t *win_base = lens32 + ch.cnt;
+        uint8_t *fmts = (uint8_t *)(win_base + ch.cnt + 1);
+        {
+            size_t o = 0;
+            for (size_t i = 0; i < ch.cnt; i++) { offs[i] = o; o += aligned(tlen[ch.lo + i]); }
+        }
+        parallel_for(ch.cnt, [&](size_t i) {
+            const size_t g = ch.lo + i;
+            uint8_t *dst = stage + offs[i];
+            uint32_t len = tlen[g];
+            if (unreadable[g]) len = 0;
+            else if (paths) {
+                const long got = read_into(paths[g], dst, len);
+                if (got < 0) { unreadable[g] = 1; len = 0; }
+                else { len = (uint32_t)got; tlen[g] = len; }  // (a file that shrank since stat)
+            } else {
+                memcpy(dst, texts[g], len);
+            }
+            lens32[i] = len;
+            // which template to try: a .wit is a JSON object whose first member is COMMITMENTS.  A wrong guess
+            // only costs the fast path -- the host reader sniffs for itself.
+            uint8_t f = fmt == SS_TEXT_WIT;
+            if (fmt == SS_TEXT_AUTO) {
+                const size_t look = len < 64 ? len : 64;
+                static const char key[] = "\"COMMITMENTS\"";
+                for (size_t p = 0; p + sizeof key - 1 <= look && !f; p++) f = memcmp(dst + p, key, sizeof key - 1) == 0;
+            }
+            fmts[i] = f;
+        }, threads);
+        uint32_t n_windows = 0;  // (after the reads: a file may have shrunk since its stat)
+        for (size_t i = 0; i < ch.cnt; i++) {
+            text_total += lens32[i];
+            win_base[i] = n_windows;
+            n_windows += (lens32[i] + 1023) >> 10;
+        }
+        win_base[ch.cnt] = n_windows;
+        stage_s += now_s() - ts0;
+        // ---- upload (after the GPU reader of chunk k - 2 has finished with the device buffer)
+        HIP_TRY(hipStreamWaitEvent(tp.up, tp.parsed[b], 0));
+        HIP_TRY(hipMemcpyAsync(tp.text_dev[b].p, stage, stage_bytes(ch), hipMemcpyHostToDevice, tp.up));
+        HIP_TRY(hipEventRecord(tp.uploaded[b], tp.up));
+        // ---- GPU reader
+        HIP_TRY(hipStreamWaitEvent(tp.cx, tp.uploaded[b], 0));
+        const uint8_t *dev = (const uint8_t *)tp.text_dev[b].p;
+        args.texts = dev;
+        args.offs = (const uint64_t *)(dev + meta_off(ch));
+        args.lens = (const uint32_t *)(args.offs + ch.cnt);
+        args.win_base = args.lens + ch.cnt;
+        args.fmt = (const uint8_t *)(args.win_base + ch.cnt + 1);
+        args.win_text = (uint32_t *)tp.win_dev.p;
+        args.win_sum = (WinSum *)(args.win_text + max_windows);
+        args.win_in = (WinIn *)(args.win_sum + max_windows);
+        args.records = (uint32_t *)tp.rec_dev[b].p;
+        args.outcome = (uint32_t *)tp.out_dev[b].p;
+        args.n = (uint32_t)ch.cnt;
+        args.n_windows = n_windows;
+        {
+            Timer t(ctx, tp.cx);
+            t.begin();
+            launch_text_parse(args, tp.cx);
+            t.end("stwo_text_parse");
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(tp.out_pin[b].p, tp.out_dev[b].p, ch.cnt * 4, hipMemcpyDeviceToHost, tp.cx));
+        HIP_TRY(hipEventRecord(tp.parsed[b], tp.cx));
+        if (k > 0 && (rc = finish(k - 1))) return rc;
+    }
+    if ((rc = finish(chunks.size() - 1))) return rc;
+    HIP_TRY(hipMemcpyAsync(status_host, status_dev, n * 4, hipMemcpyDeviceToHost, tp.cx));
+    HIP_TRY(hipStreamSynchronize(tp.cx));
+    HIP_TRY(hipStreamSynchronize(tp.up));
+    for (size_t i = 0; i < n; i++) {
+        if (outcome[i] == kMalformed) status_host[i] = SS_STATUS_MALFORMED;
+        else if (outcome[i] == kConfigMismatch) status_host[i] = SS_STATUS_CONFIG_MISMATCH;
+    }
+    if (stats) {
+        stats->read_s = stage_s;
+        stats->parse_s = parse_s;
+        stats->total_s = now_s() - t0;
+        stats->text_bytes = text_total;
+        stats->record_bytes = (uint64_t)n * W * 4;
+        stats->threads = threads;
+        stats->host_parsed = (uint32_t)std::min<uint64_t>(fallbacks, 0xffffffffu);
+    }
+    return SS_OK;
+}
+
+// The GPU reader alone (diagnostic / tests): texts -> records + outcome words, synchronous, own buffers.
+int stwo_read_texts_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *const *texts, const size_t *lens,
+                        int fmt, uint32_t *records_host, uint32_t *outcome_host)
+{
+    if (!ctx || !texts || !lens || !records_host || !outcome_host) return set_err(SS_ERR_ARG, "null argument");
+    if (!cfg_ok(c) || !n || (fmt != SS_TEXT_JSON && fmt != SS_TEXT_WIT)) return set_err(SS_ERR_ARG, "bad argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    HIP_TRY(hipSetDevice(ctx->device));
+    TextPath &tp = ctx->tp;
+    int rc;
+    if ((rc = ensure_streams(tp))) return rc;
+    const size_t W = ss_stwo_record_words(c);
+    TextParseArgs args{};
+    if ((rc = template_of(ctx, *c, SS_TEXT_JSON, tp.cx, args.tmpl[0]))) return rc;
+    if ((rc = template_of(ctx, *c, SS_TEXT_WIT, tp.cx, args.tmpl[1]))) return rc;
+    args.record_words = (uint32_t)W;
+    auto aligned = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    size_t total = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (!texts[i] || lens[i] > kMaxTextBytes) return set_err(SS_ERR_ARG, "text %zu is null or longer than 32 MiB", i);
+        total += aligned(lens[i]);
+    }
+    const size_t meta = aligned(total + kTextSlack), bytes = meta + n * 17 + 4 + 16;
+    std::vector<uint8_t> host(bytes, 0);
+    uint64_t *offs = (uint64_t *)(host.data() + meta);
+    uint32_t *l32 = (uint32_t *)(offs + n);
+    uint32_t *wb = l32 + n;
+    uint8_t *f8 = (uint8_t *)(wb + n + 1);
+    size_t o = 0;
+    uint32_t n_windows = 0;
+    for (size_t i = 0; i < n; i++) {
+        offs[i] = o;
+        memcpy(host.data() + o, texts[i], lens[i]);
+        o += aligned(lens[i]);
+        l32[i] = (uint32_t)lens[i];
+        wb[i] = n_windows;
+        n_windows += (uint32_t)((lens[i] + 1023) >> 10);
+        f8[i] = fmt == SS_TEXT_WIT;
+    }
+    wb[n] = n_windows;
+    GrowBuf text, rec, out, win;
+    auto done = [&](int code) { release(text); release(rec); release(out); release(win); return code; };
+    if ((rc = grow(text, bytes, false)) || (rc = grow(rec, n * W * 4, false)) || (rc = grow(out, n * 4, false)) ||
+        (rc = grow(win, (size_t)(n_windows + 4) * (4 + sizeof(WinSum) + sizeof(WinIn)), false)))
+        return done(rc);
+    const size_t wcap = ((size_t)n_windows + 4) & ~(size_t)3;
+    if (hipMemcpy(text.p, host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(rec.p, 0xee, n * W * 4) != hipSuccess)
+        return done(set_err(SS_ERR_HIP, "upload failed"));
+    const uint8_t *dev = (const uint8_t *)text.p;
+    args.texts = dev;
+    args.offs = (const uint64_t *)(dev + meta);
+    args.lens = (const uint32_t *)(args.offs + n);
+    args.win_base = args.lens + n;
+    args.fmt = (const uint8_t *)(args.win_base + n + 1);
+    args.win_text = (uint32_t *)win.p;
+    args.win_sum = (WinSum *)(args.win_text + wcap);
+    args.win_in = (WinIn *)(args.win_sum + wcap);
+    args.records = (uint32_t *)rec.p;
+    args.outcome = (uint32_t *)out.p;
+    args.n = (uint32_t)n;
+    args.n_windows = n_windows;
+    launch_text_parse(args, tp.cx);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(tp.cx) != hipSuccess ||
+        hipMemcpy(records_host, rec.p, n * W * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(outcome_host, out.p, n * 4, hipMemcpyDeviceToHost) != hipSuccess)
+        return done(set_err(SS_ERR_HIP, "GPU reader failed: %s", hipGetErrorString(hipGetLastError())));
+    return done(SS_OK);
+}
+
+}  // namespace ss

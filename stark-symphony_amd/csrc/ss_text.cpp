@@ -1,0 +1,389 @@
+// Canonical proof texts and their templates (see ss_text.h).  Host code, no HIP.
+#include "ss_text.h"
+
+#include <cstdio>
+#include <cstring>
+
+#include "ss_layout.h"
+
+namespace ss {
+namespace {
+
+// word offsets of a record's sections (include/ss_verify.h)
+struct Rec {
+    uint32_t N, L, Q, K, head, qstride, fbase, tbase, words;
+    uint32_t foff[kMaxList + 1];
+    explicit Rec(const ss_stwo_cfg &c) : N(c.n_cols), L(c.lde_log), Q(c.n_queries), K(c.n_layers)
+    {
+        head = 24 + 4 * N + 64 + 8 * (K + 1) + 4 + 2;
+        qstride = N + kCp + 16 * L;
+        fbase = head + Q * qstride;
+        uint32_t o = 0;
+        for (uint32_t l = 0; l <= K; l++) { foff[l] = o; o += Q * (4 + 8 * (L - 1 - l)); }
+        tbase = fbase + o;
+        words = tbase + (K + 3) * Q;
+    }
+    uint32_t oods_trace() const { return 24; }
+    uint32_t oods_cp() const { return 24 + 4 * N; }
+    uint32_t fri_root(uint32_t l) const { return 24 + 4 * N + 64 + 8 * l; }
+    uint32_t last() const { return fri_root(K + 1); }
+    uint32_t nonce() const { return last() + 4; }
+    uint32_t trace_vals(uint32_t q) const { return head + q * qstride; }
+    uint32_t cp_vals(uint32_t q) const { return trace_vals(q) + N; }
+    uint32_t trace_path(uint32_t q) const { return cp_vals(q) + kCp; }
+    uint32_t cp_path(uint32_t q) const { return trace_path(q) + 8 * L; }
+    uint32_t fri_wit(uint32_t l, uint32_t q) const { return fbase + foff[l] + q * (4 + 8 * (L - 1 - l)); }
+};
+
+bool pow_bits_of(uint64_t target, uint32_t &bits)
+{
+    if (target == ~(uint64_t)0) { bits = 0; return true; }
+    for (uint32_t b = 1; b <= 63; b++)
+        if (target == (((uint64_t)1 << (64 - b)) - 1)) { bits = b; return true; }
+    return false;  // (64 bits: target 0, which `v < 0` never meets; no config of the verifier's)
+}
+
+// The writers are templates over a sink: TextSink prints the record's numbers, SlotSink prints zeros and
+// notes where each number would go.  One description of each format serves both.
+struct TextSink {
+    std::string &out;
+    const uint32_t *rec;
+    void lit(const char *s) { out += s; }
+    void dec(uint64_t v)
+    {
+        char buf[24];
+        int n = 0;
+        do { buf[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+        while (n) out.push_back(buf[--n]);
+    }
+    void u32(uint32_t w) { dec(rec[w]); }
+    void byte(uint32_t w, uint32_t k) { dec((rec[w] >> (8 * (3 - k))) & 255); }  // byte k (0..3, big endian) of word w
+    void u64(uint32_t w) { dec(((uint64_t)rec[w] << 32) | rec[w + 1]); }
+    void hex256(uint32_t w)
+    {
+        static const char *d = "0123456789abcdef";
+        out += "0x";
+        for (uint32_t j = 0; j < 8; j++)
+            for (int s = 28; s >= 0; s -= 4) out.push_back(d[(rec[w + j] >> s) & 15]);
+    }
+    void cst(uint32_t v) { dec(v); }
+};
+
+struct SlotSink {
+    std::string &out;
+    std::vector<TextSlot> &slots;
+    std::vector<uint32_t> &at;  // byte offset of every number in `out`
+    void lit(const char *s) { out += s; }
+    void num(uint32_t dst, uint32_t kind, const char *sample)
+    {
+        at.push_back((uint32_t)out.size());
+        slots.push_back({dst, kind});
+        out += sample;
+    }
+    void u32(uint32_t w) { num(w, kSlotU32, "0"); }
+    void byte(uint32_t w, uint32_t k) { num(4 * w + 3 - k, kSlotByte, "0"); }  // little-endian byte address of the record
+    void u64(uint32_t w) { num(w, kSlotU64, "0"); }
+    void hex256(uint32_t w) { num(w, kSlotHex256, "0x0000000000000000000000000000000000000000000000000000000000000000"); }
+    void cst(uint32_t v) { num(v, kSlotConst, "0"); }
+};
+
+// ------------------------------------------------------------------------------ proof.json (format C)
+// formats.stwo_to_json: the member order of tests/data/proof.json.
+template <class S>
+void json_text(const ss_stwo_cfg &cfg, uint32_t pow_bits, TextStyle style, S &s)
+{
+    const Rec m(cfg);
+    const char *cm = style == kStylePython ? ", " : ",", *co = style == kStylePython ? ": " : ":";
+    auto key = [&](const char *k) { s.lit("\""); s.lit(k); s.lit("\""); s.lit(co); };
+    auto hash_bytes = [&](uint32_t w) {  // a hash as a list of its 32 byte values
+        s.lit("[");
+        for (uint32_t k = 0; k < 32; k++) { if (k) s.lit(cm); s.byte(w + k / 4, k % 4); }
+        s.lit("]");
+    };
+    auto qm31 = [&](uint32_t w) {
+        s.lit("[["); s.u32(w); s.lit(cm); s.u32(w + 1); s.lit("]"); s.lit(cm);
+        s.lit("["); s.u32(w + 2); s.lit(cm); s.u32(w + 3); s.lit("]]");
+    };
+    auto hash_witness = [&](auto path_of, uint32_t len) {  // concatenated over the queries
+        key("hash_witness"); s.lit("[");
+        for (uint32_t q = 0, first = 1; q < m.Q; q++)
+            for (uint32_t l = 0; l < len; l++, first = 0) { if (!first) s.lit(cm); hash_bytes(path_of(q) + 8 * l); }
+        s.lit("]"); s.lit(cm); key("column_witness"); s.lit("[]");
+    };
+    s.lit("{"); key("config"); s.lit("{"); key("pow_bits"); s.cst(pow_bits); s.lit(cm); key("fri_config"); s.lit("{");
+    key("log_blowup_factor"); s.cst(cfg.lde_log - cfg.trace_log); s.lit(cm);
+    key("log_last_layer_degree_bound"); s.cst(0); s.lit(cm); key("n_queries"); s.cst(m.Q); s.lit("}");
+    if (cfg.hash == SS_HASH_BLAKE2S) { s.lit(cm); key("hash"); s.lit("\"blake2s\""); }  // extension key; the reference has none
+    s.lit("}"); s.lit(cm);
+    key("commitments"); s.lit("[");
+    for (uint32_t k = 0; k < 3; k++) { if (k) s.lit(cm); hash_bytes(8 * k); }
+    s.lit("]"); s.lit(cm);
+    key("sampled_values"); s.lit("[[]"); s.lit(cm); s.lit("[");
+    for (uint32_t k = 0; k < m.N; k++) { if (k) s.lit(cm); s.lit("["); qm31(m.oods_trace() + 4 * k); s.lit("]"); }
+    s.lit("]"); s.lit(cm); s.lit("[");
+    for (uint32_t k = 0; k < kCp; k++) { if (k) s.lit(cm); s.lit("["); qm31(m.oods_cp() + 4 * k); s.lit("]"); }
+    s.lit("]]"); s.lit(cm);
+    key("decommitments"); s.lit("[{"); key("hash_witness"); s.lit("[]"); s.lit(cm); key("column_witness"); s.lit("[]}"); s.lit(cm);
+    s.lit("{"); hash_witness([&](uint32_t q) { return m.trace_path(q); }, m.L); s.lit("}"); s.lit(cm);
+    s.lit("{"); hash_witness([&](uint32_t q) { return m.cp_path(q); }, m.L); s.lit("}]"); s.lit(cm);
+    key("queried_values"); s.lit("[[]"); s.lit(cm); s.lit("[");
+    for (uint32_t q = 0; q < m.Q; q++)
+        for (uint32_t k = 0; k < m.N; k++) { if (q | k) s.lit(cm); s.u32(m.trace_vals(q) + k); }
+    s.lit("]"); s.lit(cm); s.lit("[");
+    for (uint32_t q = 0; q < m.Q; q++)
+        for (uint32_t k = 0; k < kCp; k++) { if (q | k) s.lit(cm); s.u32(m.cp_vals(q) + k); }
+    s.lit("]]"); s.lit(cm);
+    key("proof_of_work"); s.u64(m.nonce()); s.lit(cm);
+    auto layer = [&](uint32_t l) {
+        s.lit("{"); key("fri_witness"); s.lit("[");
+        for (uint32_t q = 0; q < m.Q; q++) { if (q) s.lit(cm); qm31(m.fri_wit(l, q)); }
+        s.lit("]"); s.lit(cm); key("decommitment"); s.lit("{");
+        hash_witness([&](uint32_t q) { return m.fri_wit(l, q) + 4; }, m.L - 1 - l);
+        s.lit("}"); s.lit(cm); key("commitment"); hash_bytes(m.fri_root(l)); s.lit("}");
+    };
+    key("fri_proof"); s.lit("{"); key("first_layer"); layer(0); s.lit(cm); key("inner_layers"); s.lit("[");
+    for (uint32_t l = 1; l <= m.K; l++) { if (l > 1) s.lit(cm); layer(l); }
+    s.lit("]"); s.lit(cm); key("last_layer_poly"); s.lit("{"); key("coeffs"); s.lit("["); qm31(m.last()); s.lit("]"); s.lit(cm);
+    key("log_size"); s.cst(0); s.lit("}}}");
+}
+
+// -------------------------------------------------------------------------------- proof.wit (format D)
+// formats.stwo_to_wit = stwo-verifier/scripts/generate_wit.py:106-245, printed by json.dumps(indent=4).
+template <class S>
+void wit_text(const ss_stwo_cfg &cfg, S &s)
+{
+    const Rec m(cfg);
+    auto qm31 = [&](uint32_t w) {
+        s.lit("(("); s.u32(w); s.lit(", "); s.u32(w + 1); s.lit("), ("); s.u32(w + 2); s.lit(", "); s.u32(w + 3); s.lit("))");
+    };
+    auto lst = [&](uint32_t w, uint32_t len) {
+        s.lit("list![");
+        for (uint32_t l = 0; l < len; l++) { if (l) s.lit(", "); s.hex256(w + 8 * l); }
+        s.lit("]");
+    };
+    const char *QM = "((u32, u32), (u32, u32))", *MP = "List<u256, ";  // + 32 + ">"
+    auto mp = [&]() { s.lit(MP); s.cst(32); s.lit(">"); };
+    auto entry = [&](const char *name) { s.lit("    \""); s.lit(name); s.lit("\": {\n        \"value\": \""); };
+    auto type = [&]() { s.lit("\",\n        \"type\": \""); };
+    auto close = [&](bool last) { s.lit(last ? "\"\n    }\n" : "\"\n    },\n"); };
+    s.lit("{\n");
+    entry("COMMITMENTS");
+    s.lit("("); s.hex256(0); s.lit(", "); s.hex256(8); s.lit(", "); s.hex256(16); s.lit(")");
+    type(); s.lit("(u256, u256, u256)"); close(false);
+    entry("DECOMMITMENTS");
+    s.lit("[");
+    for (uint32_t q = 0; q < m.Q; q++) {
+        if (q) s.lit(", ");
+        s.lit("(([");
+        for (uint32_t k = 0; k < m.N; k++) { if (k) s.lit(", "); s.lit("["); s.u32(m.trace_vals(q) + k); s.lit("]"); }
+        s.lit("], "); lst(m.trace_path(q), m.L); s.lit("), ([");
+        for (uint32_t k = 0; k < kCp; k++) { if (k) s.lit(", "); s.u32(m.cp_vals(q) + k); }
+        s.lit("], "); lst(m.cp_path(q), m.L); s.lit("))");
+    }
+    s.lit("]");
+    type();
+    s.lit("[(([[u32; "); s.cst(1); s.lit("]; "); s.cst(m.N); s.lit("], "); mp(); s.lit("), ([u32; "); s.cst(16); s.lit("], "); mp();
+    s.lit(")); "); s.cst(m.Q); s.lit("]");
+    close(false);
+    entry("OODS_EVALS");
+    s.lit("([");
+    for (uint32_t k = 0; k < m.N; k++) { if (k) s.lit(", "); s.lit("["); qm31(m.oods_trace() + 4 * k); s.lit("]"); }
+    s.lit("], [");
+    for (uint32_t k = 0; k < kCp; k++) { if (k) s.lit(", "); qm31(m.oods_cp() + 4 * k); }
+    s.lit("])");
+    type();
+    s.lit("([["); s.lit(QM); s.lit("; "); s.cst(1); s.lit("]; "); s.cst(m.N); s.lit("], ["); s.lit(QM); s.lit("; "); s.cst(16); s.lit("])");
+    close(false);
+    entry("FRI_COMMITMENTS");
+    s.lit("("); s.hex256(m.fri_root(0)); s.lit(", [");
+    for (uint32_t l = 1; l <= m.K; l++) { if (l > 1) s.lit(", "); s.hex256(m.fri_root(l)); }
+    s.lit("], "); qm31(m.last()); s.lit(")");
+    type();
+    s.lit("(u256, [u256; "); s.cst(m.K); s.lit("], "); s.lit(QM); s.lit(")");
+    close(false);
+    entry("FRI_DECOMMITMENTS");
+    auto fl = [&](uint32_t l) {
+        s.lit("[");
+        for (uint32_t q = 0; q < m.Q; q++) {
+            if (q) s.lit(", ");
+            s.lit("("); qm31(m.fri_wit(l, q)); s.lit(", "); lst(m.fri_wit(l, q) + 4, m.L - 1 - l); s.lit(")");
+        }
+        s.lit("]");
+    };
+    s.lit("("); fl(0); s.lit(", [");
+    for (uint32_t l = 1; l <= m.K; l++) { if (l > 1) s.lit(", "); fl(l); }
+    s.lit("])");
+    type();
+    auto fld = [&]() { s.lit("[("); s.lit(QM); s.lit(", "); mp(); s.lit("); "); s.cst(m.Q); s.lit("]"); };
+    s.lit("("); fld(); s.lit(", ["); fld(); s.lit("; "); s.cst(m.K); s.lit("])");
+    close(false);
+    entry("POW_NONCE");
+    s.u64(m.nonce());
+    type(); s.lit("u64"); close(true);
+    s.lit("}");
+}
+
+bool cfg_writable(const ss_stwo_cfg &c)
+{
+    return c.hash <= SS_HASH_BLAKE2S && stwo_cfg_ok(c.n_cols, c.trace_log, c.lde_log, c.n_queries, c.n_layers, c.mode & 1);
+}
+
+bool uniform_paths(const ss_stwo_cfg &cfg, const uint32_t *rec)
+{
+    const Rec m(cfg);
+    for (uint32_t kind = 0; kind < m.K + 3; kind++) {
+        const uint32_t want = kind < 2 ? m.L : m.L - 1 - (kind - 2);
+        for (uint32_t q = 0; q < m.Q; q++)
+            if (rec[m.tbase + kind * m.Q + q] != want) return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+bool stwo_write_json(const ss_stwo_cfg &cfg, const uint32_t *record, TextStyle style, std::string &out)
+{
+    uint32_t bits;
+    out.clear();
+    if (!cfg_writable(cfg) || !pow_bits_of(cfg.pow_target, bits) || !uniform_paths(cfg, record)) return false;
+    TextSink s{out, record};
+    json_text(cfg, bits, style, s);
+    return true;
+}
+
+bool stwo_write_wit(const ss_stwo_cfg &cfg, const uint32_t *record, std::string &out)
+{
+    out.clear();
+    if (!cfg_writable(cfg) || !uniform_paths(cfg, record)) return false;
+    TextSink s{out, record};
+    wit_text(cfg, s);
+    return true;
+}
+
+TextTemplate TextTemplateHost::view() const
+{
+    TextTemplate t;
+    t.skel = skel.data(); t.skel_len = skel_len;
+    t.slots = slots.data(); t.n_slots = (uint32_t)slots.size();
+    t.record_words = record_words;
+    t.tbase = tbase; t.n_trailer = (uint32_t)trailer.size(); t.trailer = trailer.data();
+    return t;
+}
+
+void stwo_build_template(const ss_stwo_cfg &cfg, int fmt, TextTemplateHost &out)
+{
+    out = TextTemplateHost();
+    uint32_t bits = 0;
+    if (!cfg_writable(cfg) || (fmt != SS_TEXT_JSON && fmt != SS_TEXT_WIT)) return;
+    if (fmt == SS_TEXT_JSON && !pow_bits_of(cfg.pow_target, bits)) return;  // no proof.json can declare this target
+    std::string sample;
+    std::vector<uint32_t> at;
+    SlotSink s{sample, out.slots, at};
+    if (fmt == SS_TEXT_JSON) json_text(cfg, bits, kStyleCompact, s);
+    else wit_text(cfg, s);
+    // the skeleton of the sample text, by the tokenizer itself; its numbers must be exactly the sink's
+    uint32_t run = kRunNone, in_str = 0;
+    size_t k = 0;
+    bool good = true;
+    for (size_t i = 0; i < sample.size() && good; i++) {
+        const uint32_t c = (unsigned char)sample[i];
+        if (txt_is_bad(c)) { good = false; break; }
+        const uint32_t r = scan_byte(c, run, in_str);
+        if (r & 2) {
+            good = k < at.size() && at[k] == i;
+            k++;
+            out.skel.push_back(kSkelMark);
+        }
+        if (r & 1) out.skel.push_back((uint8_t)c);
+    }
+    good = good && k == at.size() && in_str == 0;
+    if (!good) { out = TextTemplateHost(); return; }
+    out.skel_len = (uint32_t)out.skel.size();
+    out.skel.resize(out.skel.size() + kSkelSlack, 0);
+    const Rec m(cfg);
+    out.record_words = m.words;
+    out.tbase = m.tbase;
+    for (uint32_t kind = 0; kind < m.K + 3; kind++)
+        for (uint32_t q = 0; q < m.Q; q++) out.trailer.push_back(kind < 2 ? m.L : m.L - 1 - (kind - 2));
+    out.ok = true;
+}
+
+// ------------------------------------------------------------------------- the fast path, scalar
+namespace {
+
+// number token body[0..n) (alnum run starting with a digit) -> record, by kind; false = not canonical / out of range
+bool place_number(const TextSlot &sl, const unsigned char *body, size_t n, uint32_t *rec)
+{
+    if (sl.kind == kSlotHex256) {
+        if (n != 66 || body[0] != '0' || (body[1] != 'x' && body[1] != 'X')) return false;
+        for (uint32_t j = 0; j < 8; j++) {
+            uint32_t w = 0;
+            for (uint32_t d = 0; d < 8; d++) {
+                const uint32_t c = body[2 + 8 * j + d];
+                uint32_t v;
+                if (c - '0' < 10u) v = c - '0';
+                else if ((c | 0x20) - 'a' < 6u) v = (c | 0x20) - 'a' + 10;
+                else return false;
+                w = (w << 4) | v;
+            }
+            rec[sl.dst + j] = w;
+        }
+        return true;
+    }
+    if (n > 20 || (n > 1 && body[0] == '0')) return false;  // no u64 has more digits; canonical decimals only
+    uint64_t v = 0;
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t d = body[i] - '0';
+        if (d > 9) return false;
+        if (v > (~(uint64_t)0 - d) / 10) return false;  // >= 2^64
+        v = v * 10 + d;
+    }
+    switch (sl.kind) {
+    case kSlotU32:
+        if (v > 0xffffffffull) return false;
+        rec[sl.dst] = (uint32_t)v;
+        return true;
+    case kSlotByte:
+        if (v > 255) return false;
+        reinterpret_cast<uint8_t *>(rec)[sl.dst] = (uint8_t)v;  // records are little-endian words
+        return true;
+    case kSlotU64:
+        rec[sl.dst] = (uint32_t)(v >> 32);
+        rec[sl.dst + 1] = (uint32_t)v;
+        return true;
+    case kSlotConst:
+        return v == sl.dst;
+    }
+    return false;
+}
+
+}  // namespace
+
+bool text_scan_reference(const TextTemplate &t, const char *text, size_t len, uint32_t *rec)
+{
+    if (!t.skel) return false;
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(text);
+    uint32_t run = kRunNone, in_str = 0, sk = 0, tok = 0;
+    for (size_t i = 0; i < len; i++) {
+        const uint32_t c = p[i];
+        if (txt_is_bad(c)) return false;
+        const uint32_t r = scan_byte(c, run, in_str);
+        if (r & 2) {
+            if (sk >= t.skel_len || t.skel[sk] != kSkelMark || tok >= t.n_slots) return false;
+            sk++;
+            size_t e = i;
+            while (e < len && txt_is_alnum(p[e])) e++;
+            if (!place_number(t.slots[tok], p + i, e - i, rec)) return false;
+            tok++;
+        }
+        if (r & 1) {
+            if (sk >= t.skel_len || t.skel[sk] != c) return false;
+            sk++;
+        }
+    }
+    if (sk != t.skel_len || tok != t.n_slots) return false;
+    for (uint32_t i = 0; i < t.n_trailer; i++) rec[t.tbase + i] = t.trailer[i];
+    return true;
+}
+
+}  // namespace ss

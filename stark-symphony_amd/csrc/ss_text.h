@@ -1,0 +1,129 @@
+// Canonical proof texts: writers, and the "template" form of a config's text that lets the GPU turn
+// proof.json / proof.wit bytes into records without a parse tree (csrc/ss_textdev.hip).
+//
+// The reference's callers hand the verifier text (stwo-verifier/scripts/generate_wit.py:106-245 reads the
+// proof.json schema and prints the .wit of :218-243 that `simfony run --witness` consumes,
+// simfony-cli/src/main.rs:163-209).  For one expected config every text an honest producer emits is the
+// same byte string except for its NUMBERS (and, outside JSON strings, its whitespace): the k-th number
+// of the text always lands in the same word of the record.  A template is that text with every number
+// replaced by a marker (the "skeleton") plus, for each marker in order, where the number goes (the
+// "slots").  A text is taken on the fast path only if its skeleton equals the template's byte for byte
+// and every number is written in canonical form and in range; ANY deviation -- other key order, escapes,
+// a float, a leading zero, a byte above 255, another shape -- sends that text to the tree parser of
+// ss_ingest.cpp, which alone decides parsed / other config / malformed.  The fast path never rejects.
+//
+// Tokenizer (identical on host and device; `scan_byte` below is the single definition):
+//   alnum = [0-9A-Za-z_];  ws = space \n \t \r;  anything else is punctuation.
+//   A maximal alnum run that starts with a digit is a NUMBER token (so "0x1f..", "12" are tokens, "u32",
+//   "sha256", "list" are not); one marker byte stands for it in the skeleton.  Every other byte is copied
+//   to the skeleton, except whitespace outside JSON strings (json.loads skips exactly these four bytes
+//   there; inside a string -- e.g. inside the SimplicityHL literal of a .wit value -- whitespace is kept).
+//   A backslash, a control character or a byte >= 0x80 anywhere takes the text off the fast path.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/ss_verify.h"
+
+#ifndef SS_HD
+#ifdef __HIPCC__
+#define SS_HD __host__ __device__
+#else
+#define SS_HD
+#endif
+#endif
+
+namespace ss {
+
+constexpr uint8_t kSkelMark = 0x01;  // stands for a number in a skeleton (control bytes never come from a text)
+
+enum SlotKind : uint32_t {
+    kSlotU32 = 0,    // decimal < 2^32            -> record word `dst`
+    kSlotByte = 1,   // decimal <= 255            -> byte `dst` of the record (hash byte k of word w: 4w + 3 - k % 4)
+    kSlotU64 = 2,    // decimal < 2^64            -> words dst (high), dst + 1 (low)
+    kSlotHex256 = 3, // 0x + exactly 64 hex digits -> words dst .. dst + 7
+    kSlotConst = 4,  // decimal that must equal `dst` (declared parameters, numbers inside type strings)
+};
+
+struct TextSlot {
+    uint32_t dst;
+    uint32_t kind;
+};
+
+// byte classes
+SS_HD inline bool txt_is_digit(uint32_t c) { return c - '0' < 10u; }
+SS_HD inline bool txt_is_alnum(uint32_t c) { return c - '0' < 10u || (c | 0x20) - 'a' < 26u || c == '_'; }
+SS_HD inline bool txt_is_ws(uint32_t c) { return c == ' ' || c == '\n' || c == '\t' || c == '\r'; }
+SS_HD inline bool txt_is_bad(uint32_t c) { return c == '\\' || c >= 0x80 || (c < 0x20 && !txt_is_ws(c)); }
+
+// run state between bytes
+enum : uint32_t { kRunNone = 0, kRunToken = 1, kRunIdent = 2 };
+
+// What one byte does.  Returns a mask: bit 0 = the byte itself goes to the skeleton, bit 1 = a marker goes to the
+// skeleton BEFORE it (a number starts here).  `run` / `in_str` are the states before the byte, updated.
+SS_HD inline uint32_t scan_byte(uint32_t c, uint32_t &run, uint32_t &in_str)
+{
+    if (txt_is_alnum(c)) {
+        uint32_t r = 0;
+        if (run == kRunNone) {
+            run = txt_is_digit(c) ? kRunToken : kRunIdent;
+            if (run == kRunToken) r = 2;
+        }
+        return r | (run == kRunIdent ? 1u : 0u);
+    }
+    run = kRunNone;
+    if (c == '"') { in_str ^= 1; return 1; }
+    return (txt_is_ws(c) && !in_str) ? 0u : 1u;
+}
+
+// A config's template for one text format.  skel is padded with zeros to skel_pad bytes (the device
+// stages 2 KiB windows of it without bounds checks).
+struct TextTemplate {
+    const uint8_t *skel = nullptr;
+    uint32_t skel_len = 0;
+    const TextSlot *slots = nullptr;
+    uint32_t n_slots = 0;
+    uint32_t record_words = 0;
+    uint32_t tbase = 0, n_trailer = 0;  // path_len trailer: words [tbase, tbase + n_trailer), constants below
+    const uint32_t *trailer = nullptr;
+};
+
+constexpr uint32_t kSkelSlack = 4096;  // zero bytes after the skeleton
+
+}  // namespace ss
+
+#include <string>
+#include <vector>
+
+namespace ss {
+
+enum TextStyle : int {
+    kStyleCompact = 0,  // JSON: "," and ":" (what the external stwo prover / serde_json writes: tests/data/proof.json)
+    kStylePython = 1,   // JSON: ", " and ": " (json.dumps default, what formats.stwo_to_json callers get)
+};
+
+// Record -> text, byte for byte what formats.py writes (json.dumps(stwo_to_json(p)) resp. stwo_to_wit(p)).
+// Only records whose Merkle paths all have the config's lengths can be written; returns false otherwise
+// (or for a pow_target that is no 2^(64-b) - 1: proof.json declares pow_bits).
+bool stwo_write_json(const ss_stwo_cfg &cfg, const uint32_t *record, TextStyle style, std::string &out);
+bool stwo_write_wit(const ss_stwo_cfg &cfg, const uint32_t *record, std::string &out);
+
+// Host-side owner of a template.
+struct TextTemplateHost {
+    std::vector<uint8_t> skel;     // skel_len bytes + kSkelSlack zeros
+    uint32_t skel_len = 0;
+    std::vector<TextSlot> slots;
+    std::vector<uint32_t> trailer;
+    uint32_t record_words = 0, tbase = 0;
+    bool ok = false;               // false: no canonical text exists for this config / format (fast path off)
+    TextTemplate view() const;
+};
+// fmt: SS_TEXT_JSON or SS_TEXT_WIT
+void stwo_build_template(const ss_stwo_cfg &cfg, int fmt, TextTemplateHost &out);
+
+// Scalar statement of the fast path (what the device kernel computes, byte by byte): true = `text` is a
+// canonical text of the template and `record` (record_words words) holds its record; false = not on the fast
+// path (record contents unspecified).  Used by the CPU tests and by nothing on the product path.
+bool text_scan_reference(const TextTemplate &t, const char *text, size_t len, uint32_t *record);
+
+}  // namespace ss

@@ -1,0 +1,43 @@
+// Launch interface of the GPU text reader (csrc/ss_textdev.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ss_text.h"
+
+namespace ss {
+
+// what a 1 KiB window of a text says on its own (text_summary_kernel) ...
+struct WinSum {
+    uint32_t flags;   // bit 0 bad byte, 1 quote parity, 2 decided (holds a non-alnum byte), 3-4 run state behind it,
+                      // 5-6 class of its first byte (kRunNone: not alnum)
+    uint32_t fixed;   // low 16: skeleton bytes that do not depend on the incoming states; high 16: numbers that start behind the leading run
+    uint32_t ws;      // whitespace bytes at even (low 16) / odd (high 16) quote parity counted from the window start
+    uint32_t lead;    // length of the leading alnum run (continues whatever run enters the window)
+};
+// ... and what the scan over a text's windows adds (text_scan_kernel)
+struct WinIn {
+    uint32_t skel_pos, tok_pos;  // skeleton bytes / numbers before the window
+    uint32_t state;              // bit 0: inside a JSON string; bits 1-2: run state entering the window
+};
+
+struct TextParseArgs {
+    const uint8_t *texts;      // the chunk's texts, each starting at a 16-byte aligned offset; >= kTextSlack readable bytes behind the last
+    const uint64_t *offs;      // [n] byte offset of text i in `texts`
+    const uint32_t *lens;      // [n] its length
+    const uint32_t *win_base;  // [n + 1] windows (ceil(len / 1024)) of the texts before text i
+    const uint8_t *fmt;        // [n] 0 = tmpl[0] (proof.json), 1 = tmpl[1] (proof.wit)
+    TextTemplate tmpl[2];      // device pointers inside; skel == nullptr: no fast path for that format
+    uint32_t *win_text;        // [n_windows] scratch: the text a window belongs to
+    WinSum *win_sum;           // [n_windows] scratch
+    WinIn *win_in;             // [n_windows] scratch
+    uint32_t *records;         // [n][record_words]
+    uint32_t *outcome;         // [n] 0 = record written on the fast path, 1 = the host reader decides
+    uint32_t record_words;
+    uint32_t n, n_windows;
+};
+
+constexpr size_t kTextSlack = 4096;  // bytes readable behind the last text of a chunk (whole 1 KiB windows + the next)
+
+void launch_text_parse(const TextParseArgs &a, hipStream_t s);
+
+}  // namespace ss

@@ -1,0 +1,410 @@
+// Text -> record on the GPU: the fast path of ss_text.h for gfx950.
+//
+// Replaces, for canonical texts, the host tree parser in front of the verifier (the reference's callers hand
+// over text: stwo-verifier/scripts/generate_wit.py:106-245,218-243; simfony-cli/src/main.rs:163-209).
+//
+// The unit of work is a 1 KiB WINDOW of a text, one wavefront per window, 16 bytes per lane -- a chunk of
+// 64 MiB of text is 65 536 independent waves whatever the number of texts.  The tokenizer of ss_text.h is
+// sequential only through three small states (inside a JSON string? inside which kind of alnum run? how many
+// skeleton bytes / numbers so far?), and each composes associatively, over lanes and over windows alike:
+//   string state   parity of the quotes before (a backslash anywhere takes the text off the fast path, so
+//                  quotes are never escaped): ballot + popcount;
+//   run state      a lane / window that holds any non-alnum byte decides its outgoing state alone; an
+//                  all-alnum one passes on what enters it.  The state entering position i is the outgoing state
+//                  of the nearest decided position below (ballot + count-leading-zeros + one shuffle) or, if
+//                  that is "no run", the class of the first byte behind it;
+//   positions      prefix sums of the skeleton bytes / numbers each position contributes -- which depend on
+//                  the entering states only through the window's leading alnum run and through whether its
+//                  whitespace sits inside a string, so a window can count both cases without knowing them.
+// Three kernels per chunk:
+//   text_summary_kernel  wave = window: WinSum (counts for either string state, leading run, flags);
+//   text_scan_kernel     wave = text:   scans its windows' summaries -> WinIn (entering states and positions),
+//                        checks the totals against the template (skeleton length, number count, string closed);
+//   text_place_kernel    wave = window: replays its bytes with the true states (scan_byte of ss_text.h),
+//                        compares what they contribute to the skeleton with the template's (staged in LDS) and
+//                        converts the numbers that start in the window into the record (digits read from the
+//                        LDS copy of this window and the next).
+// Any mismatch, non-canonical number or out-of-range value sets the text's outcome to 1: it goes to the host
+// reader (ss_ingest.cpp), which alone produces parsed / other-config / malformed.  HBM-bound byte work: no
+// MFMA; coalesced 16-byte loads; the text is read twice (1 KiB windows stay in L2 / MALL between the passes);
+// scattered 1..32-byte stores into each text's own record.
+#include <hip/hip_runtime.h>
+
+#include "ss_text.h"
+#include "ss_textdev.h"
+
+namespace ss {
+
+namespace {
+
+__device__ __forceinline__ uint32_t byte_of(const uint4 &v, uint32_t j)
+{
+    const uint32_t w = j < 8 ? (j < 4 ? v.x : v.y) : (j < 12 ? v.z : v.w);
+    return (w >> (8 * (j & 3))) & 255;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (uint32_t d = 32; d; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+// what a lane's bytes say on their own
+struct LaneLocal {
+    bool bad, det;              // a byte that ends the fast path; a non-alnum byte (the lane decides its outgoing run state)
+    uint32_t qpar, rout, ftype; // quote parity; run state behind the lane (if det); class of the first byte (kRunNone: not alnum)
+};
+
+__device__ __forceinline__ LaneLocal lane_local(const uint4 &cur, uint32_t nvalid)
+{
+    LaneLocal L{false, false, 0, kRunNone, kRunNone};
+    bool in_alnum = false;
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) {
+        const uint32_t c = byte_of(cur, j);
+        if (j < nvalid) {
+            L.bad |= txt_is_bad(c);
+            const bool an = txt_is_alnum(c);
+            const uint32_t cls = txt_is_digit(c) ? kRunToken : kRunIdent;
+            if (j == 0 && an) L.ftype = cls;
+            if (an) { if (!in_alnum) L.rout = cls; }
+            else { L.det = true; L.rout = kRunNone; }
+            in_alnum = an;
+            L.qpar ^= c == '"';
+        }
+    }
+    if (!L.det) L.rout = kRunNone;  // an all-alnum lane has no state of its own
+    return L;
+}
+
+// Run state entering position `lane` of 64 positions (lanes of a window, or windows of a text) given every
+// position's (decided?, outgoing state, class of first byte) and the state entering position 0.
+// All lanes must call it (shuffles).
+__device__ __forceinline__ uint32_t entering_run(uint64_t det_mask, uint32_t rout, uint32_t ftype, uint32_t carry,
+                                                 uint32_t lane)
+{
+    const uint64_t lower = det_mask & ((1ull << lane) - 1);
+    const int j = lower ? 63 - __builtin_clzll(lower) : -1;  // nearest decided position below
+    const uint32_t base = __shfl(rout, j < 0 ? 0 : j);
+    const uint32_t first_after = __shfl(ftype, j + 1 > 63 ? 63 : j + 1);
+    const uint32_t from = j < 0 ? carry : base;
+    // "no run" behind position j: the run, if any, starts with the first byte of position j + 1
+    return from != kRunNone ? from : ((uint32_t)(j + 1) < lane ? first_after : kRunNone);
+}
+// ... and the state behind position 63
+__device__ __forceinline__ uint32_t leaving_run(uint64_t det_mask, uint32_t rout, uint32_t ftype, uint32_t carry)
+{
+    const int j = det_mask ? 63 - __builtin_clzll(det_mask) : -1;
+    const uint32_t base = __shfl(rout, j < 0 ? 0 : j);
+    const uint32_t first_after = __shfl(ftype, j + 1 > 63 ? 63 : j + 1);
+    const uint32_t from = j < 0 ? carry : base;
+    return from != kRunNone ? from : (j + 1 < 64 ? first_after : kRunNone);
+}
+
+// skeleton bytes / numbers the leading alnum run of a window (or lane) contributes, by the run state entering it
+__device__ __forceinline__ void lead_counts(uint32_t run_in, uint32_t ftype, uint32_t lead, uint32_t &emit, uint32_t &tok)
+{
+    emit = tok = 0;
+    if (!lead) return;
+    if (run_in == kRunIdent) emit = lead;
+    else if (run_in == kRunNone) {
+        if (ftype == kRunToken) { emit = 1; tok = 1; }  // one marker
+        else emit = lead;
+    }
+}
+
+}  // namespace
+
+// window -> text
+__global__ void __launch_bounds__(64) text_index_kernel(TextParseArgs a)
+{
+    const uint32_t t = blockIdx.x;
+    if (t >= a.n) return;
+    for (uint32_t w = a.win_base[t] + threadIdx.x; w < a.win_base[t + 1]; w += 64) a.win_text[w] = t;
+}
+
+__global__ void __launch_bounds__(64) text_summary_kernel(TextParseArgs a)
+{
+    const uint32_t gw = blockIdx.x, lane = threadIdx.x;
+    if (gw >= a.n_windows) return;
+    const uint32_t t = a.win_text[gw], w = gw - a.win_base[t], len = a.lens[t];
+    const uint4 *text4 = reinterpret_cast<const uint4 *>(a.texts + a.offs[t]);
+    const uint4 cur = text4[(size_t)w * 64 + lane];
+    const uint32_t pos0 = (w << 10) + lane * 16;
+    const uint32_t nvalid = pos0 >= len ? 0 : (len - pos0 < 16 ? len - pos0 : 16);
+
+    // one pass: the leading alnum run of the lane, and behind it (where the run state is known) what the
+    // bytes contribute; whitespace counted by the quote parity relative to the lane start
+    bool bad = false, det = false, in_lead = true;
+    uint32_t qpar = 0, run = kRunNone, ftype = kRunNone, lead = 0, fixed = 0, toks = 0, ws0 = 0, ws1 = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) {
+        const uint32_t c = byte_of(cur, j);
+        if (j < nvalid) {
+            bad |= txt_is_bad(c);
+            const bool an = txt_is_alnum(c);
+            const uint32_t cls = txt_is_digit(c) ? kRunToken : kRunIdent;
+            if (j == 0 && an) ftype = cls;
+            if (in_lead && an) { lead++; }
+            else {
+                in_lead = false;
+                if (an) {
+                    if (run == kRunNone) { run = cls; if (cls == kRunToken) { fixed++; toks++; } }
+                    if (run == kRunIdent) fixed++;
+                } else {
+                    run = kRunNone;
+                    det = true;
+                    if (c == '"') { qpar ^= 1; fixed++; }
+                    else if (txt_is_ws(c)) { if (qpar) ws1++; else ws0++; }
+                    else fixed++;
+                }
+            }
+        }
+    }
+    const uint32_t rout = det ? run : kRunNone;
+    const uint64_t det_mask = __ballot(det), q_mask = __ballot(qpar);
+    const uint64_t below = (1ull << lane) - 1;
+    // lanes behind the window's first decided lane know the run state that enters them; the leading runs of the
+    // others form the window's leading run
+    const uint32_t run_in = entering_run(det_mask, rout, ftype, kRunNone, lane);
+    uint32_t lead_outer = 0;
+    if ((det_mask & below) == 0) lead_outer = lead;
+    else {
+        uint32_t e, k;
+        lead_counts(run_in, ftype, lead, e, k);
+        fixed += e;
+        toks += k;
+    }
+    const uint32_t lpar = (uint32_t)__popcll(q_mask & below) & 1;  // quote parity at the lane start, from the window start
+    const uint32_t ws_even = lpar ? ws1 : ws0, ws_odd = lpar ? ws0 : ws1;
+    const uint32_t s_fixed = wave_sum(fixed | (toks << 16));
+    const uint32_t s_ws = wave_sum(ws_even | (ws_odd << 16));
+    const uint32_t s_lead = wave_sum(lead_outer);
+    const uint32_t w_rout = leaving_run(det_mask, rout, ftype, kRunNone);
+    const uint32_t w_ftype = __shfl(ftype, 0);
+    const bool any_bad = __ballot(bad) != 0;
+    if (lane == 0) {
+        WinSum s;
+        s.flags = (any_bad ? 1u : 0u) | (((uint32_t)__popcll(q_mask) & 1) << 1) | ((det_mask ? 1u : 0u) << 2) | (w_rout << 3) |
+                  (w_ftype << 5);
+        s.fixed = s_fixed;
+        s.ws = s_ws;
+        s.lead = s_lead;
+        a.win_sum[gw] = s;
+    }
+}
+
+__global__ void __launch_bounds__(64) text_scan_kernel(TextParseArgs a)
+{
+    const uint32_t t = blockIdx.x, lane = threadIdx.x;
+    if (t >= a.n) return;
+    const uint32_t w0 = a.win_base[t], nwin = a.win_base[t + 1] - w0;
+    const bool wit = a.fmt[t] & 1;
+    const uint8_t *skel = wit ? a.tmpl[1].skel : a.tmpl[0].skel;
+    const uint32_t skel_len = wit ? a.tmpl[1].skel_len : a.tmpl[0].skel_len;
+    const uint32_t n_slots = wit ? a.tmpl[1].n_slots : a.tmpl[0].n_slots;
+    uint32_t carry_run = kRunNone, carry_str = 0, skel_pos = 0, tok_pos = 0;
+    bool bad = skel == nullptr || nwin == 0;
+    const uint64_t below = (1ull << lane) - 1;
+    for (uint32_t g = 0; g < nwin && !bad; g += 64) {
+        const uint32_t w = g + lane;
+        WinSum s{0, 0, 0, 0};
+        if (w < nwin) s = a.win_sum[w0 + w];
+        const bool det = (s.flags >> 2) & 1;
+        const uint32_t rout = (s.flags >> 3) & 3, ftype = (s.flags >> 5) & 3;
+        const uint64_t det_mask = __ballot(det), q_mask = __ballot((s.flags >> 1) & 1);
+        const uint32_t in_str = carry_str ^ ((uint32_t)__popcll(q_mask & below) & 1);
+        const uint32_t run_in = entering_run(det_mask, rout, ftype, carry_run, lane);
+        carry_run = leaving_run(det_mask, rout, ftype, carry_run);
+        carry_str ^= (uint32_t)__popcll(q_mask) & 1;
+        uint32_t e, k;
+        lead_counts(run_in, ftype, s.lead, e, k);
+        // whitespace is kept where the string state (entering state ^ local parity) is 1
+        e += (s.fixed & 0xffff) + (in_str ? (s.ws & 0xffff) : (s.ws >> 16));
+        k += s.fixed >> 16;
+        uint32_t ie = e, ik = k;
+#pragma unroll
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t ye = __shfl_up(ie, d), yk = __shfl_up(ik, d);
+            if (lane >= d) { ie += ye; ik += yk; }
+        }
+        if (w < nwin) {
+            WinIn in;
+            in.skel_pos = skel_pos + ie - e;
+            in.tok_pos = tok_pos + ik - k;
+            in.state = in_str | (run_in << 1);
+            a.win_in[w0 + w] = in;
+        }
+        skel_pos += __shfl(ie, 63);
+        tok_pos += __shfl(ik, 63);
+        bad = __ballot(s.flags & 1) != 0 || skel_pos > skel_len || tok_pos > n_slots;
+    }
+    const bool good = !bad && skel_pos == skel_len && tok_pos == n_slots && carry_str == 0;
+    if (good) {  // the path-length trailer of a canonical text is the config's
+        const TextTemplate &T = wit ? a.tmpl[1] : a.tmpl[0];
+        uint32_t *rec = a.records + (size_t)t * a.record_words;
+        for (uint32_t i = lane; i < T.n_trailer; i += 64) rec[T.tbase + i] = T.trailer[i];
+    }
+    if (lane == 0) a.outcome[t] = good ? 0u : 1u;
+}
+
+__global__ void __launch_bounds__(64) text_place_kernel(TextParseArgs a)
+{
+    __shared__ uint4 s_text4[2 * 64];   // this window and the next
+    __shared__ uint4 s_skel4[2 * 64];   // 2 KiB of the template's skeleton from skel_pos & ~15
+    __shared__ uint2 s_slot[8 * 64];    // the slots of the numbers that start in this window
+    const uint8_t *s_text = reinterpret_cast<const uint8_t *>(s_text4);
+    const uint8_t *s_skel = reinterpret_cast<const uint8_t *>(s_skel4);
+
+    const uint32_t gw = blockIdx.x, lane = threadIdx.x;
+    if (gw >= a.n_windows) return;
+    const uint32_t t = a.win_text[gw];
+    if (a.outcome[t] != 0) return;  // the scan (or another window) has already sent this text to the host reader
+    const uint32_t w = gw - a.win_base[t], nwin = a.win_base[t + 1] - a.win_base[t], len = a.lens[t];
+    const bool wit = a.fmt[t] & 1;
+    const uint8_t *skel = wit ? a.tmpl[1].skel : a.tmpl[0].skel;
+    const TextSlot *slots = wit ? a.tmpl[1].slots : a.tmpl[0].slots;
+    const uint32_t n_slots = wit ? a.tmpl[1].n_slots : a.tmpl[0].n_slots;
+    uint32_t *rec = a.records + (size_t)t * a.record_words;
+    const uint4 *text4 = reinterpret_cast<const uint4 *>(a.texts + a.offs[t]);  // 16-byte aligned by the host
+    const WinIn in = a.win_in[gw];
+
+    const uint4 cur = text4[(size_t)w * 64 + lane];
+    uint4 nxt = make_uint4(0, 0, 0, 0);
+    if (w + 1 < nwin) nxt = text4[(size_t)(w + 1) * 64 + lane];
+    const uint32_t win0 = w << 10, pos0 = win0 + lane * 16;
+    const uint32_t nvalid = pos0 >= len ? 0 : (len - pos0 < 16 ? len - pos0 : 16);
+    s_text4[lane] = cur;
+    s_text4[64 + lane] = nxt;
+    // the template's skeleton from where this window starts in it (zero padded behind its end)
+    const uint32_t sk_base = in.skel_pos & ~15u;
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(skel + sk_base);
+        s_skel4[lane] = src[lane];
+        s_skel4[64 + lane] = src[64 + lane];
+    }
+
+    // ---- the states entering this lane
+    const LaneLocal L = lane_local(cur, nvalid);
+    const uint64_t det_mask = __ballot(L.det), q_mask = __ballot(L.qpar);
+    const uint64_t below = (1ull << lane) - 1;
+    const uint32_t in_str = (in.state & 1) ^ ((uint32_t)__popcll(q_mask & below) & 1);
+    const uint32_t run = entering_run(det_mask, L.rout, L.ftype, in.state >> 1, lane);
+
+    // ---- replay with the true states
+    uint32_t emit_mask = 0, mark_mask = 0;
+    {
+        uint32_t r_run = run, r_str = in_str;
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) {
+            if (j < nvalid) {
+                const uint32_t r = scan_byte(byte_of(cur, j), r_run, r_str);
+                emit_mask |= (r & 1) << j;
+                mark_mask |= (r >> 1) << j;
+            }
+        }
+    }
+    // ---- positions inside the window
+    const uint32_t n_mark = __popc(mark_mask);
+    const uint32_t mine = (__popc(emit_mask) + n_mark) | (n_mark << 16);
+    uint32_t incl = mine;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(incl, d);
+        if (lane >= d) incl += y;
+    }
+    const uint32_t excl = incl - mine, n_tok = __shfl(incl, 63) >> 16;
+    const uint32_t sk0 = in.skel_pos + (excl & 0xffff), tk0 = excl >> 16;  // tk0: index inside the window
+    bool mism = in.tok_pos + n_tok > n_slots;
+    if (!mism)
+        for (uint32_t i = lane; i < n_tok; i += 64) {
+            const TextSlot sl = slots[in.tok_pos + i];
+            s_slot[i] = make_uint2(sl.dst, sl.kind);
+        }
+    __syncthreads();
+
+    // ---- the skeleton this lane contributes against the template's
+    {
+        uint32_t o = sk0 - sk_base;
+#pragma unroll
+        for (uint32_t j = 0; j < 16; j++) {
+            if ((mark_mask >> j) & 1) mism |= s_skel[o++] != kSkelMark;
+            if ((emit_mask >> j) & 1) mism |= s_skel[o++] != byte_of(cur, j);
+        }
+    }
+    // ---- the numbers that start in this lane's bytes
+    {
+        const uint32_t lim = len - win0 < 2048 ? len - win0 : 2048;  // text bytes present in s_text
+        uint32_t k = tk0, mm = mark_mask;
+        while (mm && !mism) {
+            const uint32_t j = __ffs(mm) - 1;
+            mm &= mm - 1;
+            const uint2 sl = s_slot[k++];
+            const uint32_t dst = sl.x, kind = sl.y;
+            const uint32_t p = lane * 16 + j;
+            uint32_t n = 0;
+            while (n < 67 && p + n < lim && txt_is_alnum(s_text[p + n])) n++;
+            if (kind == kSlotHex256) {
+                bool ok = n == 66 && s_text[p] == '0' && (s_text[p + 1] | 0x20) == 'x';
+                if (ok) {
+                    for (uint32_t wd = 0; wd < 8; wd++) {
+                        uint32_t v = 0;
+#pragma unroll
+                        for (uint32_t d = 0; d < 8; d++) {
+                            const uint32_t c = s_text[p + 2 + 8 * wd + d];
+                            uint32_t h;
+                            if (c - '0' < 10u) h = c - '0';
+                            else if ((c | 0x20) - 'a' < 6u) h = (c | 0x20) - 'a' + 10;
+                            else { h = 0; ok = false; }
+                            v = (v << 4) | h;
+                        }
+                        rec[dst + wd] = v;
+                    }
+                }
+                mism |= !ok;
+                continue;
+            }
+            // canonical decimal: digits only, no leading zero, at most 20 digits, below 2^64
+            bool ok = n >= 1 && n <= 20 && !(n > 1 && s_text[p] == '0');
+            uint64_t v = 0;
+            for (uint32_t i = 0; i < n && ok; i++) {
+                const uint32_t d = s_text[p + i] - '0';
+                ok = d <= 9 && v <= (~(uint64_t)0 - d) / 10;
+                v = v * 10 + d;
+            }
+            if (ok) {
+                switch (kind) {
+                case kSlotU32:
+                    ok = v <= 0xffffffffull;
+                    if (ok) rec[dst] = (uint32_t)v;
+                    break;
+                case kSlotByte:
+                    ok = v <= 255;
+                    if (ok) reinterpret_cast<uint8_t *>(rec)[dst] = (uint8_t)v;
+                    break;
+                case kSlotU64:
+                    rec[dst] = (uint32_t)(v >> 32);
+                    rec[dst + 1] = (uint32_t)v;
+                    break;
+                default:  // kSlotConst
+                    ok = v == dst;
+                    break;
+                }
+            }
+            mism |= !ok;
+        }
+    }
+    if (mism) a.outcome[t] = 1;
+}
+
+void launch_text_parse(const TextParseArgs &a, hipStream_t s)
+{
+    if (!a.n) return;
+    hipLaunchKernelGGL(text_index_kernel, dim3(a.n), dim3(64), 0, s, a);
+    if (a.n_windows) hipLaunchKernelGGL(text_summary_kernel, dim3(a.n_windows), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(text_scan_kernel, dim3(a.n), dim3(64), 0, s, a);
+    if (a.n_windows) hipLaunchKernelGGL(text_place_kernel, dim3(a.n_windows), dim3(64), 0, s, a);
+}
+
+}  // namespace ss

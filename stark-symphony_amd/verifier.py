@@ -564,7 +564,7 @@ class Verifier:
         status = np.full(n, 0xFFFFFFFF, dtype=np.uint32)
         stats = B.IngestStats()
         if n == 0:
-            return status, {k: 0 for k, _ in B.IngestStats._fields_ if k != "reserved"}
+            return status, {k: 0 for k, _ in B.IngestStats._fields_}
         if items and isinstance(items[0], (bytes, bytearray, memoryview)):
             bufs = [bytes(t) for t in items]
             arr = (C.c_char_p * n)(*bufs)
@@ -573,7 +573,7 @@ class Verifier:
         else:
             arr = (C.c_char_p * n)(*[os.fsencode(p) for p in items])
             B.check(fn(self.ctx, *head_args, n, arr, fmt, status.ctypes.data, C.byref(stats)))
-        return status, {k: getattr(stats, k) for k, _ in B.IngestStats._fields_ if k != "reserved"}
+        return status, {k: getattr(stats, k) for k, _ in B.IngestStats._fields_}
 
     def verify_stwo_texts(self, cfg: StwoConfig, texts: Sequence[bytes], mode: int = MODE_FIXTURE,
                           fmt: int = B.TEXT_AUTO):
@@ -583,6 +583,21 @@ class Verifier:
         STATUS_MALFORMED (ss_stwo_verify_texts)."""
         cs = stwo_cfg_struct(cfg, mode, self.stwo_flags)
         return self._ingest(B.lib().ss_stwo_verify_texts, (C.byref(cs),), list(texts), fmt)
+
+    def read_stwo_texts(self, cfg: StwoConfig, texts: Sequence[bytes], fmt: int, mode: int = MODE_FIXTURE):
+        """The GPU reader alone (ss_stwo_read_texts): -> (records uint32[n, W], outcome uint32[n]) with
+        outcome 0 = canonical text, record written by the GPU; 1 = left to the host reader."""
+        cs = stwo_cfg_struct(cfg, mode, self.stwo_flags)
+        n = len(texts)
+        W = B.lib().ss_stwo_record_words(C.byref(cs))
+        recs = np.zeros((n, W), dtype=np.uint32)
+        outcome = np.full(n, 0xFFFFFFFF, dtype=np.uint32)
+        bufs = [bytes(t) for t in texts]
+        arr = (C.c_char_p * n)(*bufs)
+        lens = (C.c_size_t * n)(*[len(b) for b in bufs])
+        B.check(B.lib().ss_stwo_read_texts(self.ctx, C.byref(cs), n, arr, lens, fmt, recs.ctypes.data,
+                                           outcome.ctypes.data))
+        return recs, outcome
 
     def verify_stwo_files(self, cfg: StwoConfig, paths: Sequence[str], mode: int = MODE_FIXTURE,
                           fmt: int = B.TEXT_AUTO):

@@ -1,0 +1,196 @@
+"""The GPU text reader (csrc/ss_textdev.hip) against the scalar rule, the host reader and formats.py.
+
+Third leg of the differential of tests/test_ingest.py / tests/test_text_fastpath.py: for every text, the
+kernel's outcome equals `ss_stwo_text_is_canonical`, and where it is 0 the record it wrote equals the host
+reader's (and therefore formats.py's).  Then the whole entry point: ss_stwo_verify_texts / _files on
+canonical texts, non-canonical texts, other shapes and garbage in one batch gives the status words of the
+record path + oracle, whatever the chunking."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import stark_symphony_amd as ss
+from stark_symphony_amd import binding, formats, records, verifier
+from oracle import oracle as O
+
+from conftest import GOLDEN
+from test_ingest import FORMATS, _text_mutant
+from test_text_fastpath import _number_mutant, canonical, write_text
+
+pytestmark = pytest.mark.gpu
+JSON, WIT = binding.TEXT_JSON, binding.TEXT_WIT
+SEED = 0x5EED2025
+
+
+@pytest.fixture(scope="module")
+def ver():
+    return verifier.Verifier(0)
+
+
+def _agree(ver, cfg, texts, fmt):
+    """GPU outcome == scalar rule for every text; GPU record == scalar rule's record where taken."""
+    recs, outcome = ver.read_stwo_texts(cfg, texts, fmt)
+    taken = 0
+    for i, t in enumerate(texts):
+        want, rec = canonical(cfg, t, fmt)
+        assert (outcome[i] == 0) == want, (i, int(outcome[i]), want, t[:160])
+        if want:
+            assert np.array_equal(recs[i], rec), (i, np.nonzero(recs[i] != rec)[0][:8])
+            taken += 1
+    return taken
+
+
+@pytest.mark.parametrize("name,cfg", [("stwo_proof", ss.PRODUCTION_CONFIG), ("stwo_proof_test", ss.TESTING_CONFIG)])
+def test_reference_files_are_read_by_the_gpu(ver, name, cfg):
+    j = open(os.path.join(GOLDEN, name + ".json"), "rb").read()
+    w = open(os.path.join(FORMATS, name + ".wit"), "rb").read()
+    want = verifier.parse_stwo_text(cfg, j)[1]
+    for text, fmt in ((j, JSON), (w, WIT), (json.dumps(json.loads(j)).encode(), JSON),
+                      (json.dumps(json.loads(j), indent=1).encode(), JSON)):
+        recs, outcome = ver.read_stwo_texts(cfg, [text, text.rstrip()[:-1], text], fmt)
+        assert outcome.tolist() == [0, 1, 0]
+        assert np.array_equal(recs[0], want) and np.array_equal(recs[2], want)
+    other = ss.TESTING_CONFIG if cfg is ss.PRODUCTION_CONFIG else ss.PRODUCTION_CONFIG
+    assert ver.read_stwo_texts(other, [j], JSON)[1].tolist() == [1]
+    assert ver.read_stwo_texts(cfg, [j], WIT)[1].tolist() == [1] and ver.read_stwo_texts(cfg, [w], JSON)[1].tolist() == [1]
+
+
+@pytest.mark.parametrize("npz", ["stwo_trace16.npz", "stwo_wide256.npz", "stwo_trace20.npz", "stwo_trace16_blake2s.npz"])
+def test_prover_made_proofs_are_read_by_the_gpu(ver, npz):
+    """Texts of every size class (a 2^20-row proof is 0.8 MB of JSON: ~780 windows per wave), all styles."""
+    p = records.load_stwo_npz(os.path.join(GOLDEN, npz))[0]
+    rec = verifier.stwo_record(p)
+    for text, fmt in ((write_text(p.cfg, rec, JSON, 0), JSON), (write_text(p.cfg, rec, JSON, 1), JSON),
+                      (write_text(p.cfg, rec, WIT), WIT)):
+        recs, outcome = ver.read_stwo_texts(p.cfg, [text] * 3, fmt)
+        assert outcome.tolist() == [0, 0, 0] and all(np.array_equal(r, rec) for r in recs)
+
+
+@pytest.mark.parametrize("kind", ["json", "wit"])
+def test_gpu_reader_equals_the_scalar_rule_on_mutants(ver, kind):
+    """Byte-level and number-level mutants of the reference's small proof and of its production proof
+    (texts of every length, cut at every position relative to the 1 KiB windows and 16-byte lanes)."""
+    fmt = JSON if kind == "json" else WIT
+    rnd = random.Random(SEED + len(kind))
+    for name, cfg, n in (("stwo_proof_test", ss.TESTING_CONFIG, 4000), ("stwo_proof", ss.PRODUCTION_CONFIG, 600)):
+        path = os.path.join(GOLDEN, name + ".json") if kind == "json" else os.path.join(FORMATS, name + ".wit")
+        base = open(path, "rb").read()
+        texts = [base]
+        for i in range(n):
+            t = _text_mutant(rnd, base) if i % 3 == 0 else _number_mutant(rnd, base)
+            if i % 5 == 0:
+                t = _number_mutant(rnd, t)
+            if i % 11 == 0:  # shift everything against the window grid
+                t = b" " * rnd.randrange(1, 40) + t
+            texts.append(t)
+        texts += [b"", b"{", b"0", b"\x00" * 100, b"1" * 5000, b"a" * 3000, b'"' * 2049, b"[" * 1024 + b"1"]
+        taken = _agree(ver, cfg, texts, fmt)
+        assert taken > n // 10
+
+
+def test_window_and_lane_boundaries(ver):
+    """Numbers, strings and runs that straddle lane (16 B) and window (1 KiB) boundaries: the same text
+    shifted by 0..1040 leading blanks (JSON: whitespace outside strings is free) must always be taken
+    with the same record; a blank INSIDE a number or a key must never be."""
+    cfg = ss.TESTING_CONFIG
+    j = open(os.path.join(GOLDEN, "stwo_proof_test.json"), "rb").read()
+    want = verifier.parse_stwo_text(cfg, j)[1]
+    texts = [b" " * k + j for k in list(range(0, 70)) + list(range(1000, 1045))]
+    recs, outcome = ver.read_stwo_texts(cfg, texts, JSON)
+    assert not outcome.any() and all(np.array_equal(r, want) for r in recs)
+    inner = [j[:k] + b" " + j[k:] for k in range(0, len(j), 7)]
+    _agree(ver, cfg, inner, JSON)
+
+
+def test_verify_texts_mixed_batch_and_chunking(ver, tmp_path):
+    """The entry point: canonical texts (GPU reader), non-canonical but valid texts (host reader), other
+    shapes, garbage, corrupted proofs -- one batch, verdicts equal the oracle's / the stage-0 codes; the
+    count of host-read texts is what the rule predicts; ~400 MB of text so several chunks are in flight."""
+    base = ss.stwo_from_json(json.load(open(os.path.join(GOLDEN, "stwo_proof.json"))))
+    cfg = base.cfg
+    rng = np.random.default_rng(SEED + 90)
+    bad = [formats.stwo_corrupt(base, rng)[0] for _ in range(5)]
+    proofs = [base] + bad
+    want_d = O.stwo_verify_batch(proofs).tolist()
+    small = open(os.path.join(GOLDEN, "stwo_proof_test.json"), "rb").read()
+    variants, want = [], []
+    for p, w in zip(proofs, want_d):
+        obj = ss.stwo_to_json(p)
+        variants += [json.dumps(obj).encode(), json.dumps(obj, separators=(",", ":")).encode(), ss.stwo_to_wit(p).encode(),
+                     json.dumps(dict(reversed(list(obj.items())))).encode()]   # the last one: host reader
+        want += [w, w, w, w]
+    variants += [small, b"{}", b"nonsense", b""]
+    want += [1, 2, 2, 2]
+    host_expected = sum(1 for v in variants if not (canonical(cfg, v, JSON)[0] or canonical(cfg, v, WIT)[0]))
+    assert host_expected == len(proofs) + 4
+    for n in (len(variants), 2500):
+        batch = [variants[i % len(variants)] for i in range(n)]
+        status, stats = ver.verify_stwo_texts(cfg, batch)
+        assert status.tolist() == [want[i % len(variants)] for i in range(n)]
+        assert stats["host_parsed"] == sum(1 for i in range(n) if i % len(variants) % 4 == 3 or i % len(variants) >= 4 * len(proofs))
+        assert stats["text_bytes"] == sum(len(b) for b in batch)
+    # files, with formats forced and sniffed
+    paths = []
+    for i, v in enumerate(variants[:12]):
+        f = tmp_path / ("p%d.txt" % i)
+        f.write_bytes(v)
+        paths.append(str(f))
+    paths.append(str(tmp_path / "absent.json"))
+    status, stats = ver.verify_stwo_files(cfg, paths)
+    assert status.tolist() == want[:12] + [2]
+    status, _ = ver.verify_stwo_texts(cfg, [variants[0], variants[2]], fmt=JSON)
+    assert status.tolist() == [want[0], 2]  # a .wit read as proof.json is no proof.json
+
+
+def test_full_size_texts_end_to_end(ver):
+    """2^20-row proofs as text, valid and corrupted, both formats, 600 texts (0.4 GB): the statuses of the
+    record path."""
+    p = records.load_stwo_npz(os.path.join(GOLDEN, "stwo_trace20.npz"))[0]
+    rng = np.random.default_rng(SEED + 91)
+    proofs = [p] + [formats.stwo_corrupt(p, rng)[0] for _ in range(3)]
+    want = O.stwo_verify_batch(proofs).tolist()
+    texts = []
+    for q in proofs:
+        rec = verifier.stwo_record(q)
+        texts += [write_text(q.cfg, rec, JSON, 0), write_text(q.cfg, rec, WIT)]
+    batch = [texts[i % 8] for i in range(600)]
+    status, stats = ver.verify_stwo_texts(p.cfg, batch)
+    assert status.tolist() == [want[(i % 8) // 2] for i in range(600)]
+    assert stats["host_parsed"] == 0 and want[0] == 0 and any(want[1:])
+
+
+def test_two_threads_share_one_context(ver):
+    """include/ss_verify.h, "threads": the scratch-using entry points serialize inside the context."""
+    import threading
+    base = ss.stwo_from_json(json.load(open(os.path.join(GOLDEN, "stwo_proof.json"))))
+    rng = np.random.default_rng(SEED + 92)
+    proofs = [base] + [formats.stwo_corrupt(base, rng)[0] for _ in range(3)]
+    want = O.stwo_verify_batch(proofs).tolist()
+    texts = [json.dumps(ss.stwo_to_json(q)).encode() for q in proofs]
+    recs = [verifier.stwo_record(q) for q in proofs]
+    errors = []
+
+    def by_text():
+        try:
+            for _ in range(6):
+                st, _ = ver.verify_stwo_texts(base.cfg, texts * 40)
+                assert st.tolist() == want * 40
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    def by_record():
+        try:
+            for _ in range(6):
+                st = ver.verify_stwo_records(base.cfg, recs * 50)
+                assert st.tolist() == want * 50
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+    th = [threading.Thread(target=by_text), threading.Thread(target=by_record), threading.Thread(target=by_text)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
