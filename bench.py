@@ -295,7 +295,7 @@ def main() -> None:
                     help="distinct valid proofs in the batch (made by the GPU prover; 0 = fixtures only)")
     ap.add_argument("--inflight", type=int, default=3,
                     help="batch passes in flight (one HIP stream each)")
-    ap.add_argument("--e2e", type=int, default=1536,
+    ap.add_argument("--e2e", type=int, default=4096,
                     help="proof.json / proof.wit texts for the end-to-end (text -> verdict) figures; 0 = skip")
     ap.add_argument("--graph", choices=["auto", "on", "off", "streams"], default="auto",
                     help="small batches (auto: stark101): 'streams' = whole passes on 16 independent streams, "

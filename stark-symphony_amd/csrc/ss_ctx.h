@@ -56,16 +56,18 @@ struct GrowBuf {
     size_t bytes = 0;
     bool pinned = false;
 };
+constexpr int kTextBufs = 3;  // chunks in flight: one uploading, one being read / verified, one being staged
 struct TextPath {
-    GrowBuf text_pin[2], text_dev[2];  // texts + their offsets / lengths / formats behind them
-    GrowBuf rec_dev[2], out_dev[2], out_pin[2];
-    GrowBuf fix_pin[2];                // records re-made by the host reader, on their way up
+    GrowBuf text_pin[kTextBufs], text_dev[kTextBufs];  // texts + their offsets / lengths / formats behind them
+    GrowBuf rec_dev[kTextBufs], out_dev[kTextBufs], out_pin[kTextBufs];
+    GrowBuf win_dev[kTextBufs];        // per-window scratch of the GPU reader (ss_textdev.h)
+    GrowBuf fix_pin[kTextBufs];        // records re-made by the host reader, on their way up
     GrowBuf batch_dev, ws_dev, status_dev;
-    GrowBuf win_dev;                   // per-window scratch of the GPU reader (ss_textdev.h)
-    hipStream_t up = nullptr, cx = nullptr;
-    hipEvent_t uploaded[2] = {nullptr, nullptr};  // H2D of buffer b complete (its pinned side is free again)
-    hipEvent_t parsed[2] = {nullptr, nullptr};    // GPU reader + outcome download of buffer b complete
-    hipEvent_t fixed[2] = {nullptr, nullptr};     // fix-up uploads from fix_pin[b] complete
+    hipStream_t up = nullptr, cx = nullptr, vx = nullptr;  // upload, GPU reader, re-tile + verify
+    hipEvent_t uploaded[kTextBufs] = {};  // H2D of buffer b complete
+    hipEvent_t parsed[kTextBufs] = {};    // GPU reader + outcome download of buffer b complete
+    hipEvent_t fixed[kTextBufs] = {};     // fix-up uploads from fix_pin[b] complete
+    hipEvent_t packed[kTextBufs] = {};    // rec_dev[b] re-tiled: the GPU reader may write it again
     std::vector<DevTemplate> templates;
 };
 

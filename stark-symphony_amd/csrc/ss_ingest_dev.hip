@@ -9,16 +9,21 @@
 //   host           texts the GPU reader did not take (outcome 1: not byte-for-byte canonical) go through the
 //                  tree parser of ss_ingest.cpp -- the arbiter for parsed / other config / malformed -- and
 //                  their records are uploaded over the GPU's;
-//   compute stream re-tile (ss_stwo_pack_dev) + verify the chunk.
-// Chunk c+1 is staged and uploaded while chunk c is read and verified.
+//   verify stream  re-tile (ss_stwo_pack_dev) + verify the chunk.
+// A stager thread keeps up to kTextBufs chunks staged ahead, so the upload stream never waits for the host;
+// the GPU reader of chunk c+1 runs beside the verification of chunk c.
 #include <hip/hip_runtime.h>
 
+#include <emmintrin.h>
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "ss_ctx.h"
@@ -49,14 +54,15 @@ void release(GrowBuf &b)
 
 void text_path_destroy(TextPath &tp)
 {
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < kTextBufs; i++) {
         release(tp.text_pin[i]); release(tp.text_dev[i]); release(tp.rec_dev[i]); release(tp.out_dev[i]);
-        release(tp.out_pin[i]); release(tp.fix_pin[i]);
+        release(tp.out_pin[i]); release(tp.fix_pin[i]); release(tp.win_dev[i]);
         if (tp.uploaded[i]) (void)hipEventDestroy(tp.uploaded[i]);
         if (tp.parsed[i]) (void)hipEventDestroy(tp.parsed[i]);
         if (tp.fixed[i]) (void)hipEventDestroy(tp.fixed[i]);
+        if (tp.packed[i]) (void)hipEventDestroy(tp.packed[i]);
     }
-    release(tp.batch_dev); release(tp.ws_dev); release(tp.status_dev); release(tp.win_dev);
+    release(tp.batch_dev); release(tp.ws_dev); release(tp.status_dev);
     for (auto &t : tp.templates) {
         if (t.skel) (void)hipFree(t.skel);
         if (t.slots) (void)hipFree(t.slots);
@@ -65,7 +71,8 @@ void text_path_destroy(TextPath &tp)
     tp.templates.clear();
     if (tp.up) (void)hipStreamDestroy(tp.up);
     if (tp.cx) (void)hipStreamDestroy(tp.cx);
-    tp.up = tp.cx = nullptr;
+    if (tp.vx) (void)hipStreamDestroy(tp.vx);
+    tp.up = tp.cx = tp.vx = nullptr;
 }
 
 namespace {
@@ -115,10 +122,13 @@ int ensure_streams(TextPath &tp)
 {
     if (!tp.up) HIP_TRY(hipStreamCreateWithFlags(&tp.up, hipStreamNonBlocking));
     if (!tp.cx) HIP_TRY(hipStreamCreateWithFlags(&tp.cx, hipStreamNonBlocking));
-    for (int i = 0; i < 2; i++) {
+    if (!tp.vx) HIP_TRY(hipStreamCreateWithFlags(&tp.vx, hipStreamNonBlocking));
+    for (int i = 0; i < kTextBufs; i++) {
         if (!tp.uploaded[i]) HIP_TRY(hipEventCreateWithFlags(&tp.uploaded[i], hipEventDisableTiming));
-        if (!tp.parsed[i]) HIP_TRY(hipEventCreateWithFlags(&tp.parsed[i], hipEventDisableTiming));
-        if (!tp.fixed[i]) HIP_TRY(hipEventCreateWithFlags(&tp.fixed[i], hipEventDisableTiming));
+        // (the host waits on these two while the stager's threads copy: sleep, do not spin on a core)
+        if (!tp.parsed[i]) HIP_TRY(hipEventCreateWithFlags(&tp.parsed[i], hipEventDisableTiming | hipEventBlockingSync));
+        if (!tp.fixed[i]) HIP_TRY(hipEventCreateWithFlags(&tp.fixed[i], hipEventDisableTiming | hipEventBlockingSync));
+        if (!tp.packed[i]) HIP_TRY(hipEventCreateWithFlags(&tp.packed[i], hipEventDisableTiming));
     }
     return SS_OK;
 }
@@ -131,6 +141,25 @@ struct Chunk {
     size_t lo = 0, cnt = 0;
     size_t text_bytes = 0;  // aligned text area
 };
+
+// Copy into pinned staging with streaming stores: the destination is read next by the DMA engine, not by a
+// core, so it should neither be fetched into the cache first (a read for ownership per line) nor push the
+// source out of it.  dst is 16-byte aligned (every text starts at an aligned offset of the staging buffer).
+void copy_streaming(uint8_t *dst, const void *src_, size_t n)
+{
+    const uint8_t *src = (const uint8_t *)src_;
+    size_t i = 0;
+    for (; i + 64 <= n; i += 64) {
+        const __m128i a = _mm_loadu_si128((const __m128i *)(src + i)), b = _mm_loadu_si128((const __m128i *)(src + i + 16));
+        const __m128i c = _mm_loadu_si128((const __m128i *)(src + i + 32)), d = _mm_loadu_si128((const __m128i *)(src + i + 48));
+        _mm_stream_si128((__m128i *)(dst + i), a);
+        _mm_stream_si128((__m128i *)(dst + i + 16), b);
+        _mm_stream_si128((__m128i *)(dst + i + 32), c);
+        _mm_stream_si128((__m128i *)(dst + i + 48), d);
+    }
+    if (i < n) memcpy(dst + i, src + i, n - i);
+    _mm_sfence();
+}
 
 // read a whole file into dst (cap bytes); returns its length, or -1 (absent, unreadable, longer than cap)
 long read_into(const char *path, uint8_t *dst, size_t cap)
@@ -176,6 +205,9 @@ int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *con
     if ((rc = template_of(ctx, *c, SS_TEXT_WIT, tp.cx, args.tmpl[1]))) return rc;
     args.record_words = (uint32_t)W;
     const unsigned threads = effective_cpus();
+    // staging is a copy: a few threads saturate it, and the thread that drives the GPU needs a core too
+    unsigned stage_threads = std::max(1u, std::min(threads > 1 ? threads - 1 : 1u, 8u));
+    if (const char *e = getenv("SS_STAGE_THREADS")) stage_threads = (unsigned)std::max(1, atoi(e));  // tuning knob
 
     // ---- sizes (files: stat) and the chunk plan
     std::vector<uint32_t> tlen(n, 0);
@@ -193,20 +225,33 @@ int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *con
         }
     }
     auto aligned = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    // Chunks of kChunkTextBytes of text -- smaller at both ends of the call: nothing can overlap the staging and
+    // upload of the first chunk, nor the reading and verification of the last one.
     std::vector<Chunk> chunks;
     {
+        size_t total = 0;
+        for (size_t i = 0; i < n; i++) total += aligned(tlen[i]);
+        size_t done = 0;
         Chunk cur;
+        auto cap_now = [&]() {
+            const size_t ramp = std::min(done, total - std::min(total, done)) / 2 + (kChunkTextBytes >> 3);
+            return std::min(kChunkTextBytes, std::max(kChunkTextBytes >> 3, ramp));
+        };
+        size_t cap = cap_now();
         for (size_t i = 0; i < n; i++) {
             const size_t a = aligned(tlen[i]);
-            if (cur.cnt && (cur.text_bytes + a > kChunkTextBytes || (cur.cnt + 1) * W * 4 > kChunkRecordBytes)) {
+            if (cur.cnt && (cur.text_bytes + a > cap || (cur.cnt + 1) * W * 4 > kChunkRecordBytes)) {
                 chunks.push_back(cur);
+                done += cur.text_bytes;
                 cur = Chunk{i, 0, 0};
+                cap = cap_now();
             }
             cur.cnt++;
             cur.text_bytes += a;
         }
         chunks.push_back(cur);
     }
+    const size_t nchunks = chunks.size();
     size_t max_cnt = 0, max_text = 0;
     for (auto &ch : chunks) { max_cnt = std::max(max_cnt, ch.cnt); max_text = std::max(max_text, ch.text_bytes); }
     // staging layout of a chunk:
@@ -221,68 +266,32 @@ int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *con
         words = std::max(words, ss_stwo_batch_words(&cv, ch.cnt));
         wsb = std::max(wsb, ss_stwo_workspace_bytes(&cv, ch.cnt));
     }
-    for (int b = 0; b < 2; b++) {
+    for (int b = 0; b < kTextBufs; b++) {
         if ((rc = grow(tp.text_pin[b], stage_cap, true))) return rc;
         if ((rc = grow(tp.text_dev[b], stage_cap, false))) return rc;
         if ((rc = grow(tp.rec_dev[b], max_cnt * W * 4, false))) return rc;
         if ((rc = grow(tp.out_dev[b], max_cnt * 4, false))) return rc;
         if ((rc = grow(tp.out_pin[b], max_cnt * 4, true))) return rc;
+        if ((rc = grow(tp.win_dev[b], max_windows * (4 + sizeof(WinSum) + sizeof(WinIn)), false))) return rc;
     }
-    if ((rc = grow(tp.win_dev, max_windows * (4 + sizeof(WinSum) + sizeof(WinIn)), false))) return rc;
     if ((rc = grow(tp.batch_dev, words * 4, false))) return rc;
     if ((rc = grow(tp.ws_dev, wsb, false))) return rc;
     if ((rc = grow(tp.status_dev, n * 4, false))) return rc;
 
     std::vector<uint8_t> outcome(n, 0);  // ParseResult of the texts the host reader handled (0 = verified as parsed)
+    std::vector<uint32_t> chunk_windows(nchunks, 0);
     double stage_s = 0, parse_s = 0;
     uint64_t text_total = 0, fallbacks = 0;
     uint32_t *status_dev = (uint32_t *)tp.status_dev.p;
 
-    // what the host has to do once the GPU reader of chunk k is through: re-read what it did not take,
-    // then re-tile and verify the chunk
-    auto finish = [&](size_t k) -> int {
+    // ---- the stager: raw bytes into pinned memory, a few chunks ahead of the GPU.  No HIP calls on this thread.
+    std::mutex m;
+    std::condition_variable cv_staged, cv_freed;
+    size_t staged = 0, freed = 0;  // chunks staged so far / chunks whose pinned buffer is free again (finished)
+    bool abort = false;
+    auto stage_chunk = [&](size_t k) {
         const Chunk &ch = chunks[k];
-        const int b = (int)(k & 1);
-        HIP_TRY(hipEventSynchronize(tp.parsed[b]));
-        const uint32_t *oc = (const uint32_t *)tp.out_pin[b].p;
-        std::vector<uint32_t> todo;
-        for (size_t i = 0; i < ch.cnt; i++)
-            if (oc[i] != 0) todo.push_back((uint32_t)i);
-        if (!todo.empty()) {
-            const double tp0 = now_s();
-            fallbacks += todo.size();
-            HIP_TRY(hipEventSynchronize(tp.fixed[b]));  // fix_pin[b]'s previous uploads are through
-            if ((rc = grow(tp.fix_pin[b], todo.size() * W * 4, true))) return rc;
-            uint32_t *fix = (uint32_t *)tp.fix_pin[b].p;
-            const uint8_t *stage = (const uint8_t *)tp.text_pin[b].p;
-            const uint64_t *offs = (const uint64_t *)(stage + meta_off(ch));
-            parallel_for(todo.size(), [&](size_t j) {
-                const size_t i = todo[j], g = ch.lo + i;
-                uint32_t *dst = fix + j * W;
-                ParseResult r = kMalformed;
-                if (!unreadable[g]) r = stwo_parse_text(*c, (const char *)stage + offs[i], tlen[g], fmt, dst);
-                if (r != kParsed) memset(dst, 0, W * 4);
-                outcome[g] = (uint8_t)r;
-            }, threads);
-            uint32_t *rec = (uint32_t *)tp.rec_dev[b].p;
-            for (size_t j = 0; j < todo.size(); j++)
-                HIP_TRY(hipMemcpyAsync(rec + (size_t)todo[j] * W, fix + j * W, W * 4, hipMemcpyHostToDevice, tp.cx));
-            HIP_TRY(hipEventRecord(tp.fixed[b], tp.cx));
-            parse_s += now_s() - tp0;
-        }
-        if ((rc = ss_stwo_pack_dev(ctx, c, ch.cnt, (const uint32_t *)tp.rec_dev[b].p, (uint32_t *)tp.batch_dev.p, tp.cx))) return rc;
-        return ss_stwo_verify_batch_dev(ctx, c, ch.cnt, (const uint32_t *)tp.batch_dev.p, tp.ws_dev.p, tp.ws_dev.bytes,
-                                        status_dev + ch.lo, nullptr, tp.cx);
-    };
-
-    for (size_t k = 0; k < chunks.size(); k++) {
-        const Chunk &ch = chunks[k];
-        const int b = (int)(k & 1);
-        // ---- stage: raw bytes into pinned memory (the previous upload from this buffer is through, and the
-        // host reader no longer needs its texts: finish(k - 2) ran before stage(k))
-        HIP_TRY(hipEventSynchronize(tp.uploaded[b]));
-        const double ts0 = now_s();
-        uint8_t *stage = (uint8_t *)tp.text_pin[b].p;
+        uint8_t *stage = (uint8_t *)tp.text_pin[k % kTextBufs].p;
         uint64_t *offs = (uint64_t *)(stage + meta_off(ch));
         uint32_t *lens32 = (uint32_t *)(offs + ch.cnt);
         uint32_t *win_base = lens32 + ch.cnt;
@@ -301,7 +310,8 @@ int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *con
                 if (got < 0) { unreadable[g] = 1; len = 0; }
                 else { len = (uint32_t)got; tlen[g] = len; }  // (a file that shrank since stat)
             } else {
-                memcpy(dst, texts[g], len);
+                // (plain memcpy here costs a third of the rate: 84.6k -> 65-71k proofs/s, profiles/r03_text_staging_ab.txt)
+                copy_streaming(dst, texts[g], len);
             }
             lens32[i] = len;
             // which template to try: a .wit is a JSON object whose first member is COMMITMENTS.  A wrong guess
@@ -313,49 +323,128 @@ int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *con
                 for (size_t p = 0; p + sizeof key - 1 <= look && !f; p++) f = memcmp(dst + p, key, sizeof key - 1) == 0;
             }
             fmts[i] = f;
-        }, threads);
+        }, stage_threads);
         uint32_t n_windows = 0;  // (after the reads: a file may have shrunk since its stat)
         for (size_t i = 0; i < ch.cnt; i++) {
-            text_total += lens32[i];
             win_base[i] = n_windows;
             n_windows += (lens32[i] + 1023) >> 10;
         }
         win_base[ch.cnt] = n_windows;
-        stage_s += now_s() - ts0;
-        // ---- upload (after the GPU reader of chunk k - 2 has finished with the device buffer)
-        HIP_TRY(hipStreamWaitEvent(tp.up, tp.parsed[b], 0));
-        HIP_TRY(hipMemcpyAsync(tp.text_dev[b].p, stage, stage_bytes(ch), hipMemcpyHostToDevice, tp.up));
-        HIP_TRY(hipEventRecord(tp.uploaded[b], tp.up));
-        // ---- GPU reader
-        HIP_TRY(hipStreamWaitEvent(tp.cx, tp.uploaded[b], 0));
-        const uint8_t *dev = (const uint8_t *)tp.text_dev[b].p;
-        args.texts = dev;
-        args.offs = (const uint64_t *)(dev + meta_off(ch));
-        args.lens = (const uint32_t *)(args.offs + ch.cnt);
-        args.win_base = args.lens + ch.cnt;
-        args.fmt = (const uint8_t *)(args.win_base + ch.cnt + 1);
-        args.win_text = (uint32_t *)tp.win_dev.p;
-        args.win_sum = (WinSum *)(args.win_text + max_windows);
-        args.win_in = (WinIn *)(args.win_sum + max_windows);
-        args.records = (uint32_t *)tp.rec_dev[b].p;
-        args.outcome = (uint32_t *)tp.out_dev[b].p;
-        args.n = (uint32_t)ch.cnt;
-        args.n_windows = n_windows;
-        {
-            Timer t(ctx, tp.cx);
-            t.begin();
-            launch_text_parse(args, tp.cx);
-            t.end("stwo_text_parse");
+        chunk_windows[k] = n_windows;
+    };
+    std::thread stager([&]() {
+        for (size_t k = 0; k < nchunks; k++) {
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv_freed.wait(lk, [&] { return abort || k < freed + kTextBufs; });
+                if (abort) return;
+            }
+            const double ts0 = now_s();
+            stage_chunk(k);
+            const double dt = now_s() - ts0;
+            { std::lock_guard<std::mutex> lk(m); staged = k + 1; stage_s += dt; }
+            cv_staged.notify_all();
         }
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(tp.out_pin[b].p, tp.out_dev[b].p, ch.cnt * 4, hipMemcpyDeviceToHost, tp.cx));
-        HIP_TRY(hipEventRecord(tp.parsed[b], tp.cx));
-        if (k > 0 && (rc = finish(k - 1))) return rc;
-    }
-    if ((rc = finish(chunks.size() - 1))) return rc;
-    HIP_TRY(hipMemcpyAsync(status_host, status_dev, n * 4, hipMemcpyDeviceToHost, tp.cx));
-    HIP_TRY(hipStreamSynchronize(tp.cx));
-    HIP_TRY(hipStreamSynchronize(tp.up));
+    });
+    auto stop_stager = [&]() {
+        { std::lock_guard<std::mutex> lk(m); abort = true; }
+        cv_freed.notify_all();
+        stager.join();
+    };
+
+    // What is left once the GPU reader of chunk k is through: texts it did not take go through the host reader and
+    // their records over the GPU's; then the chunk is re-tiled and verified on the verify stream.
+    auto finish = [&](size_t k) -> int {
+        const Chunk &ch = chunks[k];
+        const int b = (int)(k % kTextBufs);
+        HIP_TRY(hipEventSynchronize(tp.parsed[b]));
+        const uint32_t *oc = (const uint32_t *)tp.out_pin[b].p;
+        std::vector<uint32_t> todo;
+        for (size_t i = 0; i < ch.cnt; i++)
+            if (oc[i] != 0) todo.push_back((uint32_t)i);
+        HIP_TRY(hipStreamWaitEvent(tp.vx, tp.parsed[b], 0));
+        if (!todo.empty()) {
+            const double tp0 = now_s();
+            fallbacks += todo.size();
+            HIP_TRY(hipEventSynchronize(tp.fixed[b]));  // fix_pin[b]'s previous uploads are through
+            if ((rc = grow(tp.fix_pin[b], todo.size() * W * 4, true))) return rc;
+            uint32_t *fix = (uint32_t *)tp.fix_pin[b].p;
+            const uint8_t *stage = (const uint8_t *)tp.text_pin[b].p;
+            const uint64_t *offs = (const uint64_t *)(stage + meta_off(ch));
+            parallel_for(todo.size(), [&](size_t j) {
+                const size_t i = todo[j], g = ch.lo + i;
+                uint32_t *dst = fix + j * W;
+                ParseResult r = kMalformed;
+                if (!unreadable[g]) r = stwo_parse_text(*c, (const char *)stage + offs[i], tlen[g], fmt, dst);
+                if (r != kParsed) memset(dst, 0, W * 4);
+                outcome[g] = (uint8_t)r;
+            }, threads);
+            uint32_t *rec = (uint32_t *)tp.rec_dev[b].p;
+            for (size_t j = 0; j < todo.size(); j++)
+                HIP_TRY(hipMemcpyAsync(rec + (size_t)todo[j] * W, fix + j * W, W * 4, hipMemcpyHostToDevice, tp.vx));
+            HIP_TRY(hipEventRecord(tp.fixed[b], tp.vx));
+            parse_s += now_s() - tp0;
+        }
+        for (size_t i = 0; i < ch.cnt; i++) text_total += tlen[ch.lo + i];
+        { std::lock_guard<std::mutex> lk(m); freed = k + 1; }  // the pinned texts of this chunk are no longer needed
+        cv_freed.notify_all();
+        if ((rc = ss_stwo_pack_dev(ctx, c, ch.cnt, (const uint32_t *)tp.rec_dev[b].p, (uint32_t *)tp.batch_dev.p, tp.vx))) return rc;
+        HIP_TRY(hipEventRecord(tp.packed[b], tp.vx));  // rec_dev[b] may be written again
+        return ss_stwo_verify_batch_dev(ctx, c, ch.cnt, (const uint32_t *)tp.batch_dev.p, tp.ws_dev.p, tp.ws_dev.bytes,
+                                        status_dev + ch.lo, nullptr, tp.vx);
+    };
+
+    auto run = [&]() -> int {
+        for (size_t k = 0; k < nchunks; k++) {
+            const Chunk &ch = chunks[k];
+            const int b = (int)(k % kTextBufs);
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv_staged.wait(lk, [&] { return staged > k; });
+            }
+            // ---- upload (the GPU reader of chunk k - kTextBufs has finished with the device buffer: its outcome
+            // download completed before finish() freed the pinned buffer this chunk was staged into)
+            HIP_TRY(hipMemcpyAsync(tp.text_dev[b].p, tp.text_pin[b].p, stage_bytes(ch), hipMemcpyHostToDevice, tp.up));
+            HIP_TRY(hipEventRecord(tp.uploaded[b], tp.up));
+            // ---- GPU reader (after rec_dev[b] has been re-tiled for chunk k - kTextBufs)
+            HIP_TRY(hipStreamWaitEvent(tp.cx, tp.uploaded[b], 0));
+            HIP_TRY(hipStreamWaitEvent(tp.cx, tp.packed[b], 0));
+            const uint8_t *dev = (const uint8_t *)tp.text_dev[b].p;
+            args.texts = dev;
+            args.offs = (const uint64_t *)(dev + meta_off(ch));
+            args.lens = (const uint32_t *)(args.offs + ch.cnt);
+            args.win_base = args.lens + ch.cnt;
+            args.fmt = (const uint8_t *)(args.win_base + ch.cnt + 1);
+            args.win_text = (uint32_t *)tp.win_dev[b].p;
+            args.win_sum = (WinSum *)(args.win_text + max_windows);
+            args.win_in = (WinIn *)(args.win_sum + max_windows);
+            args.records = (uint32_t *)tp.rec_dev[b].p;
+            args.outcome = (uint32_t *)tp.out_dev[b].p;
+            args.n = (uint32_t)ch.cnt;
+            args.n_windows = chunk_windows[k];
+            {
+                Timer t(ctx, tp.cx);
+                t.begin();
+                launch_text_parse(args, tp.cx);
+                t.end("stwo_text_parse");
+            }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(tp.out_pin[b].p, tp.out_dev[b].p, ch.cnt * 4, hipMemcpyDeviceToHost, tp.cx));
+            HIP_TRY(hipEventRecord(tp.parsed[b], tp.cx));
+            if (k > 0 && (rc = finish(k - 1))) return rc;
+        }
+        if ((rc = finish(nchunks - 1))) return rc;
+        HIP_TRY(hipMemcpyAsync(status_host, status_dev, n * 4, hipMemcpyDeviceToHost, tp.vx));
+        HIP_TRY(hipStreamSynchronize(tp.vx));
+        return SS_OK;
+    };
+    rc = run();
+    stop_stager();
+    // whatever happened, nothing of this call may still be in flight when the scratch is used again
+    (void)hipStreamSynchronize(tp.up);
+    (void)hipStreamSynchronize(tp.cx);
+    (void)hipStreamSynchronize(tp.vx);
+    if (rc) return rc;
     for (size_t i = 0; i < n; i++) {
         if (outcome[i] == kMalformed) status_host[i] = SS_STATUS_MALFORMED;
         else if (outcome[i] == kConfigMismatch) status_host[i] = SS_STATUS_CONFIG_MISMATCH;
