@@ -252,6 +252,16 @@ extern "C" int ss_stwo_pack(const ss_stwo_cfg *c, size_t n, const uint32_t *cons
     const StwoLayout y = lay_of(c, n);
     memset(out, 0, (size_t)y.total_words * 4);
     const uint32_t N = y.N, L = y.L, Q = y.Q, K = y.K;
+    // sibling `lv` (from the leaf) of query q's path in tree `type` of proof p: the lowest len - top levels sit in
+    // the 64-chain tiles, the top ones in top[proof][type][level][query][8]  (ss_layout.h)
+    auto path_word = [&](uint32_t type, uint32_t len, size_t p, uint32_t q, uint32_t lv, uint32_t w) -> uint32_t & {
+        const uint32_t top = y.T < len ? y.T : len, low = len - top;
+        if (lv < low) {
+            const uint64_t base = type == 0 ? y.off_trace_path : type == 1 ? y.off_cp_path : y.off_fri_path[type - 2];
+            return out[tile_word(base, low, (uint64_t)p * Q + q, lv, w)];
+        }
+        return out[y.off_top + (uint64_t)p * y.top_words + y.top_off[type] + ((uint64_t)(lv - low) * Q + q) * 8 + w];
+    };
     parallel_for(n, [&](size_t p) {
         const uint32_t *r = records[p];
         for (uint32_t w = 0; w < y.head_words; w++) out[y.off_head + (uint64_t)w * y.np + p] = r[w];
@@ -260,10 +270,9 @@ extern "C" int ss_stwo_pack(const ss_stwo_cfg *c, size_t n, const uint32_t *cons
             const uint64_t inst = (uint64_t)p * Q + q;
             for (uint32_t k = 0; k < N; k++) out[y.off_trace_vals + (uint64_t)k * y.nip + inst] = *r++;
             for (uint32_t k = 0; k < kCp; k++) out[y.off_cp_vals + (uint64_t)k * y.nip + inst] = *r++;
-            for (uint32_t l = 0; l < L; l++)
-                for (uint32_t w = 0; w < 8; w++) out[tile_word(y.off_trace_path, L, inst, l, w)] = *r++;
-            for (uint32_t l = 0; l < L; l++)
-                for (uint32_t w = 0; w < 8; w++) out[tile_word(y.off_cp_path, L, inst, l, w)] = *r++;
+            for (uint32_t type = 0; type < 2; type++)
+                for (uint32_t l = 0; l < L; l++)
+                    for (uint32_t w = 0; w < 8; w++) path_word(type, L, p, q, l, w) = *r++;
         }
         for (uint32_t l = 0; l <= K; l++) {
             const uint32_t len = L - 1 - l;
@@ -272,7 +281,7 @@ extern "C" int ss_stwo_pack(const ss_stwo_cfg *c, size_t n, const uint32_t *cons
                 for (uint32_t w = 0; w < 4; w++)
                     out[y.off_fri_wit + ((uint64_t)l * 4 + w) * y.nip + inst] = *r++;
                 for (uint32_t lv = 0; lv < len; lv++)
-                    for (uint32_t w = 0; w < 8; w++) out[tile_word(y.off_fri_path[l], len, inst, lv, w)] = *r++;
+                    for (uint32_t w = 0; w < 8; w++) path_word(2 + l, len, p, q, lv, w) = *r++;
             }
         }
         for (uint32_t kind = 0; kind < K + 3; kind++)  // trailer: path lengths
@@ -320,10 +329,15 @@ extern "C" int ss_stwo_verify_phase_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_
             t.begin();
             const int hf = c->hash == SS_HASH_BLAKE2S;
             const uint32_t blocks = std::min<uint32_t>(y.top_blocks, (uint32_t)(ctx->top_blocks_per_cu[hf] * ctx->cus));
-            HIP_TRY(hipMemsetAsync(ws + y.ws_counter, 0, 4, s));  // the kernel's group counter
+            HIP_TRY(hipMemsetAsync(ws + y.ws_counter, 0, 8, s));  // the kernel's group counter and its count of flagged trees
             hipLaunchKernelGGL(hf ? stwo_top_kernel_b2s : stwo_top_kernel_sha, dim3(blocks), dim3(kTopChains), 0, s,
                                y, batch, ws, status);
             t.end("stwo_top");
+            // trees in which queries disagree about a node (none in an honest batch: the grid reads one word and leaves)
+            t.begin();
+            hipLaunchKernelGGL(hf ? stwo_top_cold_kernel_b2s : stwo_top_cold_kernel_sha, dim3(4 * ctx->cus), dim3(256), 0, s,
+                               y, batch, (const uint32_t *)ws, status);
+            t.end("stwo_top_cold");
         }
         t.begin();
         hipLaunchKernelGGL(stwo_finalize_kernel, dim3((y.n + 255) / 256), dim3(256), 0, s, y.n, status,
@@ -493,7 +507,8 @@ __global__ void stwo_pack_words_kernel(StwoLayout y, StwoRecordMap m, const uint
     out[d] = v;
 }
 
-// Merkle path tiles: one 16-byte unit (level, half, lane) per thread
+// Merkle paths: one 16-byte unit per thread.  Tiles [g][level][half][lane] hold the lowest len - top levels of a
+// type, the `top` section [proof][type][level][query][half] the top ones (ss_layout.h).
 __global__ void stwo_pack_paths_kernel(StwoLayout y, StwoRecordMap m, const uint32_t *__restrict__ rec,
                                        uint32_t *__restrict__ out)
 {
@@ -501,31 +516,55 @@ __global__ void stwo_pack_paths_kernel(StwoLayout y, StwoRecordMap m, const uint
     const uint64_t first = y.off_trace_path >> 2, total = (y.total_words >> 2) - first;
     if (u >= total) return;
     const uint64_t d = (first + u) << 2;  // word offset
-    // which section
-    uint64_t base;
-    uint32_t len, src0, per_q;  // src0: record offset of level 0 word 0 for query 0
-    if (d < y.off_cp_path) { base = y.off_trace_path; len = y.L; src0 = y.head_words + y.N + kCp; per_q = m.qstride; }
-    else if (d < y.off_fri_path[0]) { base = y.off_cp_path; len = y.L; src0 = y.head_words + y.N + kCp + 8 * y.L; per_q = m.qstride; }
-    else {
-        uint32_t l = 0;
-        while (l < y.K && d >= y.off_fri_path[l + 1]) l++;
-        base = y.off_fri_path[l];
+    auto src_of = [&](uint32_t type, uint32_t &len, uint32_t &per_q) {  // record offset of level 0 word 0 for query 0
+        if (type < 2) { len = y.L; per_q = m.qstride; return y.head_words + y.N + kCp + type * 8 * y.L; }
+        const uint32_t l = type - 2;
         len = y.L - 1 - l;
-        src0 = m.fbase + m.foff[l] + 4;
         per_q = 4 + 8 * len;
-    }
-    const uint64_t r = (d - base) >> 2;           // uint4 units inside the section
-    const uint32_t lane = (uint32_t)(r & 63);
-    const uint64_t r2 = r >> 6;
-    const uint32_t half = (uint32_t)(r2 & 1);
-    const uint64_t r3 = r2 >> 1;                   // g * len + level
-    const uint32_t g = (uint32_t)(r3 / len), level = (uint32_t)(r3 - (uint64_t)g * len);
-    const uint32_t inst = g * 64 + lane;
+        return m.fbase + m.foff[l] + 4;
+    };
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (inst < y.ni) {
-        const uint32_t p = inst / y.Q, q = inst - p * y.Q;
-        const uint32_t *s = rec + (uint64_t)p * m.W + src0 + q * per_q + level * 8 + half * 4;
-        v = make_uint4(s[0], s[1], s[2], s[3]);
+    if (d >= y.off_top) {
+        const uint64_t r = (d - y.off_top) >> 2, per_proof = y.top_words >> 2;
+        const uint32_t p = per_proof ? (uint32_t)(r / per_proof) : y.n;
+        if (p < y.n) {  // (behind the last proof: alignment padding)
+            const uint32_t in_p = (uint32_t)(r - (uint64_t)p * per_proof) << 2;  // word inside the proof's part
+            uint32_t type = 0;
+            while (type + 1 < y.K + 3 && in_p >= y.top_off[type + 1]) type++;
+            uint32_t len, per_q;
+            const uint32_t src0 = src_of(type, len, per_q);
+            const uint32_t top = y.T < len ? y.T : len;
+            const uint32_t e = (in_p - y.top_off[type]) >> 2;  // (level * Q + query) * 2 + half
+            const uint32_t half = e & 1, lq = e >> 1, lvl = lq / y.Q, q = lq - lvl * y.Q;
+            const uint32_t *s = rec + (uint64_t)p * m.W + src0 + q * per_q + (len - top + lvl) * 8 + half * 4;
+            v = make_uint4(s[0], s[1], s[2], s[3]);
+        }
+    } else {
+        uint32_t type;
+        uint64_t base;
+        if (d < y.off_cp_path) { type = 0; base = y.off_trace_path; }
+        else if (d < y.off_fri_path[0]) { type = 1; base = y.off_cp_path; }
+        else {
+            uint32_t l = 0;
+            while (l < y.K && d >= y.off_fri_path[l + 1]) l++;
+            type = 2 + l;
+            base = y.off_fri_path[l];
+        }
+        uint32_t len, per_q;
+        const uint32_t src0 = src_of(type, len, per_q);
+        const uint32_t low = len - (y.T < len ? y.T : len);  // levels in the tile (> 0: the unit lies in this section)
+        const uint64_t r = (d - base) >> 2;           // uint4 units inside the section
+        const uint32_t lane = (uint32_t)(r & 63);
+        const uint64_t r2 = r >> 6;
+        const uint32_t half = (uint32_t)(r2 & 1);
+        const uint64_t r3 = r2 >> 1;                   // g * low + level
+        const uint32_t g = (uint32_t)(r3 / low), level = (uint32_t)(r3 - (uint64_t)g * low);
+        const uint32_t inst = g * 64 + lane;
+        if (inst < y.ni) {
+            const uint32_t p = inst / y.Q, q = inst - p * y.Q;
+            const uint32_t *s = rec + (uint64_t)p * m.W + src0 + q * per_q + level * 8 + half * 4;
+            v = make_uint4(s[0], s[1], s[2], s[3]);
+        }
     }
     reinterpret_cast<uint4 *>(out)[first + u] = v;
 }

@@ -8,6 +8,12 @@
 //   Merkle paths, per chain type: 64-chain tiles
 //          tile[g][level][half][lane][4 words],   g = instance / 64, lane = instance % 64
 //     so a wavefront fetches one sibling level of its 64 chains as two contiguous 1 KiB reads.
+//     With pair memoisation (T > 0) the tiles hold only the levels stwo_merkle_kernel hashes, the lowest
+//     len - min(T, len); the top min(T, len) levels of every tree live in
+//          top[proof][type][level][query][8 words]
+//     -- the Q siblings of one (proof, tree, level) are one contiguous run of Q * 32 bytes, so the leader that
+//     hashes a node and the followers whose bytes are compared with its sibling touch the same cache lines.
+//     A batch is therefore laid out for the cfg (hash family and flags included) it will be verified with.
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
@@ -46,6 +52,9 @@ struct StwoLayout {
     // section word offsets inside the batch buffer
     uint64_t off_head, off_trace_vals, off_cp_vals, off_fri_wit, off_plen, off_trace_path, off_cp_path;
     uint64_t off_fri_path[kMaxList + 1];
+    uint64_t off_top;                  // top[proof][type][level][query][8]
+    uint32_t top_off[kMaxList + 3];    // word offset of a type inside a proof's part of `top`
+    uint32_t top_words;                // words per proof in `top`
     uint64_t total_words;
     // workspace word offsets (u32 words)
     uint32_t c_queries, c_p, c_p2, c_b01, c_b02, c_a1, c_c1, c_a2, c_c2, c_m1, c_fold, ctx_words;
@@ -58,7 +67,8 @@ struct StwoLayout {
     uint32_t top_blocks;  // persistent blocks of the top kernel (each owns a slice of ws_vals)
     uint64_t ws_top;      // top[type][inst][8]: node of every chain at depth min(T, len), native words
     uint64_t ws_vals;     // vals[block][parity][type][slot][8]: nodes of the distinct pairs, two depths
-    uint64_t ws_counter;  // next group of the top kernel (one word, zeroed before each launch)
+    uint64_t ws_counter;  // [0] next group of the top kernel, [1] trees it flagged (two words, zeroed before each launch)
+    uint64_t ws_flag;     // flag[type][proof]: 1 = the tree's checks failed, stwo_top_cold_kernel re-hashes its chains
 };
 
 constexpr uint32_t kTopChains = 256;     // chains a top-kernel block plans at once (= its threads)
@@ -100,12 +110,31 @@ SS_HD inline StwoLayout stwo_layout(uint32_t N, uint32_t TL, uint32_t L, uint32_
     y.off_cp_vals = o;     o += (uint64_t)kCp * y.nip;
     y.off_fri_wit = o;     o += (uint64_t)(K + 1) * 4 * y.nip;
     y.off_plen = o;        o += (uint64_t)(K + 3) * y.nip;  // path length per chain: plen[kind][inst]
-    y.off_trace_path = o;  o += (uint64_t)L * 8 * y.nip;
-    y.off_cp_path = o;     o += (uint64_t)L * 8 * y.nip;
+    // Q random leaves share their ancestors down to about log2(Q) levels below the root; two more
+    // levels still merge ~1.5 pairs per tree, below that almost nothing.  With a hash half as long
+    // (Blake2s: one compression per node) the second extra level no longer pays for its bookkeeping
+    // (measured: configs[2] with Blake2s 4.71 M -> 4.82 M proofs/s at one level less).
+    const uint32_t want = ceil_log2(Q) + (light_hash ? 1 : 2);
+    y.T = (dedup && Q > 1) ? (want < L ? want : L) : 0;
+    auto tile_len = [&](uint32_t len) { return len - (y.T < len ? y.T : len); };
+    y.off_trace_path = o;  o += (uint64_t)tile_len(L) * 8 * y.nip;
+    y.off_cp_path = o;     o += (uint64_t)tile_len(L) * 8 * y.nip;
     for (uint32_t l = 0; l <= K; l++) {
         y.off_fri_path[l] = o;
-        o += (uint64_t)(L - 1 - l) * 8 * y.nip;
+        o += (uint64_t)tile_len(L - 1 - l) * 8 * y.nip;
     }
+    y.off_top = o;
+    {
+        uint32_t t = 0;
+        for (uint32_t type = 0; type < K + 3; type++) {
+            const uint32_t len = type < 2 ? L : L - 1 - (type - 2);
+            y.top_off[type] = t;
+            t += (y.T < len ? y.T : len) * Q * 8;
+        }
+        y.top_words = t;
+    }
+    o += (uint64_t)y.top_words * n;
+    o = (o + 3) & ~(uint64_t)3;
     y.total_words = o;
     // per-proof context written by the transcript kernel
     uint32_t c = 0;
@@ -127,12 +156,6 @@ SS_HD inline StwoLayout stwo_layout(uint32_t N, uint32_t TL, uint32_t L, uint32_
     y.n_pow = N + kCp;
     y.ws_alpha = w; w += (uint64_t)y.n_pow * 4 * y.np;
     y.ws_leaf = w;  w += (uint64_t)(K + 1) * 8 * y.nip;
-    // Q random leaves share their ancestors down to about log2(Q) levels below the root; two more
-    // levels still merge ~1.5 pairs per tree, below that almost nothing.  With a hash half as long
-    // (Blake2s: one compression per node) the second extra level no longer pays for its bookkeeping
-    // (measured: configs[2] with Blake2s 4.71 M -> 4.82 M proofs/s at one level less).
-    const uint32_t want = ceil_log2(Q) + (light_hash ? 1 : 2);
-    y.T = (dedup && Q > 1) ? (want < L ? want : L) : 0;
     y.top_G = kTopChains / Q;  // Q <= kMaxQueries = 64
     // a batch that gives fewer groups than the ~1024 blocks the chip holds at once (4 per CU) is cut
     // into smaller groups: half-empty plans cost less than half-empty CUs
@@ -142,6 +165,7 @@ SS_HD inline StwoLayout stwo_layout(uint32_t N, uint32_t TL, uint32_t L, uint32_
     y.ws_top = w;   w += y.T ? (uint64_t)(K + 3) * y.nip * 8 : 0;
     y.ws_vals = w;  w += (uint64_t)y.top_blocks * 2 * (K + 3) * kTopChains * 8;
     y.ws_counter = w; w += 4;
+    y.ws_flag = w;  w += y.T ? (uint64_t)(K + 3) * y.np : 0;
     y.ws_total_words = w;
     return y;
 }

@@ -457,7 +457,8 @@ __device__ __forceinline__ void stwo_merkle_body(const StwoLayout &lay, const ui
     // on (lay.T) this kernel stops `top` levels below the root and hands the node to stwo_top_kernel.
     const uint32_t top = lay.T < len ? lay.T : len;
     const uint32_t n_lvl = len - top;
-    const uint4 *tp = reinterpret_cast<const uint4 *>(path) + ((size_t)g * len * 2) * 64 + lane;
+    // (the tiles hold only the n_lvl levels hashed here; the top ones live in the `top` section)
+    const uint4 *tp = reinterpret_cast<const uint4 *>(path) + ((size_t)g * n_lvl * 2) * 64 + lane;
     uint4 s0 = make_uint4(0, 0, 0, 0), s1 = s0;
     if (n_lvl) { s0 = tp[0]; s1 = tp[64]; }
     for (uint32_t lvl = 0; lvl < n_lvl; lvl++) {
@@ -535,6 +536,13 @@ __device__ __forceinline__ void stwo_merkle_body(const StwoLayout &lay, const ui
 // shallow depth has beyond two per hash iteration is drained four in flight before its barrier.  Nodes of two consecutive depths live in the
 // block's slice of ws_vals.
 constexpr uint32_t kTopMaxT = 8;  // ceil_log2(kMaxQueries) + 2
+#ifndef SS_TOP_LIGHTS
+#define SS_TOP_LIGHTS 2
+#endif
+#ifndef SS_TOP_WAVES
+#define SS_TOP_WAVES 3
+#endif
+constexpr uint32_t kTopLights = SS_TOP_LIGHTS;  // light checks that ride along one pair hash
 
 template <int HF>
 __device__ __forceinline__ void stwo_top_body(const StwoLayout &lay, const uint32_t *__restrict__ batch,
@@ -559,7 +567,7 @@ __device__ __forceinline__ void stwo_top_body(const StwoLayout &lay, const uint3
     __shared__ uint32_t s_grp, s_take;
     __shared__ uint8_t s_g[kTopChains];            // chain -> proof of the group
     __shared__ uint8_t s_bad[NT][kTopChains / 2];  // [tree][proof of the group] (Q >= 2: <= 128 proofs)
-    __shared__ uint64_t s_path[NT];                // word offset of the tree's path tiles
+    __shared__ uint32_t s_topoff[NT];              // word offset of the tree inside a proof's part of `top`
     __shared__ uint32_t s_len[NT], s_rootw[NT], s_code[NT];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -573,7 +581,7 @@ __device__ __forceinline__ void stwo_top_body(const StwoLayout &lay, const uint3
     if (tid < n_types) {
         const uint32_t l = tid < 2 ? 0 : tid - 2;
         s_len[tid] = tid < 2 ? L : L - 1 - l;
-        s_path[tid] = tid == 0 ? lay.off_trace_path : tid == 1 ? lay.off_cp_path : lay.off_fri_path[l];
+        s_topoff[tid] = lay.top_off[tid];
         s_rootw[tid] = tid < 2 ? lay.h_roots + 8 * (tid + 1) : lay.h_fri_roots + 8 * l;
         s_code[tid] = tid < 2 ? stwo_code(5, 0, 0, 2 * tid) : stwo_code(7, l, 0, 0);
     }
@@ -583,12 +591,14 @@ __device__ __forceinline__ void stwo_top_body(const StwoLayout &lay, const uint3
         return ((x.a.x ^ y.a.x) | (x.a.y ^ y.a.y) | (x.a.z ^ y.a.z) | (x.a.w ^ y.a.w) | (x.b.x ^ y.b.x) |
                 (x.b.y ^ y.b.y) | (x.b.z ^ y.b.z) | (x.b.w ^ y.b.w)) != 0;
     };
-    // sibling of chain `inst` at `lvl` levels above its leaf, as native words
-    auto sibling = [&](uint32_t ti, uint32_t inst, uint32_t lvl) {
-        const uint32_t len = s_len[ti];
-        const uint4 *tp = reinterpret_cast<const uint4 *>(batch + s_path[ti]) +
-                          ((size_t)(inst >> 6) * len + lvl) * 128 + (inst & 63);
-        H8 h = {tp[0], tp[64]};
+    // sibling of chain c of the group (first proof p0) at `lvl` levels above its leaf, as native words: the top
+    // min(T, len) levels of a tree are stored as top[proof][type][level][query][8], 32 contiguous bytes each
+    uint32_t p0 = 0;
+    auto sibling = [&](uint32_t ti, uint32_t c, uint32_t lvl) {
+        const uint32_t len = s_len[ti], top = lay.T < len ? lay.T : len, g = s_g[c];
+        const uint4 *tp = reinterpret_cast<const uint4 *>(batch + lay.off_top + (size_t)(p0 + g) * lay.top_words + s_topoff[ti]) +
+                          ((size_t)(lvl - (len - top)) * Q + (c - g * Q)) * 2;
+        H8 h = {tp[0], tp[1]};
         h.a.x = Hasher<HF>::native(h.a.x); h.a.y = Hasher<HF>::native(h.a.y);
         h.a.z = Hasher<HF>::native(h.a.z); h.a.w = Hasher<HF>::native(h.a.w);
         h.b.x = Hasher<HF>::native(h.b.x); h.b.y = Hasher<HF>::native(h.b.y);
@@ -626,7 +636,7 @@ __device__ __forceinline__ void stwo_top_body(const StwoLayout &lay, const uint3
         }
         __syncthreads();
         if (s_grp >= n_units) break;
-        const uint32_t p0 = s_grp * unit;
+        p0 = s_grp * unit;
         const uint32_t gp = lay.n - p0 < s_take * unit ? lay.n - p0 : s_take * unit;  // proofs of this group
         const uint32_t nch = gp * Q, inst0 = p0 * Q;
         if (tid < nch) {
@@ -745,13 +755,13 @@ __device__ __forceinline__ void stwo_top_body(const StwoLayout &lay, const uint3
                 const uint32_t c = s_item[dd][e], o = s_sibl[dd][e];
                 if (o == kNone) return;
                 x.a = node_at(ti, c, dd);
-                x.b = sibling(ti, inst0 + o, lvl);
+                x.b = sibling(ti, o, lvl);
                 x.g = s_g[c];
             } else {
                 const uint32_t c = s_fol[dd][e], c1 = s_lead[dd][c];
                 if (kind == 0) {  // same: a follower presents the sibling its leader presents
-                    x.a = sibling(ti, inst0 + c, lvl);
-                    x.b = sibling(ti, inst0 + c1, lvl);
+                    x.a = sibling(ti, c, lvl);
+                    x.b = sibling(ti, c1, lvl);
                 } else {          // edge: it enters with its leader's node
                     x.a = node_at(ti, c, dd);
                     x.b = node_at(ti, c1, dd);
@@ -786,20 +796,20 @@ __device__ __forceinline__ void stwo_top_body(const StwoLayout &lay, const uint3
                 k_ = i - ti_ * nlead;
                 const uint32_t c = s_item[d][k_], len = s_len[ti_];
                 nd_ = node_at(ti_, c, d + 1);
-                sb_ = sibling(ti_, inst0 + c, len - 1 - d);
+                sb_ = sibling(ti_, c, len - 1 - d);
                 fl_ = (s_query[c] >> (L - d - 1)) & 1;
                 const uint32_t y = d ? s_sibl[d][k_] : kNone;
-                if (y != kNone) { ys_ = sibling(ti_, inst0 + y, len - d); fl_ |= 2; }
+                if (y != kNone) { ys_ = sibling(ti_, y, len - d); fl_ |= 2; }
             };
             if (tid < total) fetch(tid, nd, sb, ys, ti, k, flags);
             for (uint32_t i = tid; i < total; i += kTopChains) {
                 H8 nd2 = zero8, sb2 = zero8, ys2 = zero8;
                 uint32_t ti2 = 0, k2 = 0, flags2 = 0;
                 if (i + kTopChains < total) fetch(i + kTopChains, nd2, sb2, ys2, ti2, k2, flags2);
-                Light x0, x1;
-                light_issue(li, x0);
-                light_issue(li + kTopChains, x1);
-                li += 2 * kTopChains;
+                Light x[kTopLights];
+#pragma unroll
+                for (uint32_t u = 0; u < kTopLights; u++) light_issue(li + u * kTopChains, x[u]);
+                li += kTopLights * kTopChains;
                 uint32_t a[8], b[8], lft[8], rgt[8], out[8];
                 unpack(nd, a);
                 unpack(sb, b);
@@ -816,8 +826,8 @@ __device__ __forceinline__ void stwo_top_body(const StwoLayout &lay, const uint3
                 o[1] = o8.b;
                 // (ii): the leader of the sibling position presents this node as its sibling
                 if ((flags & 2) && differ(o8, ys)) s_bad[ti][s_g[s_item[d][k]]] = 1;
-                light_settle(x0);
-                light_settle(x1);
+#pragma unroll
+                for (uint32_t u = 0; u < kTopLights; u++) light_settle(x[u]);
                 nd = nd2; sb = sb2; ys = ys2; ti = ti2; k = k2; flags = flags2;
             }
             // what this step's hash iterations did not carry (the shallow depths have more checks than
@@ -833,10 +843,13 @@ __device__ __forceinline__ void stwo_top_body(const StwoLayout &lay, const uint3
             __syncthreads();
         }
 
-        // ---- roots: at depth 0 proof g's only leader is its first chain, slot g
+        // ---- roots: at depth 0 proof g's only leader is its first chain, slot g.  A tree whose checks failed is
+        // flagged for stwo_top_cold_kernel, which re-hashes its Q chains one by one (merkle.simf:22-44 as written).
         for (uint32_t i = tid; i < gp * n_types; i += kTopChains) {
             const uint32_t ti = i / gp, g = i - ti * gp;
-            if (s_bad[ti][g]) continue;
+            const uint32_t badf = s_bad[ti][g];
+            ws[lay.ws_flag + (size_t)ti * np + p0 + g] = badf;
+            if (badf) { atomicAdd(counter + 1, 1u); continue; }
             const uint4 *v = vals + ((size_t)ti * kTopChains + g) * 2;  // parity 0
             uint32_t nd[8];
             unpack(H8{v[0], v[1]}, nd);
@@ -846,31 +859,51 @@ __device__ __forceinline__ void stwo_top_body(const StwoLayout &lay, const uint3
                 same &= nd[j] == Hasher<HF>::native(head[(size_t)(s_rootw[ti] + j) * np + p0 + g]);
             if (!same) atomicMin(&status[p0 + g], s_code[ti] + 1);  // all Q chains fail: query 0 is first
         }
-        // ---- flagged trees: every chain on its own, as merkle_verify_32 is written
-        for (uint32_t i = tid; i < nch * n_types; i += kTopChains) {
-            const uint32_t ti = i / nch, c = i - ti * nch, g = c / Q;
-            if (!s_bad[ti][g]) continue;
-            const uint32_t len = s_len[ti], top = lay.T < len ? lay.T : len;
-            const uint4 *v = topn + ((size_t)ti * nip + inst0 + c) * 2;
-            uint32_t nd[8];
-            unpack(H8{v[0], v[1]}, nd);
-            for (uint32_t d = top; d-- > 0;) {
-                uint32_t sib[8], lft[8], rgt[8];
-                unpack(sibling(ti, inst0 + c, len - 1 - d), sib);
-                const bool right = (s_query[c] >> (L - d - 1)) & 1;
+    }
+}
+
+// The cold path of the pair memoisation: trees in which two queries disagree about a node (flagged by
+// stwo_top_kernel) get every chain hashed on its own from where the tree entered the top kernel, exactly as
+// merkle_verify_32 is written.  An honest batch flags nothing: the kernel reads one counter and returns.
+template <int HF>
+__device__ __forceinline__ void stwo_top_cold_body(const StwoLayout &lay, const uint32_t *__restrict__ batch,
+                                                   const uint32_t *__restrict__ ws, uint32_t *__restrict__ status)
+{
+    if (ws[lay.ws_counter + 1] == 0) return;  // nothing flagged: the whole (small) grid leaves here
+    const uint32_t n_types = lay.K + 3, Q = lay.Q, L = lay.L, np = lay.np, nip = lay.nip;
+    const uint64_t total = (uint64_t)n_types * lay.ni, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {  // (type, proof, query)
+    const uint32_t ti = (uint32_t)(i / lay.ni), inst = (uint32_t)(i - (uint64_t)ti * lay.ni);
+    const uint32_t p = inst / Q, q = inst - p * Q;
+    if (!ws[lay.ws_flag + (size_t)ti * np + p]) continue;
+    const uint32_t l = ti < 2 ? 0 : ti - 2;
+    const uint32_t len = ti < 2 ? L : L - 1 - l, top = lay.T < len ? lay.T : len;
+    const uint32_t root_w = ti < 2 ? lay.h_roots + 8 * (ti + 1) : lay.h_fri_roots + 8 * l;
+    const uint32_t code = ti < 2 ? stwo_code(5, 0, q, 2 * ti) : stwo_code(7, l, q, 0);
+    const uint32_t query = ws[lay.ws_ctx + (size_t)(lay.c_queries + q) * np + p];
+    const uint4 *v = reinterpret_cast<const uint4 *>(ws + lay.ws_top) + ((size_t)ti * nip + inst) * 2;
+    uint32_t nd[8] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w};
+    const uint4 *tp = reinterpret_cast<const uint4 *>(batch + lay.off_top + (size_t)p * lay.top_words + lay.top_off[ti]);
+    for (uint32_t d = top; d-- > 0;) {
+        const uint4 *sp = tp + ((size_t)(top - 1 - d) * Q + q) * 2;  // level len - 1 - d, counted from the first top level
+        const uint4 s0 = sp[0], s1 = sp[1];
+        const uint32_t sib[8] = {Hasher<HF>::native(s0.x), Hasher<HF>::native(s0.y), Hasher<HF>::native(s0.z),
+                                 Hasher<HF>::native(s0.w), Hasher<HF>::native(s1.x), Hasher<HF>::native(s1.y),
+                                 Hasher<HF>::native(s1.z), Hasher<HF>::native(s1.w)};
+        const bool right = (query >> (L - d - 1)) & 1;
+        uint32_t lft[8], rgt[8];
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    lft[j] = right ? sib[j] : nd[j];
-                    rgt[j] = right ? nd[j] : sib[j];
-                }
-                Hasher<HF>::template pair<false>(lft, rgt, nd);
-            }
-            bool same = true;
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-                same &= nd[j] == Hasher<HF>::native(head[(size_t)(s_rootw[ti] + j) * np + p0 + g]);
-            if (!same) atomicMin(&status[p0 + g], s_code[ti] + ((c - g * Q) << 4) + 1);
+        for (int j = 0; j < 8; j++) {
+            lft[j] = right ? sib[j] : nd[j];
+            rgt[j] = right ? nd[j] : sib[j];
         }
+        Hasher<HF>::template pair<false>(lft, rgt, nd);
+    }
+    const uint32_t *head = batch + lay.off_head;
+    bool same = true;
+#pragma unroll
+    for (int j = 0; j < 8; j++) same &= nd[j] == Hasher<HF>::native(head[(size_t)(root_w + j) * np + p]);
+    if (!same) atomicMin(&status[p], code + 1);
     }
 }
 
@@ -886,17 +919,30 @@ stwo_merkle_kernel_b2s(StwoLayout lay, const uint32_t *__restrict__ batch, uint3
 {
     stwo_merkle_body<1>(lay, batch, ws, status);
 }
-__global__ void __launch_bounds__(kTopChains, 3)
+__global__ void __launch_bounds__(kTopChains, SS_TOP_WAVES)
 stwo_top_kernel_sha(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,
                     uint32_t *__restrict__ status)
 {
     stwo_top_body<0>(lay, batch, ws, status);
 }
-__global__ void __launch_bounds__(kTopChains, 3)
+__global__ void __launch_bounds__(kTopChains, SS_TOP_WAVES)
 stwo_top_kernel_b2s(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,
                     uint32_t *__restrict__ status)
 {
     stwo_top_body<1>(lay, batch, ws, status);
+}
+
+__global__ void __launch_bounds__(256)
+stwo_top_cold_kernel_sha(StwoLayout lay, const uint32_t *__restrict__ batch, const uint32_t *__restrict__ ws,
+                         uint32_t *__restrict__ status)
+{
+    stwo_top_cold_body<0>(lay, batch, ws, status);
+}
+__global__ void __launch_bounds__(256)
+stwo_top_cold_kernel_b2s(StwoLayout lay, const uint32_t *__restrict__ batch, const uint32_t *__restrict__ ws,
+                         uint32_t *__restrict__ status)
+{
+    stwo_top_cold_body<1>(lay, batch, ws, status);
 }
 
 // ============================================================================ finalize

@@ -24,10 +24,14 @@ PHASE_HEAD, PHASE_TAIL, PHASE_ALL = 1, 2, 3
 class Pipeline:
     """Keeps `depth` passes over resident batches in flight on two HIP streams: the HEAD half
     (transcript + query kernels, latency bound) of pass i+1 runs on the head stream while the
-    TAIL half (Merkle kernel, ALU bound) of pass i runs on the tail stream.  Merkle kernels
-    never overlap each other, so their event-measured durations stay meaningful."""
+    TAIL half (Merkle kernel, ALU bound) of pass i runs on the tail stream.  With one tail stream
+    (the default) Merkle kernels never overlap each other, so their event-measured durations stay
+    meaningful.  `tail_streams=2` alternates the TAIL halves over two streams: the drain of one Merkle
+    launch (its last, half-empty round of workgroups) overlaps the start of the next, which is worth a
+    few per cent when a launch is only a few milliseconds (one GPU's 8 192-proof share of a batch);
+    per-kernel durations measured under that overlap are inflated."""
 
-    def __init__(self, slots: Sequence["_DeviceBatch"]):
+    def __init__(self, slots: Sequence["_DeviceBatch"], tail_streams: int = 1):
         torch = _torch()
         self.slots = list(slots)
         dev = self.slots[0].ver.device
@@ -35,7 +39,8 @@ class Pipeline:
         # several of them also overlap each other; TAIL halves share one stream.
         self.head_streams = [torch.cuda.Stream(device=dev) for _ in self.slots]
         # (a high-priority tail stream was tried: no measurable effect on MI355X)
-        self.tail_stream = torch.cuda.Stream(device=dev)
+        self.tail_streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, tail_streams))]
+        self.tail_stream = self.tail_streams[0]
         self.comm_stream = torch.cuda.Stream(device=dev)  # accept-reduce, off the kernels' path
         self.head_done = [torch.cuda.Event() for _ in self.slots]
         self.tail_done = [None for _ in self.slots]
@@ -56,10 +61,11 @@ class Pipeline:
         # hipStreamEndCapture on ROCm 7.0 (tools/probes/graph_capture_probe.py)
         self.head_done[k] = torch.cuda.Event()
         self.head_done[k].record(hs)
-        self.tail_stream.wait_event(self.head_done[k])
-        slot.run(self.tail_stream, PHASE_TAIL)
+        ts = self.tail_streams[(self.i - 1) % len(self.tail_streams)]
+        ts.wait_event(self.head_done[k])
+        slot.run(ts, PHASE_TAIL)
         ev = torch.cuda.Event()
-        ev.record(self.tail_stream)
+        ev.record(ts)
         if after_tail is not None:
             # e.g. the RCCL accept-reduce: on its own stream, so the next Merkle kernel on the
             # tail stream never waits for a collective (or for a slower rank)
@@ -74,7 +80,8 @@ class Pipeline:
     def synchronize(self) -> None:
         for s in self.head_streams:
             s.synchronize()
-        self.tail_stream.synchronize()
+        for s in self.tail_streams:
+            s.synchronize()
         self.comm_stream.synchronize()
 
 
@@ -324,10 +331,12 @@ def stwo_cfg_struct(cfg: StwoConfig, mode: int, flags: int = 0) -> B.StwoCfg:
                      cfg.pow_target, 1 if cfg.hash == "blake2s" else 0, flags)
 
 
-def pack_stwo(cfg: StwoConfig, mode: int, records: Sequence[np.ndarray]) -> np.ndarray:
-    """records (one per proof; entries may repeat) -> host batch buffer (uint32)."""
+def pack_stwo(cfg: StwoConfig, mode: int, records: Sequence[np.ndarray], flags: int = 0) -> np.ndarray:
+    """records (one per proof; entries may repeat) -> host batch buffer (uint32).  A batch is laid out for
+    the cfg it will be verified with, hash family and SS_FLAG_* included (csrc/ss_layout.h: with pair
+    memoisation the top levels of every tree are stored per proof, not in the 64-chain tiles)."""
     L = B.lib()
-    cs = stwo_cfg_struct(cfg, mode)
+    cs = stwo_cfg_struct(cfg, mode, flags)
     want = L.ss_stwo_record_words(C.byref(cs))
     if want == 0:
         raise B.SsError(B.SS_ERR_ARG, "unsupported stwo config %r" % (cfg,))
@@ -412,7 +421,7 @@ class StwoDeviceBatch(_DeviceBatch):
         self.cs = stwo_cfg_struct(cfg, mode, ver.stwo_flags)
         if index is None:
             n = len(records)
-            packed = pack_stwo(cfg, mode, records)
+            packed = pack_stwo(cfg, mode, records, ver.stwo_flags)
         else:
             torch = _torch()
             n = len(index)
@@ -614,7 +623,7 @@ class Verifier:
         """Upload records as they are and re-tile them with ss_stwo_pack_dev; returns the batch
         tensor (int32 view of the u32 words)."""
         torch = _torch()
-        cs = stwo_cfg_struct(cfg, mode)
+        cs = stwo_cfg_struct(cfg, mode, self.stwo_flags)
         flat = np.ascontiguousarray(np.stack(records), dtype=np.uint32)
         rec_dev = _to_dev(flat.reshape(-1), self.device)
         words = B.lib().ss_stwo_batch_words(C.byref(cs), len(records))

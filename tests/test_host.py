@@ -117,11 +117,15 @@ def _tile_word(base, tile_len, inst, level, w):
     return base + (((inst >> 6) * tile_len + level) * 2 + (w >> 2)) * 256 + (inst & 63) * 4 + (w & 3)
 
 
-def test_stwo_record_and_pack_layout(stwo_prod):
+@pytest.mark.parametrize("flags", [0, verifier.FLAG_NO_DEDUP])
+def test_stwo_record_and_pack_layout(stwo_prod, flags):
+    """Every word of every record sits where csrc/ss_layout.h says.  With pair memoisation (flags 0: T = 6 top
+    levels at Q = 16) the 64-chain tiles hold the lowest len - T levels of a tree and the top ones live in
+    top[proof][type][level][query][8]; with SS_FLAG_NO_DEDUP every level is in the tiles."""
     cfg = stwo_prod.cfg
     rec = verifier.stwo_record(stwo_prod)
     lib = binding.lib()
-    cs = verifier.stwo_cfg_struct(cfg, verifier.MODE_FIXTURE)
+    cs = verifier.stwo_cfg_struct(cfg, verifier.MODE_FIXTURE, flags)
     assert rec.size == lib.ss_stwo_record_words(C.byref(cs))
     # the record is the algorithmic bytes + one length word per Merkle path
     assert rec.size * 4 == cfg.packed_bytes + 4 * (cfg.n_layers + 3) * cfg.n_queries
@@ -129,24 +133,35 @@ def test_stwo_record_and_pack_layout(stwo_prod):
     other = rec.copy()
     other[::7] ^= 0xA5A5A5A5
     recs = [rec if i % 2 == 0 else other for i in range(n)]
-    batch = verifier.pack_stwo(cfg, verifier.MODE_FIXTURE, recs)
+    batch = verifier.pack_stwo(cfg, verifier.MODE_FIXTURE, recs, flags)
     N, L, Q, K = cfg.n_cols, cfg.lde_log, cfg.n_queries, cfg.n_layers
+    T = 0 if flags else min((Q - 1).bit_length() + 2, L)
+    lens = [L, L] + [L - 1 - l for l in range(K + 1)]
+    tops = [min(T, ln) for ln in lens]
     npad, nip = 128, ((n * Q + 63) // 64) * 64
     head_words = 24 + 4 * N + 64 + 8 * (K + 1) + 4 + 2
     assert batch.size == lib.ss_stwo_batch_words(C.byref(cs), n)
-    # every word of every record sits where the documented layout says; nothing else is set
     expect = np.zeros_like(batch)
     off_head = 0
     off_tv = off_head + head_words * npad
     off_cv = off_tv + N * nip
     off_wit = off_cv + 16 * nip
     off_len = off_wit + (K + 1) * 4 * nip
-    off_tp = off_len + (K + 3) * nip
-    off_cp = off_tp + L * 8 * nip
-    off_fp = [off_cp + L * 8 * nip]
-    for l in range(K + 1):
-        off_fp.append(off_fp[-1] + (L - 1 - l) * 8 * nip)
-    assert off_fp[-1] == batch.size
+    off_tile = [off_len + (K + 3) * nip]
+    for ln, tp in zip(lens, tops):
+        off_tile.append(off_tile[-1] + (ln - tp) * 8 * nip)
+    off_top = off_tile[-1]
+    top_off = [0]
+    for tp in tops:
+        top_off.append(top_off[-1] + tp * Q * 8)
+    top_words = top_off[-1]
+    assert (off_top + top_words * n + 3) // 4 * 4 == batch.size
+
+    def path_word(kind, p, q, lv, w):
+        low = lens[kind] - tops[kind]
+        if lv < low:
+            return _tile_word(off_tile[kind], low, p * Q + q, lv, w)
+        return off_top + p * top_words + top_off[kind] + ((lv - low) * Q + q) * 8 + w
     for p, r in enumerate(recs):
         pos = 0
         for w in range(head_words):
@@ -157,10 +172,10 @@ def test_stwo_record_and_pack_layout(stwo_prod):
                 expect[off_tv + k * nip + inst] = r[pos]; pos += 1
             for k in range(16):
                 expect[off_cv + k * nip + inst] = r[pos]; pos += 1
-            for base in (off_tp, off_cp):
+            for kind in (0, 1):
                 for lv in range(L):
                     for w in range(8):
-                        expect[_tile_word(base, L, inst, lv, w)] = r[pos]; pos += 1
+                        expect[path_word(kind, p, q, lv, w)] = r[pos]; pos += 1
         for l in range(K + 1):
             ln = L - 1 - l
             for q in range(Q):
@@ -169,7 +184,7 @@ def test_stwo_record_and_pack_layout(stwo_prod):
                     expect[off_wit + (l * 4 + w) * nip + inst] = r[pos]; pos += 1
                 for lv in range(ln):
                     for w in range(8):
-                        expect[_tile_word(off_fp[l], ln, inst, lv, w)] = r[pos]; pos += 1
+                        expect[path_word(2 + l, p, q, lv, w)] = r[pos]; pos += 1
         for kind in range(K + 3):
             for q in range(Q):
                 expect[off_len + kind * nip + p * Q + q] = r[pos]; pos += 1
