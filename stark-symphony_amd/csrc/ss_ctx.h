@@ -9,12 +9,11 @@
 #include <vector>
 
 #include "../../include/ss_verify.h"
+#include "ss_pack.h"
 #include "ss_pool.h"
 #include "ss_text.h"
 
 namespace ss {
-
-int set_err(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
@@ -103,7 +102,6 @@ struct Timer {
 int grow(GrowBuf &b, size_t bytes, bool pinned);  // (re)allocates when too small; contents are not kept
 void release(GrowBuf &b);
 
-bool cfg_ok(const ss_stwo_cfg *c);
 double now_s();
 bool read_file(const char *path, std::string &out);
 

@@ -72,7 +72,9 @@ struct StwoLayout {
 };
 
 constexpr uint32_t kTopChains = 256;     // chains a top-kernel block plans at once (= its threads)
-constexpr uint32_t kTopMaxBlocks = 2048;  // workspace slices; the launch uses min(groups, resident blocks)
+// workspace slices of the persistent top kernel.  The launch uses min(groups, blocks resident at once), and at
+// 256 threads and >= 123 VGPRs per lane at most 4 blocks fit a CU (3 for SHA-256): 1024 on the 256 CUs of an MI355X.
+constexpr uint32_t kTopMaxBlocks = 1024;
 
 SS_HD inline uint32_t ceil_log2(uint32_t v)
 {

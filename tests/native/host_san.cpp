@@ -1,0 +1,156 @@
+// Sanitizer driver of the library's host code that indexes caller-owned buffers: the record -> batch
+// packers (csrc/ss_pack.cpp), the canonical text writers, the template builder and the scalar statement of
+// the GPU reader's rule (csrc/ss_text.cpp).  Built by tests/test_sanitizers.py with
+//   g++ -fsanitize=address,undefined -fno-sanitize-recover=all
+// Exact-size heap buffers make any out-of-bounds index an ASan report; UBSan catches shifts / overflows.
+//
+//   host_san <seed> <mutants> file.json file.wit     (the reference's production proof in both formats)
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "ss_ingest.h"
+#include "ss_pack.h"
+#include "ss_text.h"
+
+int ss::set_err(int code, const char *, ...) { return code; }  // (the library's lives in ss_api.hip)
+
+static uint64_t rng_state;
+static uint32_t rnd()
+{
+    rng_state = rng_state * 6364136223846793005ull + 1442695040888963407ull;
+    return (uint32_t)(rng_state >> 33);
+}
+
+static std::string slurp(const char *path)
+{
+    std::ifstream f(path, std::ios::binary);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    return ss.str();
+}
+
+static std::string mutate(const std::string &s)
+{
+    std::string m = s;
+    const int n_edits = 1 + rnd() % 3;
+    for (int e = 0; e < n_edits && !m.empty(); e++) {
+        const size_t at = rnd() % m.size();
+        switch (rnd() % 7) {
+        case 0: m[at] = (char)(m[at] ^ (1 << (rnd() % 8))); break;
+        case 1: m.erase(at, 1 + rnd() % 40); break;
+        case 2: m.insert(at, m.substr(at, 1 + rnd() % 60)); break;
+        case 3: m.resize(at); break;
+        case 4: m[at] = "0123456789"[rnd() % 10]; break;
+        case 5: m[at] = "[](){},:\" x_"[rnd() % 12]; break;
+        default: m.insert(at, std::string(1 + rnd() % 90, (char)('0' + rnd() % 10))); break;
+        }
+    }
+    return m;
+}
+
+static ss_stwo_cfg make_cfg(uint32_t N, uint32_t TL, uint32_t L, uint32_t Q, uint32_t K, uint32_t hash, uint32_t flags)
+{
+    ss_stwo_cfg c;
+    memset(&c, 0, sizeof c);
+    c.n_cols = N; c.trace_log = TL; c.lde_log = L; c.n_queries = Q; c.n_layers = K; c.mode = 1;
+    c.pow_target = 0x07ffffffffffffffull; c.hash = hash; c.flags = flags;
+    return c;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 5) { fprintf(stderr, "usage: host_san seed mutants proof.json proof.wit\n"); return 2; }
+    rng_state = strtoull(argv[1], nullptr, 10);
+    const int mutants = atoi(argv[2]);
+    size_t checks = 0;
+
+    // ---- packers: random records, every word of the batch accounted for, exact-size buffers
+    const uint32_t shapes[][5] = {{4, 9, 13, 16, 8}, {4, 3, 4, 1, 2}, {1, 1, 2, 1, 0}, {7, 5, 9, 3, 4}, {40, 6, 10, 64, 3}, {4, 16, 20, 32, 15}};
+    for (const auto &sh : shapes)
+        for (uint32_t hash = 0; hash < 2; hash++)
+            for (uint32_t flags = 0; flags < 2; flags++) {
+                const ss_stwo_cfg c = make_cfg(sh[0], sh[1], sh[2], sh[3], sh[4], hash, flags);
+                const size_t W = ss_stwo_record_words(&c);
+                if (!W) { fprintf(stderr, "config refused\n"); return 1; }
+                for (size_t n : {(size_t)1, (size_t)5, (size_t)64, (size_t)131}) {
+                    std::vector<std::vector<uint32_t>> recs(3, std::vector<uint32_t>(W));
+                    for (auto &r : recs)
+                        for (auto &w : r) w = rnd() | 1u;  // non-zero: zeros in the batch are padding only
+                    std::vector<const uint32_t *> ptrs(n);
+                    for (size_t i = 0; i < n; i++) ptrs[i] = recs[i % 3].data();
+                    const size_t words = ss_stwo_batch_words(&c, n);
+                    uint32_t *batch = new uint32_t[words];  // exact size: ASan sees any overrun
+                    if (ss_stwo_pack(&c, n, ptrs.data(), batch) != SS_OK) { fprintf(stderr, "pack failed\n"); return 1; }
+                    size_t nonzero = 0;
+                    for (size_t i = 0; i < words; i++) nonzero += batch[i] != 0;
+                    if (nonzero != n * W) { fprintf(stderr, "pack is not a permutation: %zu of %zu words\n", nonzero, n * W); return 1; }
+                    delete[] batch;
+                    checks++;
+                }
+            }
+    for (uint32_t ml : {0u, 1u, 10u, 31u})
+        for (uint32_t pm : {0u, 4u, 13u, 31u}) {
+            ss_s101_shape sh = {ml, pm};
+            const size_t W = ss_s101_record_words(&sh);
+            std::vector<uint32_t> rec(W);
+            for (auto &w : rec) w = rnd() | 1u;
+            for (size_t n : {(size_t)1, (size_t)65}) {
+                std::vector<const uint32_t *> ptrs(n, rec.data());
+                const size_t words = ss_s101_batch_words(&sh, n);
+                uint32_t *batch = new uint32_t[words];
+                if (ss_s101_pack(&sh, n, ptrs.data(), batch) != SS_OK) { fprintf(stderr, "s101 pack failed\n"); return 1; }
+                size_t nonzero = 0;
+                for (size_t i = 0; i < words; i++) nonzero += batch[i] != 0;
+                if (nonzero != n * W) { fprintf(stderr, "s101 pack is not a permutation\n"); return 1; }
+                delete[] batch;
+                checks++;
+            }
+        }
+
+    // ---- writers, templates and the scalar rule, on the reference's proof and its mutants
+    const ss_stwo_cfg prod = make_cfg(4, 9, 13, 16, 8, 0, 0);
+    const size_t W = ss_stwo_record_words(&prod);
+    size_t taken = 0;
+    for (int f = 0; f < 2; f++) {
+        const int fmt = f == 0 ? SS_TEXT_JSON : SS_TEXT_WIT;
+        const std::string base = slurp(argv[3 + f]);
+        ss::TextTemplateHost t;
+        ss::stwo_build_template(prod, fmt, t);
+        if (!t.ok) { fprintf(stderr, "no template\n"); return 1; }
+        uint32_t *rec = new uint32_t[W];  // exact size
+        if (!ss::text_scan_reference(t.view(), base.data(), base.size(), rec)) { fprintf(stderr, "reference file not canonical\n"); return 1; }
+        std::string back;
+        const bool ok = fmt == SS_TEXT_JSON ? ss::stwo_write_json(prod, rec, ss::kStyleCompact, back) : ss::stwo_write_wit(prod, rec, back);
+        if (!ok || back.size() + 2 < base.size()) { fprintf(stderr, "writer does not reproduce the file\n"); return 1; }
+        for (int i = 0; i < mutants; i++) {
+            const std::string m = mutate(base);
+            char *exact = new char[m.size() ? m.size() : 1];  // no terminator, no slack
+            memcpy(exact, m.data(), m.size());
+            taken += ss::text_scan_reference(t.view(), exact, m.size(), rec);
+            delete[] exact;
+            checks++;
+        }
+        delete[] rec;
+    }
+    // templates of awkward configs (zero inner layers, one query, many columns, no JSON for an odd pow_target)
+    for (const auto &sh : shapes) {
+        ss_stwo_cfg c = make_cfg(sh[0], sh[1], sh[2], sh[3], sh[4], 1, 0);
+        ss::TextTemplateHost a, b;
+        ss::stwo_build_template(c, SS_TEXT_JSON, a);
+        ss::stwo_build_template(c, SS_TEXT_WIT, b);
+        c.pow_target = 12345;
+        ss::TextTemplateHost d;
+        ss::stwo_build_template(c, SS_TEXT_JSON, d);
+        if (!a.ok || !b.ok || d.ok) { fprintf(stderr, "template of a supported config missing (or made for an odd pow_target)\n"); return 1; }
+        checks++;
+    }
+    printf("host_san: %zu checks, %zu mutants taken by the scalar rule\n", checks, taken);
+    return 0;
+}
