@@ -174,6 +174,30 @@ def time_simfony(exe: str):
                 "sample": "%d x `simfony run` of the stark101 proof" % n}
 
 
+def end_to_end_s101(ver, proof, n: int):
+    """stark101 texts (the one valid proof replicated: SURVEY.md F3) -> verdicts through ss_s101_verify_texts."""
+    import stark_symphony_amd as ss
+    from stark_symphony_amd import binding
+    texts = {"json": json.dumps(ss.stark101_to_json(proof)).encode(), "wit": ss.stark101_to_wit(proof).encode()}
+    out = {"proofs": n, "note": "stark101 proof text -> verdict through ss_s101_verify_texts (GPU reader, host link included)"}
+    for kind, fmt in (("json", binding.TEXT_JSON), ("wit", binding.TEXT_WIT)):
+        batch = [texts[kind]] * n
+        ver.verify_stark101_texts(batch[:64], fmt=fmt)
+        ver.verify_stark101_texts(batch, fmt=fmt)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            status, st = ver.verify_stark101_texts(batch, fmt=fmt)
+            dt = time.perf_counter() - t0
+            assert (status == 0).all(), "e2e: the stark101 proof was not accepted"
+            if best is None or dt < best[0]:
+                best = (dt, st)
+        dt, st = best
+        out[kind] = {"proofs_per_s": n / dt, "total_s": dt, "text_GB_per_s": st["text_bytes"] / dt / 1e9,
+                     "host_parsed_texts": st["host_parsed"], "text_bytes_per_proof": st["text_bytes"] // n}
+    return out
+
+
 def end_to_end(ver, proofs, n: int):
     """Text in, verdicts out (never `value`): what a caller holding proof.json / proof.wit files sees.
     n texts of this workload's proofs go through ss_stwo_verify_texts -- native readers on the host
@@ -597,6 +621,8 @@ def main() -> None:
         }
         if family == "stwo" and args.e2e > 0 and world == 1:
             out["e2e"] = end_to_end(ver, proofs, args.e2e)
+        elif family == "stark101" and args.e2e > 0 and world == 1:
+            out["e2e"] = end_to_end_s101(ver, proofs[0], max(args.e2e, 16384))
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(family, proofs, args.cpu_seconds)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

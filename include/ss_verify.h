@@ -165,6 +165,11 @@ void ss_ctx_destroy(ss_ctx *ctx);
 int ss_stwo_pack_dev(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const uint32_t *records_dev,
                      uint32_t *batch_dev, void *stream);
 
+/* The same for stark101: records_dev holds n records of `shape` back to back, batch_dev receives
+ * ss_s101_batch_words words (the permutation of ss_s101_pack).                                      */
+int ss_s101_pack_dev(ss_ctx *ctx, const ss_s101_shape *shape, size_t n, const uint32_t *records_dev,
+                     uint32_t *batch_dev, void *stream);
+
 /* Device-resident entry points: every pointer is device memory on ctx's GPU, `stream` is a
  * hipStream_t (NULL = default stream).  Asynchronous; status_dev is valid once the stream
  * has drained.  accept_count_dev (may be NULL) receives the
@@ -238,7 +243,7 @@ typedef struct ss_ingest_stats {
     uint32_t host_parsed; /* texts that went through the host reader (0 for canonical texts) */
 } ss_ingest_stats;
 
-/* Texts / files -> verdicts, synchronous.  stwo: the raw bytes are uploaded in pinned chunks and turned
+/* Texts / files -> verdicts, synchronous.  The raw bytes are uploaded in pinned chunks and turned
  * into records ON THE GPU (csrc/ss_textdev.hip): a text that is, byte for byte, what the reference's
  * producers write for the expected config -- proof.json as the external prover / json.dumps prints it
  * (tests/data/proof.json), proof.wit as generate_wit.py:218-243 prints it -- except for its numbers and
@@ -246,6 +251,9 @@ typedef struct ss_ingest_stats {
  * order, escapes, non-canonical numbers, another shape, not a witness at all) is handed to the host
  * reader behind ss_stwo_parse, which alone decides parsed / SS_STATUS_CONFIG_MISMATCH /
  * SS_STATUS_MALFORMED.  Chunks are staged, uploaded, read, re-tiled and verified in a pipeline.
+ * stark101 has canonical texts for the protocol's proof shape (10 layers, paths of 13 / 13 - layer siblings:
+ * prover.py:108,143-167 and stark101/scripts/generate_wit.py:13-30); proofs of other shapes -- which no honest
+ * prover makes -- are read by the host reader and verified in a batch of their own shape.
  * status_host[i] is the verdict of input i (stage-0 codes above included).  stats may be NULL.      */
 int ss_stwo_verify_texts(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const char *const *texts,
                          const size_t *lens, int fmt, uint32_t *status_host, ss_ingest_stats *stats);
@@ -269,11 +277,21 @@ size_t ss_stwo_write_text(const ss_stwo_cfg *cfg, const uint32_t *record, int fm
  * returns 1 and record_out is not NULL, record_out holds the record.  No GPU involved.              */
 int ss_stwo_text_is_canonical(const ss_stwo_cfg *cfg, const char *text, size_t len, int fmt, uint32_t *record_out);
 
+/* stark101 twins.  The protocol fixes the shape of a stark101 proof (10 FRI layers, Merkle paths of 13 and
+ * 13 - layer siblings: stark101/scripts/fibsquare/prover.py:94-171), so canonical texts exist for that shape only;
+ * records here have shape {max_layers 10, max_path 13}.  ss_s101_write_text prints what prover.py's proof.json
+ * (json.dumps, `python_separators` as above) resp. stark101/scripts/generate_wit.py:13-30 print.                  */
+size_t ss_s101_write_text(const uint32_t *record, int fmt, int python_separators, char *buf, size_t cap);
+int ss_s101_text_is_canonical(const char *text, size_t len, int fmt, uint32_t *record_out);
+
 /* The GPU reader alone (diagnostic): n texts of format fmt (SS_TEXT_JSON / SS_TEXT_WIT) -> records_host
  * (n * ss_stwo_record_words words) and outcome_host[i] = 0 (canonical: record i written by the GPU) or 1
  * (left to the host reader; record i unspecified).  Synchronous; outcome equals ss_stwo_text_is_canonical. */
 int ss_stwo_read_texts(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const char *const *texts, const size_t *lens,
                        int fmt, uint32_t *records_host, uint32_t *outcome_host);
+
+int ss_s101_read_texts(ss_ctx *ctx, size_t n, const char *const *texts, const size_t *lens, int fmt,
+                       uint32_t *records_host, uint32_t *outcome_host); /* records of shape {10, 13} */
 
 /* Per-stage intermediates of one proof after a verify call (the reference's counterpart is the
  * debug tracker of `simfony run`, simfony-cli/src/tracker.rs:48-80, which prints the values a

@@ -62,6 +62,7 @@ EXPORTS = [
     "ss_s101_verify_phase_dev", "ss_stwo_verify_phase_dev", "ss_stwo_pack_dev",
     "ss_s101_verify_records", "ss_stwo_verify_records", "ss_ctx_set_timing", "ss_ctx_collect_timing",
     "ss_selftest", "ss_stwo_write_text", "ss_stwo_text_is_canonical", "ss_stwo_read_texts",
+    "ss_s101_write_text", "ss_s101_text_is_canonical", "ss_s101_pack_dev", "ss_s101_read_texts",
 ]
 
 _lib = None
@@ -111,6 +112,7 @@ def lib() -> C.CDLL:
     sig("ss_s101_verify_phase_dev", C.c_int, vp, sp, sz, vp, vp, sz, vp, vp, C.c_int, vp)
     sig("ss_stwo_verify_phase_dev", C.c_int, vp, cp, sz, vp, vp, sz, vp, vp, C.c_int, vp)
     sig("ss_stwo_pack_dev", C.c_int, vp, cp, sz, vp, vp, vp)
+    sig("ss_s101_pack_dev", C.c_int, vp, sp, sz, vp, vp, vp)
     sig("ss_s101_verify_records", C.c_int, vp, sp, sz, pp, vp)
     sig("ss_stwo_verify_records", C.c_int, vp, cp, sz, pp, vp)
     sig("ss_ctx_set_timing", C.c_int, vp, C.c_int)
@@ -123,11 +125,14 @@ def lib() -> C.CDLL:
     sig("ss_s101_verify_texts", C.c_int, vp, sz, cpp, szp, C.c_int, vp, stp)
     sig("ss_s101_verify_files", C.c_int, vp, sz, cpp, C.c_int, vp, stp)
     sig("ss_stwo_read_texts", C.c_int, vp, cp, sz, cpp, szp, C.c_int, vp, vp)
+    sig("ss_s101_read_texts", C.c_int, vp, sz, cpp, szp, C.c_int, vp, vp)
     sig("ss_stwo_ws_layout_of", C.c_int, cp, sz, C.POINTER(StwoWsLayout))
     sig("ss_stwo_read_intermediates", C.c_int, vp, cp, sz, vp, sz, vp, vp, vp, vp, vp, vp)
     sig("ss_selftest", C.c_int, vp, C.c_int, sz, vp, vp)
     sig("ss_stwo_write_text", sz, cp, vp, C.c_int, C.c_int, vp, sz)
     sig("ss_stwo_text_is_canonical", C.c_int, cp, C.c_char_p, sz, C.c_int, vp)
+    sig("ss_s101_write_text", sz, vp, C.c_int, C.c_int, vp, sz)
+    sig("ss_s101_text_is_canonical", C.c_int, C.c_char_p, sz, C.c_int, vp)
     _lib = L
     return L
 

@@ -489,6 +489,69 @@ extern "C" int ss_stwo_pack_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, con
     return SS_OK;
 }
 
+// ------------------------------------------------------------ device-side packing (stark101)
+namespace ss {
+// one word of the batch per thread (ss_layout.h: head[w][proof], leaf / len[type][proof], path tiles per type)
+__global__ void s101_pack_kernel(S101Layout y, const uint32_t *__restrict__ rec, uint32_t *__restrict__ out)
+{
+    const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= y.total_words) return;
+    const uint32_t chain = 2 + 8 * y.PM;
+    const uint64_t W = s101_record_words(y.ML, y.PM);
+    auto chain_base = [&](uint32_t type) {  // record offset of chain `type`: ev, len, path
+        if (type < 3) return 10 + type * chain;
+        const uint32_t i = (type - 3) >> 1, which = (type - 3) & 1;
+        return 10 + 3 * chain + i * (9 + 2 * chain) + 9 + which * chain;
+    };
+    uint32_t v = 0;
+    if (d < y.off_leaf) {
+        const uint32_t w = (uint32_t)(d / y.np), p = (uint32_t)(d - (uint64_t)w * y.np);
+        if (p < y.n) {
+            uint32_t src;
+            if (w < y.h_layer) src = w;  // root[8], n_layers, last
+            else { const uint32_t i = (w - y.h_layer) / 9, j = (w - y.h_layer) - 9 * i; src = 10 + 3 * chain + i * (9 + 2 * chain) + j; }
+            v = rec[(uint64_t)p * W + src];
+        }
+    } else if (d < y.off_path) {
+        const bool is_len = d >= y.off_len;
+        const uint64_t e = d - (is_len ? y.off_len : y.off_leaf);
+        const uint32_t type = (uint32_t)(e / y.np), p = (uint32_t)(e - (uint64_t)type * y.np);
+        if (p < y.n) v = rec[(uint64_t)p * W + chain_base(type) + (is_len ? 1 : 0)];
+    } else {
+        const uint64_t e = d - y.off_path;
+        const uint32_t type = (uint32_t)(e / y.path_stride);
+        const uint64_t r = e - (uint64_t)type * y.path_stride;
+        const uint32_t lane4 = (uint32_t)(r & 255), lane = lane4 >> 2, wlo = lane4 & 3;
+        const uint64_t r2 = r >> 8;
+        const uint32_t half = (uint32_t)(r2 & 1);
+        const uint64_t r3 = r2 >> 1;  // g * PM + level
+        const uint32_t g = (uint32_t)(r3 / y.PM), level = (uint32_t)(r3 - (uint64_t)g * y.PM);
+        const uint32_t p = g * 64 + lane;
+        if (p < y.n) v = rec[(uint64_t)p * W + chain_base(type) + 2 + level * 8 + half * 4 + wlo];
+    }
+    out[d] = v;
+}
+}  // namespace ss
+
+extern "C" int ss_s101_pack_dev(ss_ctx *ctx, const ss_s101_shape *sh, size_t n, const uint32_t *records_dev,
+                                uint32_t *batch_dev, void *stream_)
+{
+    if (!ctx) return set_err(SS_ERR_ARG, "ctx is null");
+    if (!shape_ok(sh)) return set_err(SS_ERR_ARG, "unsupported stark101 shape");
+    if (!n || !records_dev || !batch_dev) return set_err(SS_ERR_ARG, "null/empty argument");
+    if (n > 0x7fffffffu) return set_err(SS_ERR_ARG, "batch too large");
+    const S101Layout y = s101_layout(sh->max_layers, sh->max_path, n);
+    if (!y.total_words) return SS_OK;
+    hipStream_t s = (hipStream_t)stream_;
+    Timer t(ctx, s);
+    t.begin();
+    hipLaunchKernelGGL(s101_pack_kernel, dim3((unsigned)((y.total_words + 255) / 256)), dim3(256), 0, s, y, records_dev,
+                       batch_dev);
+    t.end("s101_pack");
+    HIP_TRY(hipGetLastError());
+    return SS_OK;
+}
+
 static int hp_reserve(ss_ctx *ctx, int slot, size_t bytes)
 {
     HostPath &hp = ctx->hp;
@@ -562,11 +625,18 @@ extern "C" int ss_stwo_verify_records(ss_ctx *ctx, const ss_stwo_cfg *c, size_t 
 extern "C" int ss_s101_verify_records(ss_ctx *ctx, const ss_s101_shape *sh, size_t n,
                                       const uint32_t *const *records, uint32_t *status_host)
 {
+    if (!ctx) return set_err(SS_ERR_ARG, "null argument");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    return s101_verify_records_locked(ctx, sh, n, records, status_host);
+}
+
+int ss::s101_verify_records_locked(ss_ctx *ctx, const ss_s101_shape *sh, size_t n, const uint32_t *const *records,
+                                   uint32_t *status_host)
+{
     if (!ctx || !status_host || !records) return set_err(SS_ERR_ARG, "null argument");
     if (!shape_ok(sh)) return set_err(SS_ERR_ARG, "unsupported stark101 shape");
     if (!n) return set_err(SS_ERR_ARG, "empty batch");
     if (n > 0x7fffffffu) return set_err(SS_ERR_ARG, "batch too large");
-    std::lock_guard<std::mutex> lock(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t words = ss_s101_batch_words(sh, n), wsb = ss_s101_workspace_bytes(sh, n);
     int rc;
@@ -636,6 +706,29 @@ extern "C" int ss_stwo_text_is_canonical(const ss_stwo_cfg *c, const char *text,
     return text_scan_reference(h.view(), text, len, rec) ? 1 : 0;
 }
 
+extern "C" size_t ss_s101_write_text(const uint32_t *record, int fmt, int python_separators, char *buf, size_t cap)
+{
+    if (!record || (fmt != SS_TEXT_JSON && fmt != SS_TEXT_WIT)) { set_err(SS_ERR_ARG, "bad argument"); return 0; }
+    std::string out;
+    const bool ok = fmt == SS_TEXT_JSON ? s101_write_json(record, python_separators ? kStylePython : kStyleCompact, out)
+                                        : s101_write_wit(record, out);
+    if (!ok) { set_err(SS_ERR_ARG, "the record's path lengths are not the protocol's"); return 0; }
+    if (buf && out.size() <= cap) memcpy(buf, out.data(), out.size());
+    return out.size();
+}
+
+extern "C" int ss_s101_text_is_canonical(const char *text, size_t len, int fmt, uint32_t *record_out)
+{
+    if (!text || (fmt != SS_TEXT_JSON && fmt != SS_TEXT_WIT)) return set_err(SS_ERR_ARG, "bad argument");
+    TextTemplateHost h;
+    s101_build_template(fmt, h);
+    if (!h.ok) return 0;
+    std::vector<uint32_t> scratch(h.record_words, 0);
+    uint32_t *rec = record_out ? record_out : scratch.data();
+    if (record_out) memset(record_out, 0, (size_t)h.record_words * 4);  // shorter paths leave zero padding
+    return text_scan_reference(h.view(), text, len, rec) ? 1 : 0;
+}
+
 double ss::now_s()
 {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -670,79 +763,28 @@ extern "C" int ss_stwo_read_texts(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, c
     return stwo_read_texts_dev(ctx, c, n, texts, lens, fmt, records_host, outcome_host);
 }
 
+extern "C" int ss_s101_read_texts(ss_ctx *ctx, size_t n, const char *const *texts, const size_t *lens, int fmt,
+                                  uint32_t *records_host, uint32_t *outcome_host)
+{
+    return stwo_read_texts_dev(ctx, nullptr, n, texts, lens, fmt, records_host, outcome_host);
+}
+
 extern "C" int ss_stwo_verify_files(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *const *paths, int fmt,
                                     uint32_t *status_host, ss_ingest_stats *stats)
 {
     return stwo_ingest_dev(ctx, c, n, nullptr, nullptr, paths, fmt, status_host, stats);
 }
 
-// stark101: parse everything (the shape of the batch is the largest proof's), then records -> GPU
-static int s101_ingest(ss_ctx *ctx, size_t n, const char *const *texts, const size_t *lens, const char *const *paths,
-                       int fmt, uint32_t *status_host, ss_ingest_stats *stats)
-{
-    if (!ctx || !status_host || (!texts && !paths) || (texts && !lens)) return set_err(SS_ERR_ARG, "null argument");
-    if (!n) return set_err(SS_ERR_ARG, "empty batch");
-    if (fmt < SS_TEXT_AUTO || fmt > SS_TEXT_WIT) return set_err(SS_ERR_ARG, "unknown text format");
-    const double t0 = now_s();
-    const unsigned threads = effective_cpus();
-    std::vector<S101Parsed *> parsed(n, nullptr);
-    std::vector<uint64_t> tbytes(n, 0);
-    parallel_for(n, [&](size_t i) {
-        if (paths) {
-            std::string text;
-            if (read_file(paths[i], text)) parsed[i] = s101_parse_text(text.data(), text.size(), fmt);
-            tbytes[i] = text.size();
-        } else {
-            parsed[i] = s101_parse_text(texts[i], lens[i], fmt);
-            tbytes[i] = lens[i];
-        }
-    }, threads);
-    ss_s101_shape sh = {0, 0};
-    for (size_t i = 0; i < n; i++)
-        if (parsed[i]) {
-            uint32_t nl, pm;
-            s101_parsed_shape(parsed[i], &nl, &pm);
-            sh.max_layers = std::max(sh.max_layers, nl);
-            sh.max_path = std::max(sh.max_path, pm);
-        }
-    const size_t W = ss_s101_record_words(&sh);
-    std::vector<uint32_t> recs(n * W, 0);
-    std::vector<const uint32_t *> ptrs(n);
-    parallel_for(n, [&](size_t i) {
-        if (parsed[i]) s101_parsed_record(parsed[i], sh, recs.data() + i * W);
-        ptrs[i] = recs.data() + i * W;
-    }, threads);
-    const double parse_s = now_s() - t0;
-    int rc = ss_s101_verify_records(ctx, &sh, n, ptrs.data(), status_host);
-    uint64_t tb = 0;
-    for (size_t i = 0; i < n; i++) {
-        if (!parsed[i]) status_host[i] = SS_STATUS_MALFORMED;
-        else s101_parsed_free(parsed[i]);
-        tb += tbytes[i];
-    }
-    if (rc) return rc;
-    if (stats) {
-        stats->read_s = 0;
-        stats->parse_s = parse_s;
-        stats->total_s = now_s() - t0;
-        stats->text_bytes = tb;
-        stats->record_bytes = (uint64_t)n * W * 4;
-        stats->threads = threads;
-        stats->host_parsed = (uint32_t)n;  // stark101 texts are read by the host reader
-    }
-    return SS_OK;
-}
-
 extern "C" int ss_s101_verify_texts(ss_ctx *ctx, size_t n, const char *const *texts, const size_t *lens, int fmt,
                                     uint32_t *status_host, ss_ingest_stats *stats)
 {
-    return s101_ingest(ctx, n, texts, lens, nullptr, fmt, status_host, stats);
+    return s101_ingest_dev(ctx, n, texts, lens, nullptr, fmt, status_host, stats);
 }
 
 extern "C" int ss_s101_verify_files(ss_ctx *ctx, size_t n, const char *const *paths, int fmt, uint32_t *status_host,
                                     ss_ingest_stats *stats)
 {
-    return s101_ingest(ctx, n, nullptr, nullptr, paths, fmt, status_host, stats);
+    return s101_ingest_dev(ctx, n, nullptr, nullptr, paths, fmt, status_host, stats);
 }
 
 // =========================================================================== self-test

@@ -108,6 +108,11 @@ bool read_file(const char *path, std::string &out);
 // texts (or files) -> verdicts through the GPU reader (csrc/ss_ingest_dev.hip)
 int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *const *texts, const size_t *lens,
                     const char *const *paths, int fmt, uint32_t *status_host, ss_ingest_stats *stats);
+int s101_ingest_dev(ss_ctx *ctx, size_t n, const char *const *texts, const size_t *lens, const char *const *paths, int fmt,
+                    uint32_t *status_host, ss_ingest_stats *stats);
+// ss_s101_verify_records for a caller that already holds ctx->mu
+int s101_verify_records_locked(ss_ctx *ctx, const ss_s101_shape *sh, size_t n, const uint32_t *const *records,
+                               uint32_t *status_host);
 int stwo_read_texts_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *const *texts, const size_t *lens,
                         int fmt, uint32_t *records_host, uint32_t *outcome_host);
 void text_path_destroy(TextPath &tp);

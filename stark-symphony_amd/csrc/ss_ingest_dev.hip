@@ -22,6 +22,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -98,20 +99,26 @@ int template_of(ss_ctx *ctx, const ss_stwo_cfg &cfg, int fmt, hipStream_t s, Tex
         tp.templates.erase(tp.templates.begin());
     }
     TextTemplateHost h;
-    stwo_build_template(cfg, fmt, h);
+    if (cfg.n_cols == 0) s101_build_template(fmt, h);  // the key s101_ingest_dev uses
+    else stwo_build_template(cfg, fmt, h);
     DevTemplate d{};
     d.cfg = cfg; d.fmt = fmt; d.ok = h.ok;
     if (h.ok) {
         HIP_TRY(hipMalloc(&d.skel, h.skel.size()));
         HIP_TRY(hipMalloc(&d.slots, h.slots.size() * sizeof(TextSlot)));
-        HIP_TRY(hipMalloc(&d.trailer, h.trailer.size() * 4));
+        const size_t tail_words = h.trailer.size() + h.fixed.size();  // trailer values, then the (word, value) pairs
+        HIP_TRY(hipMalloc(&d.trailer, std::max<size_t>(tail_words, 1) * 4));
         HIP_TRY(hipMemcpy(d.skel, h.skel.data(), h.skel.size(), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(d.slots, h.slots.data(), h.slots.size() * sizeof(TextSlot), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(d.trailer, h.trailer.data(), h.trailer.size() * 4, hipMemcpyHostToDevice));
+        if (!h.trailer.empty())
+            HIP_TRY(hipMemcpy(d.trailer, h.trailer.data(), h.trailer.size() * 4, hipMemcpyHostToDevice));
+        if (!h.fixed.empty())
+            HIP_TRY(hipMemcpy((uint32_t *)d.trailer + h.trailer.size(), h.fixed.data(), h.fixed.size() * 4, hipMemcpyHostToDevice));
         d.view = h.view();
         d.view.skel = (const uint8_t *)d.skel;
         d.view.slots = (const TextSlot *)d.slots;
         d.view.trailer = (const uint32_t *)d.trailer;
+        d.view.fixed = (const uint32_t *)d.trailer + h.trailer.size();
     }
     tp.templates.push_back(d);
     view = d.ok ? d.view : TextTemplate();
@@ -185,24 +192,32 @@ long read_into(const char *path, uint8_t *dst, size_t cap)
 
 }  // namespace
 
-int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *const *texts, const size_t *lens,
-                    const char *const *paths, int fmt, uint32_t *status_host, ss_ingest_stats *stats)
+// What differs between the proof families behind the one pipeline.
+struct Family {
+    size_t W = 0;                 // words of a record on the device
+    TextTemplate tmpl[2];         // device views: proof.json, proof.wit
+    const char *wit_key = "";     // the member name a .wit starts with (format sniffing for the GPU reader's first guess)
+    bool zero_records = false;    // records have padding words the GPU reader does not write
+    // host reader of text g into dst (W words): 0 = parsed, SS_STATUS_MALFORMED / SS_STATUS_CONFIG_MISMATCH = stage-0
+    // verdict (dst zeroed), kDeferred = parsed, but it does not fit a W-word record: the caller deals with it afterwards
+    std::function<int(size_t g, const char *text, size_t len, uint32_t *dst)> host_read;
+    std::function<size_t(size_t cnt)> batch_words, ws_bytes;
+    // re-tile cnt records and verify them, asynchronously on `s`
+    std::function<int(size_t cnt, const uint32_t *rec_dev, uint32_t *batch_dev, void *ws, size_t wsb, uint32_t *status_dev,
+                      hipStream_t s)> verify;
+};
+constexpr int kDeferred = 3;
+
+static int ingest_pipeline(ss_ctx *ctx, const Family &F, size_t n, const char *const *texts, const size_t *lens,
+                           const char *const *paths, int fmt, uint32_t *status_host, std::vector<uint8_t> &outcome,
+                           ss_ingest_stats *stats, double t0)
 {
-    if (!ctx || !status_host || (!texts && !paths) || (texts && !lens)) return set_err(SS_ERR_ARG, "null argument");
-    if (!cfg_ok(c)) return set_err(SS_ERR_ARG, "unsupported stwo config");
-    if (!n) return set_err(SS_ERR_ARG, "empty batch");
-    if (fmt < SS_TEXT_AUTO || fmt > SS_TEXT_WIT) return set_err(SS_ERR_ARG, "unknown text format");
-    if (n * (size_t)c->n_queries > 0x7fffffffu) return set_err(SS_ERR_ARG, "batch too large");
-    std::lock_guard<std::mutex> lock(ctx->mu);  // the context's scratch: one such call at a time
-    const double t0 = now_s();
-    HIP_TRY(hipSetDevice(ctx->device));
     TextPath &tp = ctx->tp;
     int rc;
-    if ((rc = ensure_streams(tp))) return rc;
-    const size_t W = ss_stwo_record_words(c);
+    const size_t W = F.W;
     TextParseArgs args{};
-    if ((rc = template_of(ctx, *c, SS_TEXT_JSON, tp.cx, args.tmpl[0]))) return rc;
-    if ((rc = template_of(ctx, *c, SS_TEXT_WIT, tp.cx, args.tmpl[1]))) return rc;
+    args.tmpl[0] = F.tmpl[0];
+    args.tmpl[1] = F.tmpl[1];
     args.record_words = (uint32_t)W;
     const unsigned threads = effective_cpus();
     // staging is a copy: a few threads saturate it, and the thread that drives the GPU needs a core too
@@ -260,11 +275,10 @@ int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *con
     auto stage_bytes = [&](const Chunk &ch) { return meta_off(ch) + ch.cnt * 17 + 4 + 16; };
     const size_t stage_cap = aligned(max_text + kTextSlack) + max_cnt * 17 + 4 + 16;
     const size_t max_windows = (max_text / 1024 + max_cnt + 4) & ~(size_t)3;  // ceil(len / 1024) per text; keeps WinSum 16-byte aligned
-    ss_stwo_cfg cv = *c;
     size_t words = 0, wsb = 0;  // (the workspace is not monotone in the batch size: smaller batches get smaller groups)
     for (auto &ch : chunks) {
-        words = std::max(words, ss_stwo_batch_words(&cv, ch.cnt));
-        wsb = std::max(wsb, ss_stwo_workspace_bytes(&cv, ch.cnt));
+        words = std::max(words, F.batch_words(ch.cnt));
+        wsb = std::max(wsb, F.ws_bytes(ch.cnt));
     }
     for (int b = 0; b < kTextBufs; b++) {
         if ((rc = grow(tp.text_pin[b], stage_cap, true))) return rc;
@@ -278,7 +292,7 @@ int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *con
     if ((rc = grow(tp.ws_dev, wsb, false))) return rc;
     if ((rc = grow(tp.status_dev, n * 4, false))) return rc;
 
-    std::vector<uint8_t> outcome(n, 0);  // ParseResult of the texts the host reader handled (0 = verified as parsed)
+    outcome.assign(n, 0);  // stage-0 verdict of the texts the host reader handled (0 = verified as parsed)
     std::vector<uint32_t> chunk_windows(nchunks, 0);
     double stage_s = 0, parse_s = 0;
     uint64_t text_total = 0, fallbacks = 0;
@@ -314,13 +328,13 @@ int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *con
                 copy_streaming(dst, texts[g], len);
             }
             lens32[i] = len;
-            // which template to try: a .wit is a JSON object whose first member is COMMITMENTS.  A wrong guess
-            // only costs the fast path -- the host reader sniffs for itself.
+            // which template to try: a .wit is a JSON object whose first member is COMMITMENTS / P_MT_ROOT.  A wrong
+            // guess only costs the fast path -- the host reader sniffs for itself.
             uint8_t f = fmt == SS_TEXT_WIT;
             if (fmt == SS_TEXT_AUTO) {
                 const size_t look = len < 64 ? len : 64;
-                static const char key[] = "\"COMMITMENTS\"";
-                for (size_t p = 0; p + sizeof key - 1 <= look && !f; p++) f = memcmp(dst + p, key, sizeof key - 1) == 0;
+                const size_t kl = strlen(F.wit_key);
+                for (size_t p = 0; p + kl <= look && !f; p++) f = memcmp(dst + p, F.wit_key, kl) == 0;
             }
             fmts[i] = f;
         }, stage_threads);
@@ -374,9 +388,9 @@ int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *con
             parallel_for(todo.size(), [&](size_t j) {
                 const size_t i = todo[j], g = ch.lo + i;
                 uint32_t *dst = fix + j * W;
-                ParseResult r = kMalformed;
-                if (!unreadable[g]) r = stwo_parse_text(*c, (const char *)stage + offs[i], tlen[g], fmt, dst);
-                if (r != kParsed) memset(dst, 0, W * 4);
+                int r = (int)SS_STATUS_MALFORMED;
+                if (!unreadable[g]) r = F.host_read(g, (const char *)stage + offs[i], tlen[g], dst);
+                if (r != 0) memset(dst, 0, W * 4);
                 outcome[g] = (uint8_t)r;
             }, threads);
             uint32_t *rec = (uint32_t *)tp.rec_dev[b].p;
@@ -388,10 +402,11 @@ int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *con
         for (size_t i = 0; i < ch.cnt; i++) text_total += tlen[ch.lo + i];
         { std::lock_guard<std::mutex> lk(m); freed = k + 1; }  // the pinned texts of this chunk are no longer needed
         cv_freed.notify_all();
-        if ((rc = ss_stwo_pack_dev(ctx, c, ch.cnt, (const uint32_t *)tp.rec_dev[b].p, (uint32_t *)tp.batch_dev.p, tp.vx))) return rc;
-        HIP_TRY(hipEventRecord(tp.packed[b], tp.vx));  // rec_dev[b] may be written again
-        return ss_stwo_verify_batch_dev(ctx, c, ch.cnt, (const uint32_t *)tp.batch_dev.p, tp.ws_dev.p, tp.ws_dev.bytes,
-                                        status_dev + ch.lo, nullptr, tp.vx);
+        rc = F.verify(ch.cnt, (const uint32_t *)tp.rec_dev[b].p, (uint32_t *)tp.batch_dev.p, tp.ws_dev.p, tp.ws_dev.bytes,
+                      status_dev + ch.lo, tp.vx);
+        // (the verify stream has re-tiled rec_dev[b] by the time anything recorded after this point completes)
+        HIP_TRY(hipEventRecord(tp.packed[b], tp.vx));
+        return rc;
     };
 
     auto run = [&]() -> int {
@@ -409,6 +424,7 @@ int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *con
             // ---- GPU reader (after rec_dev[b] has been re-tiled for chunk k - kTextBufs)
             HIP_TRY(hipStreamWaitEvent(tp.cx, tp.uploaded[b], 0));
             HIP_TRY(hipStreamWaitEvent(tp.cx, tp.packed[b], 0));
+            if (F.zero_records) HIP_TRY(hipMemsetAsync(tp.rec_dev[b].p, 0, ch.cnt * W * 4, tp.cx));
             const uint8_t *dev = (const uint8_t *)tp.text_dev[b].p;
             args.texts = dev;
             args.offs = (const uint64_t *)(dev + meta_off(ch));
@@ -445,10 +461,8 @@ int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *con
     (void)hipStreamSynchronize(tp.cx);
     (void)hipStreamSynchronize(tp.vx);
     if (rc) return rc;
-    for (size_t i = 0; i < n; i++) {
-        if (outcome[i] == kMalformed) status_host[i] = SS_STATUS_MALFORMED;
-        else if (outcome[i] == kConfigMismatch) status_host[i] = SS_STATUS_CONFIG_MISMATCH;
-    }
+    for (size_t i = 0; i < n; i++)
+        if (outcome[i] == SS_STATUS_MALFORMED || outcome[i] == SS_STATUS_CONFIG_MISMATCH) status_host[i] = outcome[i];
     if (stats) {
         stats->read_s = stage_s;
         stats->parse_s = parse_s;
@@ -461,21 +475,131 @@ int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *con
     return SS_OK;
 }
 
+int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *const *texts, const size_t *lens,
+                    const char *const *paths, int fmt, uint32_t *status_host, ss_ingest_stats *stats)
+{
+    if (!ctx || !status_host || (!texts && !paths) || (texts && !lens)) return set_err(SS_ERR_ARG, "null argument");
+    if (!cfg_ok(c)) return set_err(SS_ERR_ARG, "unsupported stwo config");
+    if (!n) return set_err(SS_ERR_ARG, "empty batch");
+    if (fmt < SS_TEXT_AUTO || fmt > SS_TEXT_WIT) return set_err(SS_ERR_ARG, "unknown text format");
+    if (n * (size_t)c->n_queries > 0x7fffffffu) return set_err(SS_ERR_ARG, "batch too large");
+    std::lock_guard<std::mutex> lock(ctx->mu);  // the context's scratch: one such call at a time
+    const double t0 = now_s();
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure_streams(ctx->tp))) return rc;
+    Family F;
+    F.W = ss_stwo_record_words(c);
+    if ((rc = template_of(ctx, *c, SS_TEXT_JSON, ctx->tp.cx, F.tmpl[0]))) return rc;
+    if ((rc = template_of(ctx, *c, SS_TEXT_WIT, ctx->tp.cx, F.tmpl[1]))) return rc;
+    F.wit_key = "\"COMMITMENTS\"";
+    const ss_stwo_cfg cv = *c;
+    F.host_read = [&cv, fmt](size_t, const char *text, size_t len, uint32_t *dst) {
+        const ParseResult r = stwo_parse_text(cv, text, len, fmt, dst);
+        return r == kParsed ? 0 : r == kConfigMismatch ? (int)SS_STATUS_CONFIG_MISMATCH : (int)SS_STATUS_MALFORMED;
+    };
+    F.batch_words = [&cv](size_t cnt) { return ss_stwo_batch_words(&cv, cnt); };
+    F.ws_bytes = [&cv](size_t cnt) { return ss_stwo_workspace_bytes(&cv, cnt); };
+    F.verify = [ctx, &cv](size_t cnt, const uint32_t *rec, uint32_t *batch, void *ws, size_t wsb, uint32_t *status, hipStream_t s) {
+        const int r = ss_stwo_pack_dev(ctx, &cv, cnt, rec, batch, s);
+        return r ? r : ss_stwo_verify_batch_dev(ctx, &cv, cnt, batch, ws, wsb, status, nullptr, s);
+    };
+    std::vector<uint8_t> outcome;
+    return ingest_pipeline(ctx, F, n, texts, lens, paths, fmt, status_host, outcome, stats, t0);
+}
+
+// stark101: the protocol's shape has a template (ss_text.h); a proof of another shape is parsed by the host reader
+// and, when it does not fit the {10, 13} records of the pipeline, verified afterwards in a batch of its own shape.
+int s101_ingest_dev(ss_ctx *ctx, size_t n, const char *const *texts, const size_t *lens, const char *const *paths, int fmt,
+                    uint32_t *status_host, ss_ingest_stats *stats)
+{
+    if (!ctx || !status_host || (!texts && !paths) || (texts && !lens)) return set_err(SS_ERR_ARG, "null argument");
+    if (!n) return set_err(SS_ERR_ARG, "empty batch");
+    if (fmt < SS_TEXT_AUTO || fmt > SS_TEXT_WIT) return set_err(SS_ERR_ARG, "unknown text format");
+    if (n > 0x7fffffffu) return set_err(SS_ERR_ARG, "batch too large");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    const double t0 = now_s();
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure_streams(ctx->tp))) return rc;
+    ss_stwo_cfg key{};  // the template cache is keyed by a config: stark101 uses an impossible one (0 columns)
+    key.n_cols = 0; key.lde_log = kS101Path; key.n_layers = kS101Layers;
+    Family F;
+    const ss_s101_shape sh = {kS101Layers, kS101Path};
+    F.W = ss_s101_record_words(&sh);
+    if ((rc = template_of(ctx, key, SS_TEXT_JSON, ctx->tp.cx, F.tmpl[0]))) return rc;
+    if ((rc = template_of(ctx, key, SS_TEXT_WIT, ctx->tp.cx, F.tmpl[1]))) return rc;
+    F.wit_key = "\"P_MT_ROOT\"";
+    F.zero_records = true;
+    std::vector<S101Parsed *> deferred(n, nullptr);
+    F.host_read = [&](size_t g, const char *text, size_t len, uint32_t *dst) {
+        S101Parsed *p = s101_parse_text(text, len, fmt);
+        if (!p) return (int)SS_STATUS_MALFORMED;
+        uint32_t nl, pm;
+        s101_parsed_shape(p, &nl, &pm);
+        if (nl <= sh.max_layers && pm <= sh.max_path) {
+            s101_parsed_record(p, sh, dst);
+            s101_parsed_free(p);
+            return 0;
+        }
+        deferred[g] = p;  // (one writer per g: the pipeline hands every text to exactly one worker)
+        return kDeferred;
+    };
+    F.batch_words = [&sh](size_t cnt) { return ss_s101_batch_words(&sh, cnt); };
+    F.ws_bytes = [&sh](size_t cnt) { return ss_s101_workspace_bytes(&sh, cnt); };
+    F.verify = [ctx, &sh](size_t cnt, const uint32_t *rec, uint32_t *batch, void *ws, size_t wsb, uint32_t *status, hipStream_t s) {
+        const int r = ss_s101_pack_dev(ctx, &sh, cnt, rec, batch, s);
+        return r ? r : ss_s101_verify_batch_dev(ctx, &sh, cnt, batch, ws, wsb, status, nullptr, s);
+    };
+    std::vector<uint8_t> outcome;
+    rc = ingest_pipeline(ctx, F, n, texts, lens, paths, fmt, status_host, outcome, stats, t0);
+    // ---- proofs of a larger shape than the protocol's: one more batch, of their own shape
+    std::vector<size_t> late;
+    ss_s101_shape big = {0, 0};
+    for (size_t i = 0; i < n; i++)
+        if (deferred[i]) {
+            uint32_t nl, pm;
+            s101_parsed_shape(deferred[i], &nl, &pm);
+            big.max_layers = std::max(big.max_layers, nl);
+            big.max_path = std::max(big.max_path, pm);
+            late.push_back(i);
+        }
+    if (!rc && !late.empty()) {
+        const size_t Wb = ss_s101_record_words(&big);
+        std::vector<uint32_t> recs(late.size() * Wb, 0), st(late.size(), 0xffffffffu);
+        std::vector<const uint32_t *> ptrs(late.size());
+        for (size_t j = 0; j < late.size(); j++) {
+            s101_parsed_record(deferred[late[j]], big, recs.data() + j * Wb);
+            ptrs[j] = recs.data() + j * Wb;
+        }
+        rc = s101_verify_records_locked(ctx, &big, late.size(), ptrs.data(), st.data());
+        for (size_t j = 0; j < late.size() && !rc; j++) status_host[late[j]] = st[j];
+        if (stats) stats->total_s = now_s() - t0;
+    }
+    for (size_t i = 0; i < n; i++)
+        if (deferred[i]) s101_parsed_free(deferred[i]);
+    return rc;
+}
+
 // The GPU reader alone (diagnostic / tests): texts -> records + outcome words, synchronous, own buffers.
+// (c == nullptr: stark101, records of shape {kS101Layers, kS101Path})
 int stwo_read_texts_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *const *texts, const size_t *lens,
                         int fmt, uint32_t *records_host, uint32_t *outcome_host)
 {
     if (!ctx || !texts || !lens || !records_host || !outcome_host) return set_err(SS_ERR_ARG, "null argument");
-    if (!cfg_ok(c) || !n || (fmt != SS_TEXT_JSON && fmt != SS_TEXT_WIT)) return set_err(SS_ERR_ARG, "bad argument");
+    if ((c && !cfg_ok(c)) || !n || (fmt != SS_TEXT_JSON && fmt != SS_TEXT_WIT)) return set_err(SS_ERR_ARG, "bad argument");
     std::lock_guard<std::mutex> lock(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     TextPath &tp = ctx->tp;
     int rc;
     if ((rc = ensure_streams(tp))) return rc;
-    const size_t W = ss_stwo_record_words(c);
+    ss_stwo_cfg key{};
+    key.lde_log = kS101Path; key.n_layers = kS101Layers;  // n_cols 0: the stark101 template (s101_ingest_dev)
+    const ss_s101_shape sh = {kS101Layers, kS101Path};
+    const size_t W = c ? ss_stwo_record_words(c) : ss_s101_record_words(&sh);
     TextParseArgs args{};
-    if ((rc = template_of(ctx, *c, SS_TEXT_JSON, tp.cx, args.tmpl[0]))) return rc;
-    if ((rc = template_of(ctx, *c, SS_TEXT_WIT, tp.cx, args.tmpl[1]))) return rc;
+    if ((rc = template_of(ctx, c ? *c : key, SS_TEXT_JSON, tp.cx, args.tmpl[0]))) return rc;
+    if ((rc = template_of(ctx, c ? *c : key, SS_TEXT_WIT, tp.cx, args.tmpl[1]))) return rc;
     args.record_words = (uint32_t)W;
     auto aligned = [](size_t v) { return (v + 15) & ~(size_t)15; };
     size_t total = 0;
@@ -508,7 +632,7 @@ int stwo_read_texts_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char 
         return done(rc);
     const size_t wcap = ((size_t)n_windows + 4) & ~(size_t)3;
     if (hipMemcpy(text.p, host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(rec.p, 0xee, n * W * 4) != hipSuccess)
+        hipMemset(rec.p, c ? 0xee : 0, n * W * 4) != hipSuccess)  // (stark101 records have zero padding the reader leaves alone)
         return done(set_err(SS_ERR_HIP, "upload failed"));
     const uint8_t *dev = (const uint8_t *)text.p;
     args.texts = dev;

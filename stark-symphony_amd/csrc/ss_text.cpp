@@ -67,6 +67,27 @@ struct TextSink {
             for (int s = 28; s >= 0; s -= 4) out.push_back(d[(rec[w + j] >> s) & 15]);
     }
     void cst(uint32_t v) { dec(v); }
+    void dec256(uint32_t w)  // 8 words, most significant first, as a decimal integer
+    {
+        uint32_t limb[8];
+        for (int j = 0; j < 8; j++) limb[j] = rec[w + j];
+        char buf[80];
+        int n = 0;
+        for (;;) {
+            uint64_t rem = 0;
+            bool any = false;
+            for (int j = 0; j < 8; j++) {  // limb /= 10^9
+                const uint64_t cur = (rem << 32) | limb[j];
+                limb[j] = (uint32_t)(cur / 1000000000u);
+                rem = cur % 1000000000u;
+                any |= limb[j] != 0;
+            }
+            for (int d = 0; d < 9 && (any || rem); d++) { buf[n++] = (char)('0' + rem % 10); rem /= 10; }
+            if (!any) break;
+        }
+        if (!n) buf[n++] = '0';
+        while (n) out.push_back(buf[--n]);
+    }
 };
 
 struct SlotSink {
@@ -85,6 +106,7 @@ struct SlotSink {
     void u64(uint32_t w) { num(w, kSlotU64, "0"); }
     void hex256(uint32_t w) { num(w, kSlotHex256, "0x0000000000000000000000000000000000000000000000000000000000000000"); }
     void cst(uint32_t v) { num(v, kSlotConst, "0"); }
+    void dec256(uint32_t w) { num(w, kSlotDec256, "0"); }
 };
 
 // ------------------------------------------------------------------------------ proof.json (format C)
@@ -223,6 +245,112 @@ void wit_text(const ss_stwo_cfg &cfg, S &s)
     s.lit("}");
 }
 
+// -------------------------------------------------------------------------------------- stark101
+// record of shape {kS101Layers, kS101Path} (include/ss_verify.h): word offsets
+struct Rec101 {
+    static constexpr uint32_t ML = kS101Layers, PM = kS101Path, chain = 2 + 8 * PM;
+    static uint32_t eval(uint32_t k) { return 10 + k * chain; }                       // ev, len, path
+    static uint32_t layer(uint32_t i) { return 10 + 3 * chain + i * (9 + 2 * chain); }  // root[8], beta, cpa chain, cpb chain
+    static uint32_t words() { return layer(ML); }
+    static uint32_t layer_len(uint32_t i) { return PM - i; }
+};
+
+// formats.stark101_to_json: {"p_mt_root", "evals", "fri_layers", "fri_last_layer"} (prover.py:108,143-167)
+template <class S>
+void s101_json_text(TextStyle style, S &s)
+{
+    typedef Rec101 R;
+    const char *cm = style == kStylePython ? ", " : ",", *co = style == kStylePython ? ": " : ":";
+    auto key = [&](const char *k) { s.lit("\""); s.lit(k); s.lit("\""); s.lit(co); };
+    auto path = [&](uint32_t w, uint32_t len) {
+        s.lit("[");
+        for (uint32_t l = 0; l < len; l++) { if (l) s.lit(cm); s.dec256(w + 8 * l); }
+        s.lit("]");
+    };
+    s.lit("{"); key("p_mt_root"); s.dec256(0); s.lit(cm);
+    key("evals"); s.lit("[");
+    for (uint32_t k = 0; k < 3; k++) {
+        if (k) s.lit(cm);
+        s.lit("["); s.u32(R::eval(k)); s.lit(cm); path(R::eval(k) + 2, R::PM); s.lit("]");
+    }
+    s.lit("]"); s.lit(cm);
+    key("fri_layers"); s.lit("[");
+    for (uint32_t i = 0; i < R::ML; i++) {
+        const uint32_t b = R::layer(i), a = b + 9, c = a + R::chain, len = R::layer_len(i);
+        if (i) s.lit(cm);
+        s.lit("["); s.dec256(b); s.lit(cm); s.u32(b + 8); s.lit(cm); s.u32(a); s.lit(cm); path(a + 2, len); s.lit(cm);
+        s.u32(c); s.lit(cm); path(c + 2, len); s.lit("]");
+    }
+    s.lit("]"); s.lit(cm);
+    key("fri_last_layer"); s.u32(9); s.lit("}");
+}
+
+// formats.stark101_to_wit = stark101/scripts/generate_wit.py:13-30, printed by json.dumps(indent=4)
+template <class S>
+void s101_wit_text(S &s)
+{
+    typedef Rec101 R;
+    auto lst = [&](uint32_t w, uint32_t len) {
+        s.lit("list![");
+        for (uint32_t l = 0; l < len; l++) { if (l) s.lit(", "); s.dec256(w + 8 * l); }
+        s.lit("]");
+    };
+    auto mp = [&]() { s.lit("List<u256, "); s.cst(32); s.lit(">"); };
+    auto entry = [&](const char *name) { s.lit("    \""); s.lit(name); s.lit("\": {\n        \"value\": \""); };
+    auto type = [&]() { s.lit("\",\n        \"type\": \""); };
+    auto close = [&](bool last) { s.lit(last ? "\"\n    }\n" : "\"\n    },\n"); };
+    s.lit("{\n");
+    entry("P_MT_ROOT"); s.dec256(0); type(); s.lit("u256"); close(false);
+    entry("P_EVALS");
+    s.lit("(");
+    for (uint32_t k = 0; k < 3; k++) {
+        if (k) s.lit(", ");
+        s.lit("("); s.u32(R::eval(k)); s.lit(", "); lst(R::eval(k) + 2, R::PM); s.lit(")");
+    }
+    s.lit(")");
+    type();
+    s.lit("(");
+    for (uint32_t k = 0; k < 3; k++) { if (k) s.lit(", "); s.lit("(u32, "); mp(); s.lit(")"); }
+    s.lit(")");
+    close(false);
+    entry("FRI_LAYERS");
+    s.lit("list![");
+    for (uint32_t i = 0; i < R::ML; i++) {
+        const uint32_t b = R::layer(i), a = b + 9, c = a + R::chain, len = R::layer_len(i);
+        if (i) s.lit(", ");
+        s.lit("(("); s.dec256(b); s.lit(", "); s.u32(b + 8); s.lit(", "); s.u32(a); s.lit(", "); lst(a + 2, len); s.lit(", ");
+        s.u32(c); s.lit(", "); lst(c + 2, len); s.lit("))");
+    }
+    s.lit("]");
+    type();
+    s.lit("List<((u256, u32, u32, "); mp(); s.lit(", u32, "); mp(); s.lit("), "); s.cst(32); s.lit(")");
+    close(false);
+    entry("FRI_LAST_LAYER"); s.u32(9); type(); s.lit("u32"); close(true);
+    s.lit("}");
+}
+
+// the words a canonical stark101 text implies: n_layers and every path length
+void s101_fixed_words(std::vector<uint32_t> &fixed)
+{
+    typedef Rec101 R;
+    fixed.push_back(8); fixed.push_back(R::ML);
+    for (uint32_t k = 0; k < 3; k++) { fixed.push_back(R::eval(k) + 1); fixed.push_back(R::PM); }
+    for (uint32_t i = 0; i < R::ML; i++) {
+        const uint32_t a = R::layer(i) + 9;
+        fixed.push_back(a + 1); fixed.push_back(R::layer_len(i));
+        fixed.push_back(a + R::chain + 1); fixed.push_back(R::layer_len(i));
+    }
+}
+
+bool s101_canonical_record(const uint32_t *rec)
+{
+    std::vector<uint32_t> fixed;
+    s101_fixed_words(fixed);
+    for (size_t i = 0; i < fixed.size(); i += 2)
+        if (rec[fixed[i]] != fixed[i + 1]) return false;
+    return true;
+}
+
 bool cfg_writable(const ss_stwo_cfg &c)
 {
     return c.hash <= SS_HASH_BLAKE2S && stwo_cfg_ok(c.n_cols, c.trace_log, c.lde_log, c.n_queries, c.n_layers, c.mode & 1);
@@ -260,6 +388,26 @@ bool stwo_write_wit(const ss_stwo_cfg &cfg, const uint32_t *record, std::string 
     return true;
 }
 
+static bool skeleton_of(const std::string &sample, const std::vector<uint32_t> &at, TextTemplateHost &out);
+
+bool s101_write_json(const uint32_t *record, TextStyle style, std::string &out)
+{
+    out.clear();
+    if (!s101_canonical_record(record)) return false;
+    TextSink s{out, record};
+    s101_json_text(style, s);
+    return true;
+}
+
+bool s101_write_wit(const uint32_t *record, std::string &out)
+{
+    out.clear();
+    if (!s101_canonical_record(record)) return false;
+    TextSink s{out, record};
+    s101_wit_text(s);
+    return true;
+}
+
 TextTemplate TextTemplateHost::view() const
 {
     TextTemplate t;
@@ -267,6 +415,7 @@ TextTemplate TextTemplateHost::view() const
     t.slots = slots.data(); t.n_slots = (uint32_t)slots.size();
     t.record_words = record_words;
     t.tbase = tbase; t.n_trailer = (uint32_t)trailer.size(); t.trailer = trailer.data();
+    t.n_fixed = (uint32_t)(fixed.size() / 2); t.fixed = fixed.data();
     return t;
 }
 
@@ -281,7 +430,33 @@ void stwo_build_template(const ss_stwo_cfg &cfg, int fmt, TextTemplateHost &out)
     SlotSink s{sample, out.slots, at};
     if (fmt == SS_TEXT_JSON) json_text(cfg, bits, kStyleCompact, s);
     else wit_text(cfg, s);
-    // the skeleton of the sample text, by the tokenizer itself; its numbers must be exactly the sink's
+    if (!skeleton_of(sample, at, out)) { out = TextTemplateHost(); return; }
+    const Rec m(cfg);
+    out.record_words = m.words;
+    out.tbase = m.tbase;
+    for (uint32_t kind = 0; kind < m.K + 3; kind++)
+        for (uint32_t q = 0; q < m.Q; q++) out.trailer.push_back(kind < 2 ? m.L : m.L - 1 - (kind - 2));
+    out.ok = true;
+}
+
+void s101_build_template(int fmt, TextTemplateHost &out)
+{
+    out = TextTemplateHost();
+    if (fmt != SS_TEXT_JSON && fmt != SS_TEXT_WIT) return;
+    std::string sample;
+    std::vector<uint32_t> at;
+    SlotSink s{sample, out.slots, at};
+    if (fmt == SS_TEXT_JSON) s101_json_text(kStyleCompact, s);
+    else s101_wit_text(s);
+    if (!skeleton_of(sample, at, out)) { out = TextTemplateHost(); return; }
+    out.record_words = Rec101::words();
+    s101_fixed_words(out.fixed);
+    out.ok = true;
+}
+
+// the skeleton of the sample text, by the tokenizer itself; its numbers must be exactly the sink's
+bool skeleton_of(const std::string &sample, const std::vector<uint32_t> &at, TextTemplateHost &out)
+{
     uint32_t run = kRunNone, in_str = 0;
     size_t k = 0;
     bool good = true;
@@ -297,15 +472,10 @@ void stwo_build_template(const ss_stwo_cfg &cfg, int fmt, TextTemplateHost &out)
         if (r & 1) out.skel.push_back((uint8_t)c);
     }
     good = good && k == at.size() && in_str == 0;
-    if (!good) { out = TextTemplateHost(); return; }
+    if (!good) return false;
     out.skel_len = (uint32_t)out.skel.size();
     out.skel.resize(out.skel.size() + kSkelSlack, 0);
-    const Rec m(cfg);
-    out.record_words = m.words;
-    out.tbase = m.tbase;
-    for (uint32_t kind = 0; kind < m.K + 3; kind++)
-        for (uint32_t q = 0; q < m.Q; q++) out.trailer.push_back(kind < 2 ? m.L : m.L - 1 - (kind - 2));
-    out.ok = true;
+    return true;
 }
 
 // ------------------------------------------------------------------------- the fast path, scalar
@@ -330,7 +500,32 @@ bool place_number(const TextSlot &sl, const unsigned char *body, size_t n, uint3
         }
         return true;
     }
-    if (n > 20 || (n > 1 && body[0] == '0')) return false;  // no u64 has more digits; canonical decimals only
+    if (n > 1 && body[0] == '0') return false;  // canonical decimals only
+    if (sl.kind == kSlotDec256) {
+        if (n > 78) return false;
+        uint32_t limb[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // little endian
+        for (size_t i = 0; i < n;) {
+            const size_t k = n - i < 9 ? n - i : 9;
+            uint32_t chunk = 0, mul = 1;
+            for (size_t j = 0; j < k; j++) {
+                const uint32_t d = body[i + j] - '0';
+                if (d > 9) return false;
+                chunk = chunk * 10 + d;
+                mul *= 10;
+            }
+            uint64_t carry = chunk;
+            for (int l = 0; l < 8; l++) {
+                const uint64_t v = (uint64_t)limb[l] * mul + carry;
+                limb[l] = (uint32_t)v;
+                carry = v >> 32;
+            }
+            if (carry) return false;  // >= 2^256
+            i += k;
+        }
+        for (int l = 0; l < 8; l++) rec[sl.dst + l] = limb[7 - l];
+        return true;
+    }
+    if (n > 20) return false;  // no u64 has more digits
     uint64_t v = 0;
     for (size_t i = 0; i < n; i++) {
         const uint32_t d = body[i] - '0';
@@ -372,7 +567,7 @@ bool text_scan_reference(const TextTemplate &t, const char *text, size_t len, ui
             if (sk >= t.skel_len || t.skel[sk] != kSkelMark || tok >= t.n_slots) return false;
             sk++;
             size_t e = i;
-            while (e < len && txt_is_alnum(p[e])) e++;
+            while (e < len && e - i <= kMaxTokenBytes && txt_is_alnum(p[e])) e++;
             if (!place_number(t.slots[tok], p + i, e - i, rec)) return false;
             tok++;
         }
@@ -383,6 +578,7 @@ bool text_scan_reference(const TextTemplate &t, const char *text, size_t len, ui
     }
     if (sk != t.skel_len || tok != t.n_slots) return false;
     for (uint32_t i = 0; i < t.n_trailer; i++) rec[t.tbase + i] = t.trailer[i];
+    for (uint32_t i = 0; i < t.n_fixed; i++) rec[t.fixed[2 * i]] = t.fixed[2 * i + 1];
     return true;
 }
 

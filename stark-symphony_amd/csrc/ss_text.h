@@ -43,7 +43,9 @@ enum SlotKind : uint32_t {
     kSlotU64 = 2,    // decimal < 2^64            -> words dst (high), dst + 1 (low)
     kSlotHex256 = 3, // 0x + exactly 64 hex digits -> words dst .. dst + 7
     kSlotConst = 4,  // decimal that must equal `dst` (declared parameters, numbers inside type strings)
+    kSlotDec256 = 5, // decimal < 2^256 (stark101 writes its hashes as big integers) -> words dst .. dst + 7, most significant first
 };
+constexpr uint32_t kMaxTokenBytes = 80;  // no number of the formats is longer (78 decimal digits of a u256, 0x + 64 hex digits)
 
 struct TextSlot {
     uint32_t dst;
@@ -84,8 +86,13 @@ struct TextTemplate {
     const TextSlot *slots = nullptr;
     uint32_t n_slots = 0;
     uint32_t record_words = 0;
-    uint32_t tbase = 0, n_trailer = 0;  // path_len trailer: words [tbase, tbase + n_trailer), constants below
+    // words of the record that a canonical text implies without spelling them: stwo's path_len trailer is the
+    // run [tbase, tbase + n_trailer) (values in `trailer`); stark101's n_layers / path lengths are scattered:
+    // n_fixed (word index, value) pairs in `fixed`
+    uint32_t tbase = 0, n_trailer = 0;
     const uint32_t *trailer = nullptr;
+    uint32_t n_fixed = 0;
+    const uint32_t *fixed = nullptr;
 };
 
 constexpr uint32_t kSkelSlack = 4096;  // zero bytes after the skeleton
@@ -114,12 +121,24 @@ struct TextTemplateHost {
     uint32_t skel_len = 0;
     std::vector<TextSlot> slots;
     std::vector<uint32_t> trailer;
+    std::vector<uint32_t> fixed;   // (word, value) pairs
     uint32_t record_words = 0, tbase = 0;
     bool ok = false;               // false: no canonical text exists for this config / format (fast path off)
     TextTemplate view() const;
 };
 // fmt: SS_TEXT_JSON or SS_TEXT_WIT
 void stwo_build_template(const ss_stwo_cfg &cfg, int fmt, TextTemplateHost &out);
+
+// stark101 (stark101/scripts/fibsquare/prover.py:108,143-167 writes proof.json, stark101/scripts/generate_wit.py:13-30
+// the .wit).  The protocol fixes the proof's shape: an LDE domain of 2^13 points, so Merkle paths of 13 siblings for the
+// three trace evaluations and of 13 - i for the two openings of FRI layer i, 10 layers (prover.py:94-171;
+// stark101/src/verifier.simf:44-388 is that proof).  The template is the text of THAT shape, written into records of
+// shape {kS101Layers, kS101Path}; a proof of any other shape goes to the host reader.
+constexpr uint32_t kS101Layers = 10, kS101Path = 13;
+void s101_build_template(int fmt, TextTemplateHost &out);
+// record (shape {kS101Layers, kS101Path}, canonical path lengths) -> text; false if the record's lengths are not canonical
+bool s101_write_json(const uint32_t *record, TextStyle style, std::string &out);
+bool s101_write_wit(const uint32_t *record, std::string &out);
 
 // Scalar statement of the fast path (what the device kernel computes, byte by byte): true = `text` is a
 // canonical text of the template and `record` (record_words words) holds its record; false = not on the fast

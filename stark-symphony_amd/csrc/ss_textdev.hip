@@ -245,6 +245,7 @@ __global__ void __launch_bounds__(64) text_scan_kernel(TextParseArgs a)
         const TextTemplate &T = wit ? a.tmpl[1] : a.tmpl[0];
         uint32_t *rec = a.records + (size_t)t * a.record_words;
         for (uint32_t i = lane; i < T.n_trailer; i += 64) rec[T.tbase + i] = T.trailer[i];
+        for (uint32_t i = lane; i < T.n_fixed; i += 64) rec[T.fixed[2 * i]] = T.fixed[2 * i + 1];
     }
     if (lane == 0) a.outcome[t] = good ? 0u : 1u;
 }
@@ -344,7 +345,36 @@ __global__ void __launch_bounds__(64) text_place_kernel(TextParseArgs a)
             const uint32_t dst = sl.x, kind = sl.y;
             const uint32_t p = lane * 16 + j;
             uint32_t n = 0;
-            while (n < 67 && p + n < lim && txt_is_alnum(s_text[p + n])) n++;
+            while (n <= kMaxTokenBytes && p + n < lim && txt_is_alnum(s_text[p + n])) n++;
+            if (kind == kSlotDec256) {  // decimal below 2^256: nine digits at a time into eight limbs
+                bool ok = n >= 1 && n <= 78 && !(n > 1 && s_text[p] == '0');
+                uint32_t limb[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // little endian
+                for (uint32_t i = 0; i < n && ok;) {
+                    const uint32_t k = n - i < 9 ? n - i : 9;
+                    uint32_t chunk = 0, mul = 1;
+                    for (uint32_t j = 0; j < k; j++) {
+                        const uint32_t d = s_text[p + i + j] - '0';
+                        ok &= d <= 9;
+                        chunk = chunk * 10 + d;
+                        mul *= 10;
+                    }
+                    uint64_t carry = chunk;
+#pragma unroll
+                    for (int l = 0; l < 8; l++) {
+                        const uint64_t v = (uint64_t)limb[l] * mul + carry;
+                        limb[l] = (uint32_t)v;
+                        carry = v >> 32;
+                    }
+                    ok &= carry == 0;  // >= 2^256
+                    i += k;
+                }
+                if (ok) {
+#pragma unroll
+                    for (int l = 0; l < 8; l++) rec[dst + l] = limb[7 - l];
+                }
+                mism |= !ok;
+                continue;
+            }
             if (kind == kSlotHex256) {
                 bool ok = n == 66 && s_text[p] == '0' && (s_text[p + 1] | 0x20) == 'x';
                 if (ok) {

@@ -608,6 +608,18 @@ class Verifier:
                                            outcome.ctypes.data))
         return recs, outcome
 
+    def read_stark101_texts(self, texts: Sequence[bytes], fmt: int):
+        """The GPU reader alone on stark101 texts (ss_s101_read_texts): records of shape {10, 13}."""
+        n = len(texts)
+        W = B.lib().ss_s101_record_words(C.byref(B.S101Shape(10, 13)))
+        recs = np.zeros((n, W), dtype=np.uint32)
+        outcome = np.full(n, 0xFFFFFFFF, dtype=np.uint32)
+        bufs = [bytes(t) for t in texts]
+        arr = (C.c_char_p * n)(*bufs)
+        lens = (C.c_size_t * n)(*[len(b) for b in bufs])
+        B.check(B.lib().ss_s101_read_texts(self.ctx, n, arr, lens, fmt, recs.ctypes.data, outcome.ctypes.data))
+        return recs, outcome
+
     def verify_stwo_files(self, cfg: StwoConfig, paths: Sequence[str], mode: int = MODE_FIXTURE,
                           fmt: int = B.TEXT_AUTO):
         cs = stwo_cfg_struct(cfg, mode, self.stwo_flags)

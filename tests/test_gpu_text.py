@@ -194,3 +194,76 @@ def test_two_threads_share_one_context(ver):
     for t in th:
         t.join()
     assert not errors, errors
+
+
+# ---------------------------------------------------------------------------------------- stark101
+def test_stark101_texts_are_read_by_the_gpu(ver):
+    """The reference's stark101 proof.json / proof.wit (78-digit decimal hashes) through the GPU reader: outcome and
+    record equal the scalar rule's on the files and on mutants."""
+    from test_text_fastpath import s101_canonical
+    rnd = random.Random(SEED + 101)
+    for fn, fmt in (("stark101_proof.json", JSON), (os.path.join("formats", "stark101_proof.wit"), WIT)):
+        base = open(os.path.join(GOLDEN, fn), "rb").read()
+        texts = [base] + [(_text_mutant(rnd, base) if i % 3 == 0 else _number_mutant(rnd, base)) for i in range(1500)]
+        texts += [b" " * k + base for k in range(1, 40)] if fmt == JSON else []
+        recs, outcome = ver.read_stark101_texts(texts, fmt)
+        taken = 0
+        for i, t in enumerate(texts):
+            want, rec = s101_canonical(t, fmt)
+            assert (outcome[i] == 0) == want, (i, int(outcome[i]), want, t[:120])
+            if want:
+                pad = rec == 0xEEEEEEEE   # words the rule leaves alone are zero padding in the GPU's (pre-zeroed) record
+                assert np.array_equal(recs[i][~pad], rec[~pad]) and not recs[i][pad].any(), i
+                taken += 1
+        assert outcome[0] == 0 and taken > 150
+
+
+def test_stark101_verify_texts_mixed_shapes(ver, tmp_path):
+    """ss_s101_verify_texts / _files: the protocol's proof (GPU reader), corrupted ones (GPU reader, rejected by the
+    kernels), a proof with a layer less and one with 14-sibling paths (host reader; the latter verified in a batch of
+    its own shape), garbage -- statuses equal the oracle's / stage 0, in any mix and across chunks."""
+    s101 = ss.stark101_from_json(json.load(open(os.path.join(GOLDEN, "stark101_proof.json"))))
+    rng = np.random.default_rng(SEED + 102)
+    bad = [formats.stark101_corrupt(s101, rng)[0] for _ in range(6)]
+    fewer = s101.copy(); fewer.layers = fewer.layers[:-1]
+    longer = s101.copy()
+    longer.evals[1].path = np.concatenate([longer.evals[1].path, longer.evals[1].path[:1]])   # 14 siblings
+    proofs = [s101] + bad + [fewer, longer]
+    want = O.s101_verify_batch(proofs).tolist()
+    assert want[0] == 0 and all(want[1:])
+    texts = []
+    for i, p in enumerate(proofs):
+        texts.append(json.dumps(ss.stark101_to_json(p)).encode() if i % 2 else ss.stark101_to_wit(p).encode())
+    texts += [b"{}", b"nonsense"]
+    want += [2, 2]
+    canonical_n = sum(1 for p in proofs[:-2] if True)   # the protocol's shape, whatever the values
+    for n in (len(texts), 9000):
+        batch = [texts[i % len(texts)] for i in range(n)]
+        status, stats = ver.verify_stark101_texts(batch)
+        assert status.tolist() == [want[i % len(texts)] for i in range(n)]
+        assert stats["host_parsed"] == sum(1 for i in range(n) if i % len(texts) >= canonical_n)
+    paths = []
+    for i, t in enumerate(texts):
+        f = tmp_path / ("s%d.txt" % i)
+        f.write_bytes(t)
+        paths.append(str(f))
+    status, _ = ver.verify_stark101_files(paths + [str(tmp_path / "absent")])
+    assert status.tolist() == want + [2]
+
+
+def test_stark101_device_pack_equals_host_pack(ver):
+    import torch
+    s101 = ss.stark101_from_json(json.load(open(os.path.join(GOLDEN, "stark101_proof.json"))))
+    rng = np.random.default_rng(SEED + 103)
+    proofs = [s101] + [formats.stark101_corrupt(s101, rng)[0] for _ in range(4)]
+    for ml, pm, n in ((10, 13, 131), (12, 20, 5), (31, 31, 64)):
+        recs = [verifier.s101_record(proofs[i % 5], ml, pm) for i in range(n)]
+        host = verifier.pack_s101(ml, pm, recs)
+        sh = binding.S101Shape(ml, pm)
+        rec_dev = torch.from_numpy(np.stack(recs).view(np.int32)).to(ver.device)
+        out = torch.full((host.size,), 0x55, dtype=torch.int32, device=ver.device)
+        import ctypes as C
+        binding.check(binding.lib().ss_s101_pack_dev(ver.ctx, C.byref(sh), n, rec_dev.data_ptr(), out.data_ptr(),
+                                                     int(torch.cuda.current_stream(ver.device).cuda_stream)))
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), host)

@@ -207,3 +207,74 @@ def test_configs_without_a_canonical_text_have_no_fast_path():
     assert L.ss_stwo_write_text(C.byref(cs), rec.ctypes.data, WIT, 0, None, 0) > 0
     j = open(os.path.join(GOLDEN, "stwo_proof_test.json"), "rb").read()
     assert L.ss_stwo_text_is_canonical(C.byref(cs), j, len(j), JSON, None) == 0
+
+
+# ---------------------------------------------------------------------------------------- stark101
+def s101_write_text(rec, fmt, python_separators=0):
+    rec = np.ascontiguousarray(rec, dtype=np.uint32)
+    n = binding.lib().ss_s101_write_text(rec.ctypes.data, fmt, python_separators, None, 0)
+    if n == 0:
+        return None
+    buf = C.create_string_buffer(n)
+    assert binding.lib().ss_s101_write_text(rec.ctypes.data, fmt, python_separators, buf, n) == n
+    return buf.raw
+
+
+def s101_canonical(text, fmt):
+    W = binding.lib().ss_s101_record_words(C.byref(binding.S101Shape(10, 13)))
+    rec = np.full(W, 0xEEEEEEEE, dtype=np.uint32)
+    got = binding.check(binding.lib().ss_s101_text_is_canonical(text, len(text), fmt, rec.ctypes.data))
+    return bool(got), rec
+
+
+def _s101_python(text, kind):
+    try:
+        p = ss.stark101_from_json(json.loads(text)) if kind == "json" else ss.stark101_from_wit(text.decode())
+    except (ss.MalformedProof, ValueError, OverflowError, AttributeError, UnicodeDecodeError, RecursionError, KeyError, TypeError):
+        return None
+    return p
+
+
+def test_stark101_writers_and_the_reference_files():
+    """stark101: the writers print what prover.py's proof.json / generate_wit.py print (the committed files are the
+    reference's own output, tests/golden/make_stark101_golden.py and make_format_golden.py), both files are canonical,
+    and the protocol's shape is the only one with a canonical text."""
+    p = ss.stark101_from_json(json.load(open(os.path.join(GOLDEN, "stark101_proof.json"))))
+    rec = verifier.s101_record(p, 10, 13)
+    assert s101_write_text(rec, WIT) == ss.stark101_to_wit(p).encode()
+    assert s101_write_text(rec, WIT) == open(os.path.join(FORMATS, "stark101_proof.wit"), "rb").read().rstrip(b"\n")
+    assert s101_write_text(rec, JSON, 1) == json.dumps(ss.stark101_to_json(p)).encode()
+    assert s101_write_text(rec, JSON, 0) == json.dumps(ss.stark101_to_json(p), separators=(",", ":")).encode()
+    for fn, fmt in (("stark101_proof.json", JSON), (os.path.join("formats", "stark101_proof.wit"), WIT)):
+        text = open(os.path.join(GOLDEN, fn), "rb").read()
+        taken, got = s101_canonical(text, fmt)
+        assert taken and np.array_equal(got, rec)
+        assert not s101_canonical(text, WIT if fmt == JSON else JSON)[0]
+    short = p.copy()
+    short.layers = short.layers[:-1]                       # nine layers: a valid text, but not the protocol's shape
+    assert verifier.parse_s101_text(json.dumps(ss.stark101_to_json(short)).encode())[0] == 0
+    assert not s101_canonical(json.dumps(ss.stark101_to_json(short)).encode(), JSON)[0]
+    assert s101_write_text(verifier.s101_record(short, 10, 13), JSON) is None
+
+
+@pytest.mark.parametrize("kind", ["json", "wit"])
+def test_stark101_whatever_the_rule_takes_is_what_the_readers_read(kind):
+    """Three-way soundness for stark101 (78-digit decimal hashes): every mutant the rule takes parses in the native
+    reader and in formats.py to the same record."""
+    rnd = random.Random(20261005 + len(kind))
+    fmt = JSON if kind == "json" else WIT
+    base = open(os.path.join(GOLDEN, "stark101_proof.json" if kind == "json" else os.path.join("formats", "stark101_proof.wit")), "rb").read()
+    base_rec = s101_canonical(base, fmt)[1]
+    taken_n = changed_n = 0
+    for i in range(2500):
+        text = _text_mutant(rnd, base) if i % 3 == 0 else _number_mutant(rnd, base)
+        taken, rec = s101_canonical(text, fmt)
+        if not taken:
+            continue
+        taken_n += 1
+        rc, shape, nrec = verifier.parse_s101_text(text, fmt=fmt)
+        assert rc == 0 and shape == (10, 13) and np.array_equal(nrec, rec), (i, text[:160])
+        p = _s101_python(text, kind)
+        assert p is not None and np.array_equal(verifier.s101_record(p, 10, 13), rec), (i, text[:160])
+        changed_n += not np.array_equal(rec, base_rec)
+    assert taken_n > 200 and changed_n > 100
