@@ -383,9 +383,9 @@ def main() -> None:
         from stark_symphony_amd import formats
         c = proofs[0].cfg if proofs else formats.StwoConfig(**GEN_ONLY[wname])
         gp = prover.GpuProver(ver)
-        made = [gp.prove_proof(c.n_cols, c.trace_log, c.log_blowup, c.n_queries, c.pow_bits,
-                               seed=s + rank * args.distinct, hash=c.hash)
-                for s in range(args.distinct)]
+        made = gp.prove_many([s + rank * args.distinct for s in range(args.distinct)], workers=4, n_cols=c.n_cols,
+                             trace_log=c.trace_log, log_blowup=c.log_blowup, n_queries=c.n_queries, pow_bits=c.pow_bits,
+                             hash=c.hash)
         if rank == 0 and proofs:
             assert ss.stwo_to_json(made[0]) == ss.stwo_to_json(proofs[0]), "GPU prover != committed proof"
         note += "; %d distinct proofs made by the GPU prover%s" % (
@@ -442,7 +442,7 @@ def main() -> None:
     slots = [batch] + [batch.sibling() for _ in range(nslot - 1)]
     pipe = verifier.Pipeline(slots)
     if args.tail_streams == 0:
-        args.tail_streams = 2 if (family == "stwo" and n_local < 32768) else 1
+        args.tail_streams = 2 if (family == "stwo" and n_local < 65536) else 1
     timed_pipe = verifier.Pipeline(slots, tail_streams=args.tail_streams) if args.tail_streams > 1 else pipe
     accs = [torch.zeros(1, dtype=torch.int32, device=ver.device) for _ in range(nslot)]
     acc = accs[0]

@@ -256,7 +256,7 @@ class GpuProver:
         marks: List[Tuple[str, float]] = []
 
         def mark(name: str) -> None:
-            torch.cuda.synchronize(self.dev)
+            torch.cuda.current_stream(self.dev).synchronize()  # this proof's stream only: others may be in flight (prove_many)
             marks.append((name, time.perf_counter()))
         n, L, N = trace_log, trace_log + log_blowup, n_cols
         K = L - 1 - log_blowup
@@ -445,6 +445,48 @@ class GpuProver:
             prev = ts
         self.timings["total"] = prev - t_start
         return proof
+
+    def prove_many(self, seeds: Sequence[int], workers: int = 4, **kw) -> list:
+        """Proofs of the same configuration for every seed of `seeds`, `workers` of them in flight, each on its own
+        HIP stream (and host thread).  A single proof leaves the GPU idle between its many dependent launches -- the
+        small upper Merkle levels, the channel round trips -- and other proofs' kernels fill those gaps; nothing else
+        changes, so every proof is byte-identical to `prove_proof(seed=...)`.  Returns the StwoProofs in seed order;
+        `self.timings["proofs_per_s"]` is the rate of the call."""
+        import itertools
+        import threading
+        torch = self.torch
+        seeds = list(seeds)
+        out: list = [None] * len(seeds)
+        if not seeds:
+            return out
+        t0 = time.perf_counter()
+        out[0] = self.prove_proof(seed=seeds[0], **kw)  # also fills the twiddle cache every worker shares
+        nxt = itertools.count(1)
+        errors: list = []
+
+        def work(w: int) -> None:
+            gp = self if w == 0 else GpuProver(self.ver)
+            gp._dom = self._dom  # read-only from here on
+            try:
+                with torch.cuda.stream(torch.cuda.Stream(device=self.dev)):
+                    while not errors:
+                        i = next(nxt)
+                        if i >= len(seeds):
+                            return
+                        out[i] = gp.prove_proof(seed=seeds[i], **kw)
+            except BaseException as e:  # noqa: BLE001
+                errors.append(e)
+        threads = [threading.Thread(target=work, args=(w,)) for w in range(max(1, min(workers, len(seeds) - 1)))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        torch.cuda.synchronize(self.dev)
+        dt = time.perf_counter() - t0
+        self.timings = {"total": dt, "proofs_per_s": len(seeds) / dt, "workers": len(threads)}
+        return out
 
     def prove(self, n_cols: int = 4, trace_log: int = 9, log_blowup: int = 4, n_queries: int = 16,
               pow_bits: int = 5, seed: int = 0, hash: str = "sha256") -> dict:

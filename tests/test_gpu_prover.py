@@ -116,3 +116,16 @@ def test_random_shapes_prove_verify_and_match_the_oracle(gp):
             want = O.stwo_verify_batch(batch, mode)
             assert got.tolist() == want.tolist(), (kw, mode)
         assert gp.ver.verify_stwo(batch, cfg=batch[0].cfg)[0] == 0, kw
+
+
+def test_prove_many_is_byte_identical_to_one_at_a_time(gp):
+    """prove_many: several proofs in flight on their own streams give, seed for seed, the proofs of prove_proof."""
+    kw = dict(n_cols=4, trace_log=12, log_blowup=4, n_queries=16, pow_bits=5, hash="sha256")
+    seeds = [3, 0, 11, 5, 8, 2, 9]
+    want = [ss.stwo_to_json(gp.prove_proof(seed=s, **kw)) for s in seeds]
+    for workers in (1, 3):
+        got = gp.prove_many(seeds, workers=workers, **kw)
+        assert [ss.stwo_to_json(p) for p in got] == want
+    assert gp.timings["proofs_per_s"] > 0
+    status = gp.ver.verify_stwo(got, cfg=got[0].cfg)
+    assert status.tolist() == [0] * len(seeds)

@@ -38,5 +38,13 @@ if trace_log == 20 and hash_name == "sha256" and os.path.exists(gold):
     same = ss.stwo_to_json(want) == ss.stwo_to_json(proof)
     print("identical to the numpy prover's committed 2^20 proof:", same)
     assert same
+if len(sys.argv) > 4:  # throughput with several proofs in flight: `prover_bench.py 20 3 sha256 <workers,...> [proofs]`
+    n_many = int(sys.argv[5]) if len(sys.argv) > 5 else 48
+    for w in [int(x) for x in sys.argv[4].split(",")]:
+        many = gp.prove_many(list(range(n_many)), workers=w, n_cols=4, trace_log=trace_log, log_blowup=4, n_queries=16,
+                             pow_bits=5, hash=hash_name)
+        assert ss.stwo_to_json(many[0]) == ss.stwo_to_json(proof)
+        print("prove_many: %d proofs, %d in flight: %.1f proofs/s (%.2f ms per proof)"
+              % (n_many, w, gp.timings["proofs_per_s"], 1e3 / gp.timings["proofs_per_s"]), flush=True)
 print(json.dumps({"metric": "prove time, wide-Fibonacci 2^%d x 4, blowup 16, Q=16" % trace_log, "value": best[0],
                   "unit": "s", "hash": hash_name, "stages_s": best[1]}))
