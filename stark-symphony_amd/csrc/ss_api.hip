@@ -12,6 +12,7 @@
 #include <string>
 
 #include "../../include/ss_verify.h"
+#include "ss_copy.h"
 #include "ss_ctx.h"
 #include "ss_fields.h"
 #include "ss_ingest.h"
@@ -606,8 +607,8 @@ extern "C" int ss_stwo_verify_records(ss_ctx *ctx, const ss_stwo_cfg *c, size_t 
         const size_t cnt = std::min(chunk, n - lo);
         HIP_TRY(hipEventSynchronize(hp.pinned_free[buf]));  // previous upload from this buffer done
         uint32_t *stage = (uint32_t *)hp.pinned[buf];
-        parallel_for(cnt, [&](size_t i) { memcpy(stage + i * W, records[lo + i], W * 4); },
-                     std::max<size_t>(1, cnt * W * 4 / (4u << 20)));
+        parallel_for(cnt, [&](size_t i) { copy_streaming(stage + i * W, records[lo + i], W * 4); },
+                     std::max<size_t>(1, std::min<size_t>(8, cnt * W * 4 / (4u << 20))));
         HIP_TRY(hipMemcpyAsync(rec_dev + lo * W, stage, cnt * W * 4, hipMemcpyHostToDevice, s));
         HIP_TRY(hipEventRecord(hp.pinned_free[buf], s));
     }

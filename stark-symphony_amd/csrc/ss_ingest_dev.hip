@@ -14,7 +14,6 @@
 // the GPU reader of chunk c+1 runs beside the verification of chunk c.
 #include <hip/hip_runtime.h>
 
-#include <emmintrin.h>
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -27,6 +26,7 @@
 #include <thread>
 #include <vector>
 
+#include "ss_copy.h"
 #include "ss_ctx.h"
 #include "ss_ingest.h"
 #include "ss_layout.h"
@@ -148,25 +148,6 @@ struct Chunk {
     size_t lo = 0, cnt = 0;
     size_t text_bytes = 0;  // aligned text area
 };
-
-// Copy into pinned staging with streaming stores: the destination is read next by the DMA engine, not by a
-// core, so it should neither be fetched into the cache first (a read for ownership per line) nor push the
-// source out of it.  dst is 16-byte aligned (every text starts at an aligned offset of the staging buffer).
-void copy_streaming(uint8_t *dst, const void *src_, size_t n)
-{
-    const uint8_t *src = (const uint8_t *)src_;
-    size_t i = 0;
-    for (; i + 64 <= n; i += 64) {
-        const __m128i a = _mm_loadu_si128((const __m128i *)(src + i)), b = _mm_loadu_si128((const __m128i *)(src + i + 16));
-        const __m128i c = _mm_loadu_si128((const __m128i *)(src + i + 32)), d = _mm_loadu_si128((const __m128i *)(src + i + 48));
-        _mm_stream_si128((__m128i *)(dst + i), a);
-        _mm_stream_si128((__m128i *)(dst + i + 16), b);
-        _mm_stream_si128((__m128i *)(dst + i + 32), c);
-        _mm_stream_si128((__m128i *)(dst + i + 48), d);
-    }
-    if (i < n) memcpy(dst + i, src + i, n - i);
-    _mm_sfence();
-}
 
 // read a whole file into dst (cap bytes); returns its length, or -1 (absent, unreadable, longer than cap)
 long read_into(const char *path, uint8_t *dst, size_t cap)

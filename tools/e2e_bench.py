@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--fmt", default="both")
     ap.add_argument("--workload", default="stwo_trace20.npz")
     ap.add_argument("--noncanonical", type=float, default=0.0, help="fraction of texts with reversed member order (host reader)")
+    ap.add_argument("--files", action="store_true", help="also time ss_stwo_verify_files on the same texts written to a temp directory")
     args = ap.parse_args()
     p = records.load_stwo_npz(os.path.join(ROOT, "tests", "golden", args.workload))[0]
     cfg = p.cfg
@@ -56,12 +57,32 @@ def main():
         ver.verify_stwo_texts(cfg, batch, fmt=fmt)
         timing = ver.collect_timing()
         ver.set_timing(False)
+        file_rate = None
+        if args.files:
+            import tempfile
+            with tempfile.TemporaryDirectory() as d:
+                paths = []
+                for i in range(args.n):
+                    pth = os.path.join(d, "p%05d.%s" % (i, kind))
+                    with open(pth, "wb") as f:
+                        f.write(batch[i])
+                    paths.append(pth)
+                ver.verify_stwo_files(cfg, paths, fmt=fmt)
+                ft = []
+                for _ in range(args.reps):
+                    t0 = time.perf_counter()
+                    status, _ = ver.verify_stwo_files(cfg, paths, fmt=fmt)
+                    ft.append(time.perf_counter() - t0)
+                    assert (status == 0).all()
+                file_rate = args.n / min(ft)
         best, med = min(times), statistics.median(times)
         out[kind] = {"text_bytes": len(text), "proofs_per_s_best": args.n / best, "proofs_per_s_median": args.n / med,
                      "text_GB_per_s_best": args.n * len(text) / best / 1e9, "total_ms_best": best * 1e3,
                      "stage_ms": st["read_s"] * 1e3, "host_reader_ms": st["parse_s"] * 1e3, "host_parsed": st["host_parsed"],
                      "kernel_ms_per_call": {k: round(v[0], 3) for k, v in timing.items()},
                      "kernel_launches": {k: v[1] for k, v in timing.items()}}
+        if file_rate is not None:
+            out[kind]["files_proofs_per_s_best"] = file_rate
     print(json.dumps(out))
 
 
