@@ -137,6 +137,7 @@ class GpuProver:
         sig("ss_p_fri_fold", sz, u32p, u32p, u32p, u32p)
         sig("ss_p_pow", C.c_uint32, u32p, C.c_uint64, C.c_uint64, C.c_uint64, u32p)
         self._dom: Dict[int, tuple] = {}
+        self._workers: list = []  # (prover, stream) of prove_many
         self.timings: Dict[str, float] = {}
 
     # -- small helpers ---------------------------------------------------------------------
@@ -464,11 +465,16 @@ class GpuProver:
         nxt = itertools.count(1)
         errors: list = []
 
+        # worker provers and their streams live as long as this prover: the caching allocator keeps a pool per
+        # stream, so a fresh stream per call would start every call with gigabytes of hipMalloc
+        while len(self._workers) < workers:
+            self._workers.append((self if not self._workers else GpuProver(self.ver), torch.cuda.Stream(device=self.dev)))
+
         def work(w: int) -> None:
-            gp = self if w == 0 else GpuProver(self.ver)
+            gp, stream = self._workers[w]
             gp._dom = self._dom  # read-only from here on
             try:
-                with torch.cuda.stream(torch.cuda.Stream(device=self.dev)):
+                with torch.cuda.stream(stream):
                     while not errors:
                         i = next(nxt)
                         if i >= len(seeds):
@@ -477,10 +483,19 @@ class GpuProver:
             except BaseException as e:  # noqa: BLE001
                 errors.append(e)
         threads = [threading.Thread(target=work, args=(w,)) for w in range(max(1, min(workers, len(seeds) - 1)))]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
+        # A worker that wakes from a stream synchronisation needs the interpreter lock back; with CPython's default
+        # 5 ms switch interval it can wait that long for a thread that is busy converting arrays, which is a third
+        # of a whole proof.  Ask for the lock every 50 us while the workers run.
+        import sys
+        interval = sys.getswitchinterval()
+        sys.setswitchinterval(5e-5)
+        try:
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        finally:
+            sys.setswitchinterval(interval)
         if errors:
             raise errors[0]
         torch.cuda.synchronize(self.dev)
