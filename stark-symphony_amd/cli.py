@@ -7,6 +7,7 @@
     python -m stark_symphony_amd.cli verify --family stwo --trace-log 20 --lde-log 24 --n-layers 19 --proof p.json
     python -m stark_symphony_amd.cli convert --family stwo --to wit tests/data/proof.json     # generate_wit.py
     python -m stark_symphony_amd.cli convert --family stwo --to simf tests/data/proof.json    # generate_simf.py
+    python -m stark_symphony_amd.cli convert --family stwo --to json-shared tests/data/proof.json   # shared Merkle paths
 
 Exit 0 when every input is ACCEPTed, 1 otherwise (REJECT or malformed witness, like the
 reference, whose type errors also end in exit 1: main.rs:77-81,187-190).  Runs on GPU 0.
@@ -45,7 +46,9 @@ def convert(args) -> int:
                 reader = formats.stwo_from_wit if kind == "wit" else formats.stwo_from_simf
                 p = reader(text, args.trace_log, args.pow_bits)
             out = {"wit": formats.stwo_to_wit, "simf": formats.stwo_to_simf,
-                   "json": lambda q: json.dumps(formats.stwo_to_json(q))}[args.to](p)
+                   "json": lambda q: json.dumps(formats.stwo_to_json(q)),
+                   # every distinct Merkle sibling once + the query positions (formats.shared_path_order)
+                   "json-shared": lambda q: json.dumps(formats.stwo_to_json(q, shared=True))}[args.to](p)
     except (formats.MalformedProof, OSError, ValueError) as e:
         print("Error: %s" % e, file=sys.stderr)
         return 1
@@ -75,7 +78,7 @@ def main(argv=None) -> int:
     c = sub.add_parser("convert", help="proof.json -> .wit / .simf snippet (the reference's "
                                        "scripts/generate_wit.py and generate_simf.py, same text), or back")
     c.add_argument("--family", choices=["stark101", "stwo"], required=True)
-    c.add_argument("--to", choices=["wit", "simf", "json"], required=True)
+    c.add_argument("--to", choices=["wit", "simf", "json", "json-shared"], required=True)
     c.add_argument("path", help="proof.json, .wit or .simf snippet (by extension; anything else = json)")
     c.add_argument("--trace-log", type=int, default=None)
     c.add_argument("--pow-bits", type=int, default=5)

@@ -699,6 +699,56 @@ struct RecordMap {
     uint32_t &plen(uint32_t *r, uint32_t kind, uint32_t q) const { return r[tbase + kind * Q + q]; }
 };
 
+// The "shared paths" variant of proof.json (formats.shared_path_order): every distinct sibling of a tree once, in
+// the order a walk over query 0, 1, .. leaf -> root first needs it, plus a top-level "queries" member with the
+// positions.  expand_shared undoes the sharing for one tree: `nodes` = the tree's shared list, out = Q x len hashes.
+bool expand_shared(const Tree &t, uint32_t hw, const std::vector<uint32_t> &qpos, uint32_t shift, uint32_t len,
+                   std::vector<U256> &out)
+{
+    const uint32_t Q = (uint32_t)qpos.size();
+    // plan[q][lvl] = index of (lvl, (idx >> lvl) ^ 1) in first-use order; at most Q distinct positions per level
+    std::vector<uint32_t> plan((size_t)Q * len), seen_pos((size_t)len * Q), seen_id((size_t)len * Q), seen_n(len, 0);
+    uint32_t count = 0;
+    for (uint32_t q = 0; q < Q; q++) {
+        const uint32_t idx = qpos[q] >> shift;
+        for (uint32_t lvl = 0; lvl < len; lvl++) {
+            const uint32_t pos = (idx >> lvl) ^ 1;
+            uint32_t id = ~0u;
+            for (uint32_t j = 0; j < seen_n[lvl]; j++)
+                if (seen_pos[(size_t)lvl * Q + j] == pos) { id = seen_id[(size_t)lvl * Q + j]; break; }
+            if (id == ~0u) {
+                id = count++;
+                seen_pos[(size_t)lvl * Q + seen_n[lvl]] = pos;
+                seen_id[(size_t)lvl * Q + seen_n[lvl]] = id;
+                seen_n[lvl]++;
+            }
+            plan[(size_t)q * len + lvl] = id;
+        }
+    }
+    if (!hw || !t.is_list(hw) || t.count(hw) != count) return false;
+    std::vector<U256> nodes(count);
+    ListIter it(t, hw);
+    for (uint32_t i = 0; i < count; i++)
+        if (!it.hash(nodes[i].w)) return false;
+    out.resize((size_t)Q * len);
+    for (size_t i = 0; i < out.size(); i++) out[i] = nodes[plan[i]];
+    return true;
+}
+
+// the hashes of a hash_witness in (query, level) order: the list itself, or what expand_shared made of it
+struct HashSeq {
+    ListIter it;
+    const std::vector<U256> *vec;
+    size_t pos = 0;
+    HashSeq(const Tree &t, uint32_t hw, const std::vector<U256> *v) : it(t, v ? 0 : hw), vec(v) {}
+    bool next(uint32_t *h)
+    {
+        if (!vec) return it.hash(h);
+        memcpy(h, (*vec)[pos++].w, 32);
+        return true;
+    }
+};
+
 // ---------------------------------------------------------------- stwo, format C (proof.json)
 // formats.stwo_from_json, with the expected config given (`expect=`): what the JSON does not
 // declare is the verifier's; what it declares, and every array length, must agree with it.
@@ -751,8 +801,23 @@ ParseResult stwo_from_json(const ss_stwo_cfg &cfg, const Tree &t, uint32_t *rec)
     const uint32_t qv1 = qv ? t.child(qv, 1) : 0, qv2 = qv ? t.child(qv, 2) : 0;
     if (!hw1 || !hw2 || !qv1 || !qv2 || !t.is_list(hw1) || !t.is_list(hw2) || !t.is_list(qv1) || !t.is_list(qv2))
         return kMalformed;
-    if (t.count(hw1) % Q || t.count(hw2) % Q || t.count(qv1) % Q || t.count(qv2) % Q) return kMalformed;
-    const uint32_t tlen = t.count(hw1) / Q, clen = t.count(hw2) / Q;
+    // ---- the shared-path variant names its query positions; the LDE size is the verifier's (paths have no ends there)
+    const uint32_t qn = t.member(0, "queries");
+    const bool shared = qn != 0;
+    std::vector<uint32_t> qpos;
+    std::vector<U256> ex1, ex2;
+    if (shared) {
+        if (!t.is_list(qn) || t.count(qn) != Q) return kMalformed;
+        ListIter it(t, qn);
+        for (uint32_t q = 0; q < Q; q++) {
+            if (!it.u32(v) || (v >> cfg.lde_log)) return kMalformed;
+            qpos.push_back(v);
+        }
+        if (!expand_shared(t, hw1, qpos, 0, cfg.lde_log, ex1) || !expand_shared(t, hw2, qpos, 0, cfg.lde_log, ex2)) return kMalformed;
+    }
+    if (!shared && (t.count(hw1) % Q || t.count(hw2) % Q)) return kMalformed;
+    if (t.count(qv1) % Q || t.count(qv2) % Q) return kMalformed;
+    const uint32_t tlen = shared ? cfg.lde_log : t.count(hw1) / Q, clen = shared ? cfg.lde_log : t.count(hw2) / Q;
     if (tlen > kMaxList || clen > kMaxList) return kMalformed;
     if (t.count(qv1) != Q * N || t.count(qv2) != Q * kCp) return kMalformed;
     mismatch |= tlen != cfg.lde_log;  // LDE_LOG_SIZE is the length of the first trace path
@@ -818,41 +883,50 @@ ParseResult stwo_from_json(const ss_stwo_cfg &cfg, const Tree &t, uint32_t *rec)
             }
         }
     }
-    auto paths = [&](uint32_t hw, uint32_t len, uint32_t slot, auto dst_of, uint32_t kind) -> bool {
-        ListIter it(t, hw);
+    auto paths = [&](uint32_t hw, const std::vector<U256> *expanded, uint32_t len, uint32_t slot, auto dst_of,
+                     uint32_t kind) -> bool {
+        HashSeq it(t, hw, expanded);
         for (uint32_t q = 0; q < Q; q++) {
             for (uint32_t k = 0; k < len; k++) {
                 uint32_t h[8];
-                if (!it.hash(h)) return false;
+                if (!it.next(h)) return false;
                 if (r && k < slot) memcpy(dst_of(q) + 8 * k, h, 32);
             }
             if (r) m.plen(r, kind, q) = len;
         }
         return true;
     };
-    if (!paths(hw1, tlen, m.L, [&](uint32_t q) { return m.trace_path(r, q); }, 0)) return kMalformed;
-    if (!paths(hw2, clen, m.L, [&](uint32_t q) { return m.cp_path(r, q); }, 1)) return kMalformed;
+    if (!paths(hw1, shared ? &ex1 : nullptr, tlen, m.L, [&](uint32_t q) { return m.trace_path(r, q); }, 0)) return kMalformed;
+    if (!paths(hw2, shared ? &ex2 : nullptr, clen, m.L, [&](uint32_t q) { return m.cp_path(r, q); }, 1)) return kMalformed;
+    if (shared && (K + 1 >= cfg.lde_log)) return kMalformed;  // a FRI tree would have no levels left
     uint32_t inner_c = inner ? t.first_child(inner) : 0;
     for (uint32_t l = 0; l <= K; l++) {
         const uint32_t layer = l == 0 ? first : t.next_child(inner_c);
         if (!layer || t.nodes[layer].kind != kObj) return kMalformed;
         const uint32_t w = t.member(layer, "fri_witness"), d = t.member(layer, "decommitment");
         const uint32_t hw = d ? t.member(d, "hash_witness") : 0, cm = t.member(layer, "commitment");
-        if (!w || !hw || !cm || !t.is_list(w) || !t.is_list(hw) || t.count(w) != Q || t.count(hw) % Q) return kMalformed;
+        if (!w || !hw || !cm || !t.is_list(w) || !t.is_list(hw) || t.count(w) != Q) return kMalformed;
+        std::vector<U256> exl;
+        if (shared) {  // FRI layer l is indexed by query >> (l + 1) in a tree of depth lde_log - 1 - l
+            if (!expand_shared(t, hw, qpos, l + 1, cfg.lde_log - 1 - l, exl)) return kMalformed;
+        } else if (t.count(hw) % Q) {
+            return kMalformed;
+        }
         uint32_t h[8];
         if (!t.is_list(cm) || !get_hash(t, cm, h)) return kMalformed;
         const bool keep = r && l <= m.K;
         if (keep) memcpy(r + 24 + 4 * m.N + 64 + 8 * l, h, 32);
-        const uint32_t len = t.count(hw) / Q;
+        const uint32_t len = shared ? cfg.lde_log - 1 - l : t.count(hw) / Q;
         if (len > kMaxList) return kMalformed;
-        ListIter iw(t, w), ih(t, hw);
+        ListIter iw(t, w);
+        HashSeq ih(t, hw, shared ? &exl : nullptr);
         for (uint32_t q = 0; q < Q; q++) {
             if (!iw.qm31(tmp)) return kMalformed;
             uint32_t *dst = keep ? m.fri_wit(r, l, q) : nullptr;
             if (dst) memcpy(dst, tmp, 16);
             const uint32_t slot = keep ? m.L - 1 - l : 0;
             for (uint32_t k = 0; k < len; k++) {
-                if (!ih.hash(h)) return kMalformed;
+                if (!ih.next(h)) return kMalformed;
                 if (dst && k < slot) memcpy(dst + 4 + 8 * k, h, 32);
             }
             if (keep) m.plen(r, 2 + l, q) = len;

@@ -273,7 +273,8 @@ __global__ void __launch_bounds__(64) text_place_kernel(TextParseArgs a)
 
     const uint4 cur = text4[(size_t)w * 64 + lane];
     uint4 nxt = make_uint4(0, 0, 0, 0);
-    if (w + 1 < nwin) nxt = text4[(size_t)(w + 1) * 64 + lane];
+    // a number that starts in this window may run into the next: its first kMaxTokenBytes bytes are enough
+    if (w + 1 < nwin && lane * 16 < kMaxTokenBytes) nxt = text4[(size_t)(w + 1) * 64 + lane];
     const uint32_t win0 = w << 10, pos0 = win0 + lane * 16;
     const uint32_t nvalid = pos0 >= len ? 0 : (len - pos0 < 16 ? len - pos0 : 16);
     s_text4[lane] = cur;
@@ -336,7 +337,8 @@ __global__ void __launch_bounds__(64) text_place_kernel(TextParseArgs a)
     }
     // ---- the numbers that start in this lane's bytes
     {
-        const uint32_t lim = len - win0 < 2048 ? len - win0 : 2048;  // text bytes present in s_text
+        const uint32_t have = 1024 + kMaxTokenBytes;                  // text bytes present in s_text
+        const uint32_t lim = len - win0 < have ? len - win0 : have;
         uint32_t k = tk0, mm = mark_mask;
         while (mm && !mism) {
             const uint32_t j = __ffs(mm) - 1;

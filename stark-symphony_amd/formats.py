@@ -462,6 +462,114 @@ def _split(lst: Sequence[Any], n: int) -> List[Sequence[Any]]:
     return [lst[i * k:(i + 1) * k] for i in range(n)]
 
 
+def shared_path_order(lde_log: int, n_layers: int, queries: Sequence[int]):
+    """The "shared paths" variant of proof.json (what the reference notes it does not do,
+    stwo-verifier/src/fri/queries.simf:41).  The per-query format repeats a sibling node for every query whose
+    authentication path passes it; the shared variant stores every DISTINCT sibling of a tree once, in the order a
+    verifier that walks query 0, 1, .. leaf -> root first needs it, and names the query positions in a top-level
+    "queries" member so that a reader can undo the sharing WITHOUT hashing (the positions are a hint, not trusted:
+    the verifier draws its own and checks the expanded paths in full, so a wrong hint can only make a proof fail).
+    Upstream stwo's MerkleDecommitment goes further and also omits siblings the verifier can compute from other
+    queries' leaves; undoing that needs hashing, i.e. a different verifier, and no bytes of either variant exist
+    in the reference to be equal to.
+
+    -> for each tree (trace, composition, FRI layer 0..K): (len, plan) with plan[q][lvl] = index into the tree's
+    shared node list of query q's sibling at level lvl."""
+    out = []
+    lens = [lde_log, lde_log] + [lde_log - 1 - l for l in range(n_layers + 1)]
+    for t, ln in enumerate(lens):
+        shift = 0 if t < 2 else t - 1          # FRI layer l (tree 2 + l) is indexed by query >> (l + 1)
+        seen: dict = {}
+        plan = []
+        for q in queries:
+            idx = int(q) >> shift
+            row = []
+            for lvl in range(ln):
+                key = (lvl, (idx >> lvl) ^ 1)
+                if key not in seen:
+                    seen[key] = len(seen)
+                row.append(seen[key])
+            plan.append(row)
+        out.append((ln, plan, len(seen)))
+    return out
+
+
+def _expand_shared(data: dict, lde_log: int, Q: int) -> dict:
+    """proof.json with "queries" and shared hash_witness lists -> the same object in the per-query form."""
+    import copy
+    queries = data["queries"]
+    if not isinstance(queries, list) or len(queries) != Q:
+        raise MalformedProof("shared-path proof: one query position per query expected")
+    qs = [_uint(q, 32) for q in queries]
+    if lde_log < 1 or lde_log > MAX_LIST or any(q >> lde_log for q in qs):
+        raise MalformedProof("shared-path proof: query position outside the LDE domain")
+    fri = data["fri_proof"]
+    layers = [fri["first_layer"]] + list(fri.get("inner_layers", []))
+    K = len(layers) - 1
+    if K + 1 >= lde_log or K > MAX_LIST:
+        raise MalformedProof("shared-path proof: too many FRI layers for the LDE size")
+    out = copy.copy(data)
+    out.pop("queries")
+    plans = shared_path_order(lde_log, K, qs)
+
+    def expand(nodes, plan):
+        ln, rows, count = plan
+        if not isinstance(nodes, list) or len(nodes) != count:
+            raise MalformedProof("shared-path proof: %d distinct siblings expected" % count)
+        return [nodes[i] for row in rows for i in row]
+    dec = [dict(d) if isinstance(d, dict) else d for d in data["decommitments"]]
+    dec[1]["hash_witness"] = expand(dec[1]["hash_witness"], plans[0])
+    dec[2]["hash_witness"] = expand(dec[2]["hash_witness"], plans[1])
+    out["decommitments"] = dec
+    new_layers = []
+    for l, layer in enumerate(layers):
+        layer = dict(layer)
+        layer["decommitment"] = dict(layer["decommitment"])
+        layer["decommitment"]["hash_witness"] = expand(layer["decommitment"]["hash_witness"], plans[2 + l])
+        new_layers.append(layer)
+    out["fri_proof"] = dict(fri, first_layer=new_layers[0], inner_layers=new_layers[1:])
+    return out
+
+
+def stwo_queries(p: "StwoProof") -> List[int]:
+    """The query positions of a proof: the public part of the Fiat-Shamir transcript replayed with hashlib
+    (stwo-verifier/src/channel.simf:31-172 in the order of verifier.simf:32-58).  No check of the proof is made;
+    `convert --to json-shared` uses this to know which siblings coincide."""
+    import hashlib
+    H = hashlib.sha256 if p.cfg.hash == "sha256" else (lambda b: hashlib.blake2s(b, digest_size=32))
+    state = {"d": bytes(32), "c": 0}
+
+    def mix(b: bytes) -> None:
+        state["d"], state["c"] = H(state["d"] + b).digest(), 0
+
+    def draw_words() -> List[int]:
+        d = H(state["d"] + state["c"].to_bytes(4, "big")).digest()
+        state["c"] += 1
+        return [int.from_bytes(d[4 * i:4 * i + 4], "big") for i in range(8)]
+
+    def draw_qm31() -> None:
+        for _ in range(256):  # channel.simf:127-135: retry while a word is >= 2^32 - 2
+            if all(x < 4294967294 for x in draw_words()[:4]):
+                return
+        raise MalformedProof("channel draw exhausted")
+
+    def be(words) -> bytes:
+        return b"".join(int(w).to_bytes(4, "big") for w in np.asarray(words).reshape(-1))
+    mix(bytes(p.roots[0])); mix(bytes(p.roots[1])); draw_qm31(); mix(bytes(p.roots[2]))
+    draw_qm31()
+    mix(be(p.oods_trace) + be(p.oods_cp))
+    draw_qm31()
+    for r in p.fri_roots:
+        mix(bytes(r))
+        draw_qm31()
+    mix(be(p.last_layer))
+    mix(int(p.pow_nonce).to_bytes(8, "big"))
+    mask, out = (1 << p.cfg.lde_log) - 1, []
+    while len(out) < p.cfg.n_queries:
+        out += [w & mask for w in draw_words()]
+    return out[:p.cfg.n_queries]
+
+
 def stwo_from_json(data: Any, trace_log: int | None = None, hash: str | None = None,
                    expect: "StwoConfig | None" = None) -> StwoProof:
     """Format C.  The JSON carries pow_bits / log_blowup / n_queries; the LDE size is
@@ -485,6 +593,14 @@ def stwo_from_json(data: Any, trace_log: int | None = None, hash: str | None = N
                 raise MalformedProof("config has no %r and no expected config was given" % key)
             return int(fallback)
         Q = declared(fri_conf, "n_queries", expect and expect.n_queries)
+        if "queries" in data:  # the shared-path variant: undo the sharing first (needs the LDE size: paths have no ends)
+            if expect is not None:
+                lde_hint = expect.lde_log
+            elif trace_log is not None and "log_blowup_factor" in fri_conf:
+                lde_hint = trace_log + _uint(fri_conf["log_blowup_factor"], 32)
+            else:
+                raise MalformedProof("a shared-path proof.json can only be read against an expected config")
+            data = _expand_shared(data, lde_hint, Q)
         roots = np.stack([np.frombuffer(bytes(c), dtype=np.uint8) for c in data["commitments"]])
         if roots.shape != (3, 32):
             raise MalformedProof("expected three 32-byte commitments")
@@ -539,13 +655,35 @@ def stwo_from_json(data: Any, trace_log: int | None = None, hash: str | None = N
         raise MalformedProof(str(e)) from e
 
 
-def stwo_to_json(p: StwoProof) -> dict:
-    """Writer for format C (what an stwo-style prover would emit)."""
+def stwo_to_json(p: StwoProof, shared: bool = False, queries: "Sequence[int] | None" = None) -> dict:
+    """Writer for format C (what an stwo-style prover would emit).  shared=True writes the shared-path variant
+    (shared_path_order): every distinct sibling once + a "queries" member; the positions come from `queries` (a
+    prover knows them) or from replaying the public transcript (stwo_queries).  Only proofs whose paths all have
+    the config's lengths and agree wherever they meet can be written that way."""
     def q(v: Sequence[int]) -> List[List[int]]:
         return [[int(v[0]), int(v[1])], [int(v[2]), int(v[3])]]
 
+    plans = None
+    if shared:
+        qs = [int(x) for x in (queries if queries is not None else stwo_queries(p))]
+        plans = shared_path_order(p.cfg.lde_log, p.cfg.n_layers, qs)
+        tree_no = {"n": 0}
+
     def hw(paths: List[np.ndarray]) -> List[List[int]]:
-        return [[int(b) for b in node] for pth in paths for node in pth]
+        if plans is None:
+            return [[int(b) for b in node] for pth in paths for node in pth]
+        ln, rows, count = plans[tree_no["n"]]
+        tree_no["n"] += 1
+        nodes: List[Any] = [None] * count
+        for pth, row in zip(paths, rows):
+            if len(pth) != ln:
+                raise MalformedProof("only full-length Merkle paths can be shared")
+            for node, i in zip(pth, row):
+                val = [int(b) for b in node]
+                if nodes[i] is not None and nodes[i] != val:
+                    raise MalformedProof("two queries present different bytes for one node: no shared form")
+                nodes[i] = val
+        return nodes
 
     def layer(i: int) -> dict:
         return {"fri_witness": [q(w) for w in p.fri_witness[i]],
@@ -557,20 +695,26 @@ def stwo_to_json(p: StwoProof) -> dict:
                            "log_last_layer_degree_bound": 0, "n_queries": c.n_queries}}
     if c.hash != "sha256":
         conf["hash"] = c.hash  # extension key; the reference's JSON has none (always SHA-256)
-    return {
+    # (hw() consumes the trees in the order trace, composition, FRI layer 0.. : keep the evaluation order below)
+    dec = [{"hash_witness": [], "column_witness": []},
+           {"hash_witness": hw(p.trace_paths), "column_witness": []},
+           {"hash_witness": hw(p.cp_paths), "column_witness": []}]
+    fri_layers = [layer(i) for i in range(c.n_layers + 1)]
+    out = {
         "config": conf,
         "commitments": [[int(b) for b in r] for r in p.roots],
         "sampled_values": [[], [[q(v)] for v in p.oods_trace], [[q(v)] for v in p.oods_cp]],
-        "decommitments": [{"hash_witness": [], "column_witness": []},
-                          {"hash_witness": hw(p.trace_paths), "column_witness": []},
-                          {"hash_witness": hw(p.cp_paths), "column_witness": []}],
+        "decommitments": dec,
         "queried_values": [[], [int(x) for x in p.trace_vals.reshape(-1)],
                            [int(x) for x in p.cp_vals.reshape(-1)]],
         "proof_of_work": int(p.pow_nonce),
-        "fri_proof": {"first_layer": layer(0),
-                      "inner_layers": [layer(i) for i in range(1, c.n_layers + 1)],
+        "fri_proof": {"first_layer": fri_layers[0],
+                      "inner_layers": fri_layers[1:],
                       "last_layer_poly": {"coeffs": [q(p.last_layer)], "log_size": 0}},
     }
+    if shared:
+        out["queries"] = qs
+    return out
 
 
 def stwo_from_wit(text: Any, trace_log: int, pow_bits: int = 5, hash: str = "sha256") -> StwoProof:

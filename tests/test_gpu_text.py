@@ -267,3 +267,22 @@ def test_stark101_device_pack_equals_host_pack(ver):
                                                      int(torch.cuda.current_stream(ver.device).cuda_stream)))
         torch.cuda.synchronize()
         assert np.array_equal(out.cpu().numpy().view(np.uint32), host)
+
+
+def test_shared_path_texts_verify_like_their_per_query_form(ver):
+    """The shared-path variant of proof.json (tests/test_shared_paths.py) through ss_stwo_verify_texts: the host reader
+    undoes the sharing, the kernels verify the expanded proof; status words equal the oracle's on the per-query form."""
+    base = ss.stwo_from_json(json.load(open(os.path.join(GOLDEN, "stwo_proof.json"))))
+    rng = np.random.default_rng(SEED + 93)
+    qs = formats.stwo_queries(base)
+    proofs, texts = [], []
+    for p in [base] + [formats.stwo_corrupt(base, rng)[0] for _ in range(40)]:
+        try:
+            texts.append(json.dumps(ss.stwo_to_json(p, shared=True, queries=qs)).encode())
+        except ss.MalformedProof:
+            continue  # two queries disagree about a node: no shared form
+        proofs.append(p)
+    want = O.stwo_verify_batch(proofs).tolist()
+    status, stats = ver.verify_stwo_texts(base.cfg, texts)
+    assert status.tolist() == want and want[0] == 0 and sum(1 for w in want if w) > 10
+    assert stats["host_parsed"] == len(texts)

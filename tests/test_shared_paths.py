@@ -1,0 +1,134 @@
+"""The shared-path variant of proof.json (second half): every distinct Merkle sibling of a tree
+once + the query positions, instead of one full path per query (the reference notes that it does not deduplicate:
+stwo-verifier/src/fri/queries.simf:41; its adapter splits per-query witnesses, scripts/generate_wit.py:36-40).
+No reference bytes exist for such a format, so parity is defined through expansion: a shared text must read, in
+formats.py and in the native reader alike, as exactly the per-query proof it was made from -- after which the
+verifier (and the oracle) see nothing new.  CPU only; the GPU leg is in tests/test_gpu_text.py."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import stark_symphony_amd as ss
+from stark_symphony_amd import formats, records, verifier
+from oracle import oracle as O
+
+from conftest import GOLDEN
+from test_ingest import MALFORMED, MISMATCH, OK, _python_outcome, _text_mutant
+
+
+def _fixtures():
+    out = [ss.stwo_from_json(json.load(open(os.path.join(GOLDEN, "stwo_proof.json")))),
+           ss.stwo_from_json(json.load(open(os.path.join(GOLDEN, "stwo_proof_test.json"))))]
+    for npz in ("stwo_trace16.npz", "stwo_wide256.npz", "stwo_trace16_blake2s.npz"):
+        out.append(records.load_stwo_npz(os.path.join(GOLDEN, npz))[0])
+    return out
+
+
+def test_query_positions_from_the_public_transcript():
+    """formats.stwo_queries replays the Fiat-Shamir transcript with hashlib; the oracle's verifier draws the same."""
+    for p in _fixtures():
+        st, tr = O.stwo_verify(p, O.MODE_FIXTURE, trace=True)
+        assert st == 0 and formats.stwo_queries(p) == [int(q) for q in list(tr.queries)[:p.cfg.n_queries]]
+
+
+def test_shared_text_reads_as_the_proof_it_was_made_from():
+    for p in _fixtures():
+        rec = verifier.stwo_record(p)
+        obj = ss.stwo_to_json(p, shared=True)
+        full = ss.stwo_to_json(p)
+        n_shared = sum(len(d["hash_witness"]) for d in obj["decommitments"]) + sum(
+            len(l["decommitment"]["hash_witness"]) for l in [obj["fri_proof"]["first_layer"]] + obj["fri_proof"]["inner_layers"])
+        n_full = sum(len(d["hash_witness"]) for d in full["decommitments"]) + sum(
+            len(l["decommitment"]["hash_witness"]) for l in [full["fri_proof"]["first_layer"]] + full["fri_proof"]["inner_layers"])
+        assert n_shared < n_full * (0.97 if p.cfg.n_queries > 1 else 1.01)
+        text = json.dumps(obj, separators=(",", ":")).encode()
+        back = ss.stwo_from_json(json.loads(text), expect=p.cfg)
+        assert back.cfg == p.cfg and np.array_equal(verifier.stwo_record(back), rec)
+        got, nrec = verifier.parse_stwo_text(p.cfg, text)
+        assert got == OK and np.array_equal(nrec, rec)
+        if p.cfg.n_queries > 1:
+            assert len(text) < 0.93 * len(json.dumps(full, separators=(",", ":")))
+
+
+def test_shared_form_of_corrupted_proofs():
+    """Seeded corruptions: where the queries still agree about every shared node the shared text expands to the
+    same (corrupted) proof; where they do not, there is no shared form and the writer says so."""
+    base = _fixtures()[0]
+    rng = np.random.default_rng(0x5EED2025 + 404)
+    made = refused = 0
+    for _ in range(60):
+        p = formats.stwo_corrupt(base, rng)[0]
+        try:
+            obj = ss.stwo_to_json(p, shared=True, queries=formats.stwo_queries(base))
+        except ss.MalformedProof:
+            refused += 1
+            continue
+        made += 1
+        text = json.dumps(obj).encode()
+        got, nrec = verifier.parse_stwo_text(base.cfg, text)
+        assert got == OK and np.array_equal(nrec, verifier.stwo_record(p))
+    assert made > 20 and refused > 3
+
+
+def test_wrong_hints_and_wrong_counts():
+    p = _fixtures()[0]
+    cfg = p.cfg
+    obj = ss.stwo_to_json(p, shared=True)
+
+    def outcome(o):
+        text = json.dumps(o).encode()
+        want = _python_outcome(text, cfg, "json")[0]
+        assert verifier.parse_stwo_text(cfg, text)[0] == want
+        return want
+    import copy
+    o = copy.deepcopy(obj); o["queries"][3] ^= 1                       # a wrong position: other sharing pattern
+    assert outcome(o) in (OK, MALFORMED)                                # (reads as SOME proof or has the wrong count; never crashes)
+    o = copy.deepcopy(obj); o["queries"].pop()
+    assert outcome(o) == MALFORMED
+    o = copy.deepcopy(obj); o["queries"][0] = 1 << cfg.lde_log
+    assert outcome(o) == MALFORMED
+    o = copy.deepcopy(obj); o["decommitments"][1]["hash_witness"].pop()
+    assert outcome(o) == MALFORMED
+    o = copy.deepcopy(obj); o["decommitments"][2]["hash_witness"].append(o["decommitments"][2]["hash_witness"][0])
+    assert outcome(o) == MALFORMED
+    o = copy.deepcopy(obj); o["fri_proof"]["inner_layers"][2]["decommitment"]["hash_witness"].pop(0)
+    assert outcome(o) == MALFORMED
+    o = copy.deepcopy(obj); o["queries"] = "0123456789abcdef"
+    assert outcome(o) == MALFORMED
+    assert outcome(obj) == OK
+    other = ss.TESTING_CONFIG
+    text = json.dumps(obj).encode()
+    assert verifier.parse_stwo_text(other, text)[0] == _python_outcome(text, other, "json")[0] != OK
+
+
+def test_differential_fuzz_of_shared_texts():
+    rnd = random.Random(20261006)
+    p = _fixtures()[1]
+    base = json.dumps(ss.stwo_to_json(p, shared=True)).encode()
+    cfg = ss.TESTING_CONFIG
+    seen = {OK: 0, MISMATCH: 0, MALFORMED: 0}
+    for i in range(2500):
+        text = _text_mutant(rnd, base)
+        try:
+            want, rec = _python_outcome(text, cfg, "json")
+        except (UnicodeDecodeError, RecursionError):
+            want, rec = MALFORMED, None
+        got, grec = verifier.parse_stwo_text(cfg, text, fmt=1)
+        assert got == want, (i, got, want, text[:200])
+        if want == OK:
+            assert np.array_equal(grec, rec)
+        seen[want] += 1
+    assert seen[OK] > 50 and seen[MALFORMED] > 500
+
+
+def test_cli_converts_to_the_shared_form(capsys):
+    from stark_symphony_amd import cli
+    src = os.path.join(GOLDEN, "stwo_proof.json")
+    assert cli.main(["convert", "--family", "stwo", "--to", "json-shared", src]) == 0
+    out = capsys.readouterr().out
+    p = ss.stwo_from_json(json.loads(out), expect=ss.PRODUCTION_CONFIG)
+    want = ss.stwo_from_json(json.load(open(src)))
+    assert np.array_equal(verifier.stwo_record(p), verifier.stwo_record(want))
