@@ -72,6 +72,7 @@ struct StwoLayout {
 };
 
 constexpr uint32_t kTopChains = 256;     // chains a top-kernel block plans at once (= its threads)
+constexpr uint32_t kTopMinGroups = 1024;  // a smaller batch is cut into smaller groups until it gives this many
 // workspace slices of the persistent top kernel.  The launch uses min(groups, blocks resident at once), and at
 // 256 threads and >= 123 VGPRs per lane at most 4 blocks fit a CU (3 for SHA-256): 1024 on the 256 CUs of an MI355X.
 constexpr uint32_t kTopMaxBlocks = 1024;
@@ -91,7 +92,7 @@ SS_HD inline bool stwo_cfg_ok(uint32_t N, uint32_t TL, uint32_t L, uint32_t Q, u
 
 SS_HD inline StwoLayout stwo_layout(uint32_t N, uint32_t TL, uint32_t L, uint32_t Q, uint32_t K,
                                     uint32_t mode, uint64_t pow_target, uint64_t n, bool dedup = true,
-                                    bool light_hash = false)
+                                    bool light_hash = false, uint32_t min_groups = kTopMinGroups)
 {
     StwoLayout y{};
     y.N = N; y.TL = TL; y.L = L; y.Q = Q; y.K = K; y.mode = mode; y.pow_target = pow_target;
@@ -161,7 +162,7 @@ SS_HD inline StwoLayout stwo_layout(uint32_t N, uint32_t TL, uint32_t L, uint32_
     y.top_G = kTopChains / Q;  // Q <= kMaxQueries = 64
     // a batch that gives fewer groups than the ~1024 blocks the chip holds at once (4 per CU) is cut
     // into smaller groups: half-empty plans cost less than half-empty CUs
-    while (y.top_G > 1 && (n + y.top_G - 1) / y.top_G < 1024) y.top_G = (y.top_G + 1) / 2;
+    while (y.top_G > 1 && (n + y.top_G - 1) / y.top_G < min_groups) y.top_G = (y.top_G + 1) / 2;
     const uint64_t groups = (n + y.top_G - 1) / y.top_G;
     y.top_blocks = y.T ? (uint32_t)(groups < kTopMaxBlocks ? groups : kTopMaxBlocks) : 0;
     y.ws_top = w;   w += y.T ? (uint64_t)(K + 3) * y.nip * 8 : 0;

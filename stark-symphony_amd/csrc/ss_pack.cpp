@@ -4,6 +4,7 @@
 // offsets computed from caller-supplied configs.
 #include "ss_pack.h"
 
+#include <cstdlib>
 #include <cstring>
 
 #include "ss_pool.h"
@@ -17,8 +18,13 @@ bool ss::cfg_ok(const ss_stwo_cfg *c)
 }
 StwoLayout ss::lay_of(const ss_stwo_cfg *c, size_t n)
 {
+    static const uint32_t min_groups = [] {  // tuning knob (tools/r03/gpu_o.sh); the default is kTopMinGroups
+        const char *e = getenv("SS_TOP_MIN_GROUPS");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? (uint32_t)v : kTopMinGroups;
+    }();
     return stwo_layout(c->n_cols, c->trace_log, c->lde_log, c->n_queries, c->n_layers, c->mode,
-                       c->pow_target, n, !(c->flags & SS_FLAG_NO_DEDUP), c->hash == SS_HASH_BLAKE2S);
+                       c->pow_target, n, !(c->flags & SS_FLAG_NO_DEDUP), c->hash == SS_HASH_BLAKE2S, min_groups);
 }
 
 extern "C" size_t ss_stwo_record_words(const ss_stwo_cfg *c)
