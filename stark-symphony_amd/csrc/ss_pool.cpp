@@ -6,6 +6,8 @@
 #include <thread>
 #include <vector>
 
+#include <unistd.h>
+
 namespace ss {
 namespace {
 
@@ -19,6 +21,7 @@ class Pool {
     std::atomic<size_t> next_{0};
     uint64_t gen_ = 0;
     bool stop_ = false;
+    pid_t owner_ = getpid();  // a fork()ed child inherits this object but none of its threads
 
     void drain()
     {
@@ -52,6 +55,7 @@ public:
     }
     ~Pool()
     {
+        if (getpid() != owner_) { for (auto &t : workers_) t.detach(); return; }  // (the child of a fork: nothing to join)
         { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
         work_.notify_all();
         for (auto &t : workers_) t.join();
@@ -59,7 +63,7 @@ public:
     void run(size_t n, const std::function<void(size_t)> &f, size_t max_threads)
     {
         const size_t helpers = std::min(workers_.size(), std::min(n, max_threads) - 1);
-        if (n <= 1 || max_threads <= 1 || helpers == 0) { for (size_t i = 0; i < n; i++) f(i); return; }
+        if (n <= 1 || max_threads <= 1 || helpers == 0 || getpid() != owner_) { for (size_t i = 0; i < n; i++) f(i); return; }
         std::lock_guard<std::mutex> one(callers_);
         {
             std::lock_guard<std::mutex> lk(m_);

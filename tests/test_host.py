@@ -465,3 +465,19 @@ def test_stark101_channel_proof_transcript_reads_as_the_res_dict(s101_proof):
                 msgs[:12] + [msgs[13], msgs[12]] + msgs[14:], [b"short"] + msgs[1:]):
         with pytest.raises(ss.MalformedProof):
             ss.stark101_from_transcript(bad)
+
+
+def test_worker_pool_survives_a_fork(stwo_prod):
+    """The library's host threads (csrc/ss_pool.cpp) belong to the process that started them: a fork()ed child
+    (multiprocessing, a pre-forking server) packs serially instead of waiting for threads it does not have."""
+    recs = [verifier.stwo_record(stwo_prod)] * 64
+    want = verifier.pack_stwo(stwo_prod.cfg, verifier.MODE_FIXTURE, recs)  # starts the pool in this process
+    pid = os.fork()
+    if pid == 0:
+        try:
+            got = verifier.pack_stwo(stwo_prod.cfg, verifier.MODE_FIXTURE, recs)
+            os._exit(0 if np.array_equal(got, want) else 1)
+        finally:
+            os._exit(2)
+    _, st = os.waitpid(pid, 0)
+    assert os.WIFEXITED(st) and os.WEXITSTATUS(st) == 0
