@@ -286,3 +286,51 @@ def test_shared_path_texts_verify_like_their_per_query_form(ver):
     status, stats = ver.verify_stwo_texts(base.cfg, texts)
     assert status.tolist() == want and want[0] == 0 and sum(1 for w in want if w) > 10
     assert stats["host_parsed"] == len(texts)
+
+
+def test_long_runs_and_blank_blocks_across_windows(ver):
+    """States that must be carried over many windows: kilobytes of whitespace between two tokens of a canonical
+    proof.json (still canonical: same record), and kilobyte runs of digits / letters / quotes dropped into it at
+    positions before, inside and behind strings (never canonical; the scalar rule and the kernels agree on every one)."""
+    cfg = ss.PRODUCTION_CONFIG
+    j = open(os.path.join(GOLDEN, "stwo_proof.json"), "rb").read().rstrip()
+    want = verifier.parse_stwo_text(cfg, j)[1]
+    rnd = random.Random(SEED + 95)
+    commas = [i for i in range(len(j)) if j[i:i + 1] == b","]
+    blank, noisy = [], []
+    for _ in range(40):
+        at = commas[rnd.randrange(len(commas))] + 1
+        pad = bytes(rnd.choice(b" \n\t\r") for _ in range(rnd.randrange(1, 5000)))
+        blank.append(j[:at] + pad + j[at:])
+    recs, outcome = ver.read_stwo_texts(cfg, blank, JSON)
+    assert not outcome.any() and all(np.array_equal(r, want) for r in recs)
+    for _ in range(120):
+        at = rnd.randrange(len(j))
+        kind = rnd.randrange(5)
+        run = (b"7" * rnd.randrange(1000, 4000) if kind == 0 else b"q" * rnd.randrange(1000, 4000) if kind == 1 else
+               b'"' * rnd.randrange(1000, 3000) if kind == 2 else b"0x" + b"f" * rnd.randrange(60, 2100) if kind == 3 else
+               b"_" * rnd.randrange(1024, 2100))
+        noisy.append(j[:at] + run + j[at:])
+    assert _agree(ver, cfg, noisy, JSON) == 0
+
+
+def test_batches_of_very_different_texts_and_all_host_read(ver):
+    """Thousands of tiny texts between full-size ones (one window each against hundreds), and a batch the GPU reader
+    takes nothing of (every text has its members in another order): chunking, window bases and the host-reader fix-ups
+    hold, verdicts are the record path's."""
+    base = ss.stwo_from_json(json.load(open(os.path.join(GOLDEN, "stwo_proof.json"))))
+    cfg = base.cfg
+    good = json.dumps(ss.stwo_to_json(base), separators=(",", ":")).encode()
+    odd = json.dumps(dict(reversed(list(ss.stwo_to_json(base).items())))).encode()
+    batch, want = [], []
+    for i in range(6000):
+        if i % 50 == 0:
+            batch.append(good); want.append(0)
+        elif i % 50 == 25:
+            batch.append(odd); want.append(0)
+        else:
+            batch.append([b"{}", b"", b"[1]", b"7", b'{"config":{}}'][i % 5]); want.append(2)
+    status, stats = ver.verify_stwo_texts(cfg, batch)
+    assert status.tolist() == want and stats["host_parsed"] == 6000 - 120
+    status, stats = ver.verify_stwo_texts(cfg, [odd] * 700)   # ~150 MB, several chunks, all through the host reader
+    assert not status.any() and stats["host_parsed"] == 700
