@@ -181,7 +181,7 @@ def end_to_end_s101(ver, proof, n: int):
     texts = {"json": json.dumps(ss.stark101_to_json(proof)).encode(), "wit": ss.stark101_to_wit(proof).encode()}
     out = {"proofs": n, "note": "stark101 proof text -> verdict through ss_s101_verify_texts (GPU reader, host link included)"}
     for kind, fmt in (("json", binding.TEXT_JSON), ("wit", binding.TEXT_WIT)):
-        batch = [texts[kind]] * n
+        batch = [texts[kind][:1] + texts[kind][1:] for _ in range(n)]  # distinct buffers
         ver.verify_stark101_texts(batch[:64], fmt=fmt)
         ver.verify_stark101_texts(batch, fmt=fmt)
         best = None
@@ -215,7 +215,8 @@ def end_to_end(ver, proofs, n: int):
                                 "uploaded, turned into records by the GPU reader (csrc/ss_textdev.hip), re-tiled, verified; "
                                 "bound by the host link, not what `value` measures"}
     for kind, fmt in (("json", binding.TEXT_JSON), ("wit", binding.TEXT_WIT)):
-        batch = [texts[kind][i % len(distinct)] for i in range(n)]
+        # every text its own buffer (a copy): the staging copy then reads host memory, not eight cache-resident strings
+        batch = [texts[kind][i % len(distinct)][:1] + texts[kind][i % len(distinct)][1:] for i in range(n)]
         ver.verify_stwo_texts(cfg, batch[:64], fmt=fmt)  # warm-up: scratch allocation, templates
         ver.verify_stwo_texts(cfg, batch, fmt=fmt)
         best = None

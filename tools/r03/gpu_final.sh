@@ -18,8 +18,9 @@ python tools/host_path_bench.py 2048 > $O/host_path.txt 2>&1
 python tools/e2e_bench.py --n 4096 --reps 4 --files > $O/e2e_4096.json 2> $O/e2e.err; echo "e2e rc=$?"
 python tools/e2e_bench.py --n 4096 --reps 3 --noncanonical 0.01 > $O/e2e_4096_nc1.json 2>> $O/e2e.err
 python tools/e2e_bench.py --n 512 --reps 4 > $O/e2e_512.json 2>> $O/e2e.err
+python tools/e2e_bench.py --n 4096 --reps 3 --fmt json --python-separators > $O/e2e_4096_pysep.json 2>> $O/e2e.err
 python tools/e2e_bench.py --n 4096 --reps 3 --workload stwo_trace16.npz > $O/e2e_4096_2p16.json 2>> $O/e2e.err
-python tools/prover_bench.py 20 3 sha256 1,4 48 > $O/prover_bench.txt 2>&1
+python tools/prover_bench.py 20 2 sha256 1,4,4,3 48 > $O/prover_bench.txt 2>&1
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline --e2e 0 > $O/stats.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_e2e -- python3 $R/tools/e2e_bench.py --n 4096 --reps 2 --fmt json > $O/stats_e2e.log 2>&1

@@ -104,7 +104,7 @@ for f in sorted(glob.glob(os.path.join(G, "e2e_*.json"))):
         pass
 json.dump({"note": "tools/e2e_bench.py: text -> verdict through ss_stwo_verify_texts / _files (e2e_4096: 4096 texts of the 2^20 shape, "
                    "with --files; _nc1: 1 % of the texts with reversed member order = host reader; _512: a small batch; _2p16: the "
-                   "2^16 / Q=32 shape)", "commit": commit, "runs": e2e}, open(os.path.join(P, "r03_e2e.json"), "w"), indent=1)
+                   "2^16 / Q=32 shape; _pysep: proof.json with json.dumps' default separators, 27 % more bytes)", "commit": commit, "runs": e2e}, open(os.path.join(P, "r03_e2e.json"), "w"), indent=1)
 
 for name, src, head in (("r03_sha_calibration.txt", "sha_bench.txt", "$ build/sha_bench 512      (tools/sha_bench.hip at %s; MI355X)" % commit),
                         ("r03_host_path.txt", "host_path.txt", "$ python tools/host_path_bench.py 2048   (ss_stwo_verify_records, 2^20 shape, at %s; "
