@@ -698,8 +698,15 @@ extern "C" size_t ss_stwo_write_text(const ss_stwo_cfg *c, const uint32_t *recor
 extern "C" int ss_stwo_text_is_canonical(const ss_stwo_cfg *c, const char *text, size_t len, int fmt, uint32_t *record_out)
 {
     if (!cfg_ok(c) || !text || (fmt != SS_TEXT_JSON && fmt != SS_TEXT_WIT)) return set_err(SS_ERR_ARG, "bad argument");
-    TextTemplateHost h;
-    stwo_build_template(*c, fmt, h);
+    // the template of the last (config, format) asked about is kept per thread: building one walks the whole text
+    static thread_local TextTemplateHost h;
+    static thread_local ss_stwo_cfg h_cfg;
+    static thread_local int h_fmt = -1;
+    if (h_fmt != fmt || memcmp(&h_cfg, c, sizeof h_cfg) != 0) {
+        stwo_build_template(*c, fmt, h);
+        memcpy(&h_cfg, c, sizeof h_cfg);  // (ctypes / C callers zero the struct's padding; a mismatch only rebuilds)
+        h_fmt = fmt;
+    }
     if (!h.ok) return 0;
     std::vector<uint32_t> scratch;
     uint32_t *rec = record_out;

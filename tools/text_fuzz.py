@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of the GPU text reader (run on the GPU box).
+
+    python tools/text_fuzz.py [mutants_per_case] [seed]
+
+For several configurations and both text formats it mutates canonical texts (byte flips, deletions, duplications,
+truncations, injected digits / brackets / escapes, numbers replaced by other spellings and values, blanks shifted
+against the window grid) and requires, for every mutant:
+    GPU outcome == scalar rule (ss_stwo_text_is_canonical);
+    where taken: GPU record == scalar rule's record == host reader's record (and the host reader parses it);
+and, through the whole entry point, status words == host reader + record path on a sample.
+Exit status 0 = no disagreement."""
+import json
+import os
+import random
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import stark_symphony_amd as ss  # noqa: E402
+from stark_symphony_amd import binding, records, verifier  # noqa: E402
+from test_ingest import _text_mutant  # noqa: E402
+from test_text_fastpath import _number_mutant, canonical, write_text, s101_canonical  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
+SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 20261007
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+JSON, WIT = binding.TEXT_JSON, binding.TEXT_WIT
+
+
+def cases():
+    yield "reference test config", ss.stwo_from_json(json.load(open(os.path.join(GOLDEN, "stwo_proof_test.json"))))
+    yield "reference production", ss.stwo_from_json(json.load(open(os.path.join(GOLDEN, "stwo_proof.json"))))
+    for npz in ("stwo_trace16.npz", "stwo_trace16_blake2s.npz", "stwo_wide256.npz"):
+        yield npz, records.load_stwo_npz(os.path.join(GOLDEN, npz))[0]
+
+
+def main():
+    ver = verifier.Verifier(0)
+    rnd = random.Random(SEED)
+    bad = 0
+    for name, p in cases():
+        rec = verifier.stwo_record(p)
+        for fmt, kind in ((JSON, "json"), (WIT, "wit")):
+            base = write_text(p.cfg, rec, fmt, rnd.randrange(2))
+            n = N if len(base) < 300000 else max(200, N // 8)
+            texts = []
+            for i in range(n):
+                t = _text_mutant(rnd, base) if i % 3 == 0 else _number_mutant(rnd, base)
+                if i % 5 == 0:
+                    t = _number_mutant(rnd, t)
+                if i % 7 == 0 and fmt == JSON:
+                    t = b" " * rnd.randrange(1, 1100) + t
+                texts.append(t)
+            recs, outcome = ver.read_stwo_texts(p.cfg, texts, fmt)
+            taken = changed = 0
+            for i, t in enumerate(texts):
+                want, srec = canonical(p.cfg, t, fmt)
+                if (outcome[i] == 0) != want:
+                    bad += 1
+                    print("OUTCOME", name, kind, i, int(outcome[i]), want, t[:100])
+                    continue
+                if want:
+                    taken += 1
+                    got, hrec = verifier.parse_stwo_text(p.cfg, t, fmt=fmt)
+                    if got != 0 or not np.array_equal(recs[i], srec) or not np.array_equal(hrec, srec):
+                        bad += 1
+                        print("RECORD", name, kind, i, got, t[:100])
+                    changed += not np.array_equal(srec, rec)
+            # the entry point on a sample: status words of the text path == of the record path for what parses
+            sample = texts[:300]
+            status, stats = ver.verify_stwo_texts(p.cfg, sample, fmt=fmt)
+            ok_recs, ok_idx = [], []
+            for i, t in enumerate(sample):
+                got, hrec = verifier.parse_stwo_text(p.cfg, t, fmt=fmt)
+                if got == 0:
+                    ok_recs.append(hrec); ok_idx.append(i)
+                elif status[i] != got:
+                    bad += 1
+                    print("STAGE0", name, kind, i, int(status[i]), got)
+            if ok_recs:
+                st2 = ver.verify_stwo_records(p.cfg, ok_recs)
+                if status[ok_idx].tolist() != st2.tolist():
+                    bad += 1
+                    print("STATUS", name, kind)
+            print("%-24s %-4s: %6d mutants, %5d taken by the GPU reader (%5d with a changed record), disagreements so far %d"
+                  % (name, kind, n, taken, changed, bad), flush=True)
+    # stark101
+    for fn, fmt in (("stark101_proof.json", JSON), (os.path.join("formats", "stark101_proof.wit"), WIT)):
+        base = open(os.path.join(GOLDEN, fn), "rb").read()
+        texts = [(_text_mutant(rnd, base) if i % 3 == 0 else _number_mutant(rnd, base)) for i in range(N)]
+        recs, outcome = ver.read_stark101_texts(texts, fmt)
+        taken = 0
+        for i, t in enumerate(texts):
+            want, srec = s101_canonical(t, fmt)
+            if (outcome[i] == 0) != want:
+                bad += 1
+                print("OUTCOME stark101", i)
+                continue
+            if want:
+                taken += 1
+                pad = srec == 0xEEEEEEEE
+                rc, shape, hrec = verifier.parse_s101_text(t, fmt=fmt)
+                if rc != 0 or not np.array_equal(recs[i][~pad], srec[~pad]) or recs[i][pad].any() or not np.array_equal(hrec, recs[i]):
+                    bad += 1
+                    print("RECORD stark101", i)
+        print("stark101 %-16s: %6d mutants, %5d taken, disagreements so far %d" % ("json" if fmt == JSON else "wit", N, taken, bad), flush=True)
+    print("TOTAL disagreements:", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
