@@ -316,7 +316,7 @@ def main() -> None:
                     help="proofs per rank and step; giving it selects --scaling weak")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--distinct", type=int, default=16,
+    ap.add_argument("--distinct", type=int, default=64,
                     help="distinct valid proofs in the batch (made by the GPU prover; 0 = fixtures only)")
     ap.add_argument("--inflight", type=int, default=3,
                     help="batch passes in flight (one HIP stream each)")

@@ -586,10 +586,11 @@ class Verifier:
 
     def verify_stwo_texts(self, cfg: StwoConfig, texts: Sequence[bytes], mode: int = MODE_FIXTURE,
                           fmt: int = B.TEXT_AUTO):
-        """proof.json / proof.wit texts (bytes) -> (status, stats): parsed by the library's host
-        threads straight into the upload staging, verified against `cfg` -- the config the caller
-        expects; other shapes / declared parameters get STATUS_CONFIG_MISMATCH, unreadable texts
-        STATUS_MALFORMED (ss_stwo_verify_texts)."""
+        """proof.json / proof.wit texts (bytes) -> (status, stats): uploaded as text and turned into
+        records by the GPU reader (canonical texts) or the library's host reader (all others, which
+        alone decides what is readable), verified against `cfg` -- the config the caller expects;
+        other shapes / declared parameters get STATUS_CONFIG_MISMATCH, unreadable texts
+        STATUS_MALFORMED (ss_stwo_verify_texts).  stats["host_parsed"] counts the host reader's share."""
         cs = stwo_cfg_struct(cfg, mode, self.stwo_flags)
         return self._ingest(B.lib().ss_stwo_verify_texts, (C.byref(cs),), list(texts), fmt)
 
