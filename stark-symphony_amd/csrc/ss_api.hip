@@ -57,10 +57,16 @@ static constexpr size_t kMaxSpans = 1 << 16;
 // LDS footprint (512 VGPRs per SIMD lane in granules of 8, 160 KB LDS per CU; a block's
 // kTopChains / 64 waves go to different SIMDs of the CU).  The grid must not exceed this, or the surplus blocks
 // run after the others at a fraction of the occupancy.  Asked once, when the context is created.
-static int top_blocks_per_cu(int hf)
+static const void *top_kernel(int hf, int hash_only)
+{
+    return hash_only ? (hf ? (const void *)stwo_top_hash_kernel_b2s : (const void *)stwo_top_hash_kernel_sha)
+                     : (hf ? (const void *)stwo_top_kernel_b2s : (const void *)stwo_top_kernel_sha);
+}
+
+static int top_blocks_per_cu(int hf, int hash_only)
 {
     hipFuncAttributes a;
-    const void *fn = hf ? (const void *)stwo_top_kernel_b2s : (const void *)stwo_top_kernel_sha;
+    const void *fn = top_kernel(hf, hash_only);
     int per_cu = 4;
     if (hipFuncGetAttributes(&a, fn) == hipSuccess && a.numRegs > 0) {
         const int by_regs = 512 / ((a.numRegs + 7) / 8 * 8);
@@ -86,8 +92,8 @@ extern "C" int ss_ctx_create(int device, ss_ctx **out)
     c->device = device;
     c->timing = 0;
     c->cus = prop.multiProcessorCount;
-    c->top_blocks_per_cu[0] = top_blocks_per_cu(0);
-    c->top_blocks_per_cu[1] = top_blocks_per_cu(1);
+    for (int hf = 0; hf < 2; hf++)
+        for (int ho = 0; ho < 2; ho++) c->top_blocks_per_cu[hf][ho] = top_blocks_per_cu(hf, ho);
     *out = c;
     return SS_OK;
 }
@@ -251,6 +257,9 @@ extern "C" int ss_stwo_verify_phase_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_
     }
     if (phases & SS_PHASE_TAIL) {
         const uint32_t tiles = (y.K + 3) * (y.nip >> 6);
+        // the top kernel's group counter, its count of flagged trees and -- when the merkle kernel makes the byte
+        // compares (y.mchk) -- the flags it raises, which lie directly behind
+        if (y.T) HIP_TRY(hipMemsetAsync(ws + y.ws_counter, 0, y.mchk ? (y.ws_plan - y.ws_counter) * 4 : 8, s));
         t.begin();
         hipLaunchKernelGGL(c->hash == SS_HASH_BLAKE2S ? stwo_merkle_kernel_b2s : stwo_merkle_kernel_sha,
                            dim3((tiles + 3) / 4), dim3(256), 0, s, y, batch, ws, status);
@@ -258,10 +267,10 @@ extern "C" int ss_stwo_verify_phase_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_
         if (y.T) {
             t.begin();
             const int hf = c->hash == SS_HASH_BLAKE2S;
-            const uint32_t blocks = std::min<uint32_t>(y.top_blocks, (uint32_t)(ctx->top_blocks_per_cu[hf] * std::min(ctx->cus, 256)));
-            HIP_TRY(hipMemsetAsync(ws + y.ws_counter, 0, 8, s));  // the kernel's group counter and its count of flagged trees
-            hipLaunchKernelGGL(hf ? stwo_top_kernel_b2s : stwo_top_kernel_sha, dim3(blocks), dim3(kTopChains), 0, s,
-                               y, batch, ws, status);
+            const int ho = y.mchk != 0;
+            const uint32_t blocks = std::min<uint32_t>(y.top_blocks, (uint32_t)(ctx->top_blocks_per_cu[hf][ho] * std::min(ctx->cus, 256)));
+            void *args[] = {(void *)&y, (void *)&batch, (void *)&ws, (void *)&status};
+            HIP_TRY(hipLaunchKernel(top_kernel(hf, ho), dim3(blocks), dim3(kTopChains), args, 0, s));
             t.end("stwo_top");
             // trees in which queries disagree about a node (none in an honest batch: the grid reads one word and leaves)
             t.begin();

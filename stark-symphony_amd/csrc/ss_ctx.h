@@ -76,7 +76,7 @@ struct ss_ctx {
     int device;
     int timing;
     int cus;                   // compute units of the device
-    int top_blocks_per_cu[2];  // resident stwo_top_kernel blocks per CU, per hash family (0 = not yet asked)
+    int top_blocks_per_cu[2][2];  // resident top-kernel blocks per CU: [hash family][0 = with the byte compares, 1 = hash only]
     std::vector<ss::TimedSpan> spans;  // recorded since the last collect
     std::vector<hipEvent_t> pool;      // recycled events
     ss::HostPath hp;

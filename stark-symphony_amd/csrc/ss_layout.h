@@ -69,9 +69,16 @@ struct StwoLayout {
     uint64_t ws_vals;     // vals[block][parity][type][slot][8]: nodes of the distinct pairs, two depths
     uint64_t ws_counter;  // [0] next group of the top kernel, [1] trees it flagged (two words, zeroed before each launch)
     uint64_t ws_flag;     // flag[type][proof]: 1 = the tree's checks failed, stwo_top_cold_kernel re-hashes its chains
+    // The byte compares that prove the sharing ("same", "edge", "cross at the edge": stwo_top_kernel) depend on proof
+    // bytes only.  When a proof's Q chains sit in one wavefront of the merkle kernel (64 % Q == 0) they are made THERE,
+    // lane against lane, from a per-query plan the query kernel leaves in ws_plan; the top kernel then only hashes.
+    uint32_t mchk;
+    uint64_t ws_plan;     // plan[inst] = 4 words: byte dd-1 of words 0..1 = the query (of its proof) that leads this
+                          // chain's position at depth dd, of words 2..3 = the one that leads the sibling position (0xff: none)
 };
 
 constexpr uint32_t kTopChains = 256;     // chains a top-kernel block plans at once (= its threads)
+constexpr uint32_t kTopMaxT = 8;         // ceil_log2(kMaxQueries) + 2 >= T
 constexpr uint32_t kTopMinGroups = 1024;  // a smaller batch is cut into smaller groups until it gives this many
 // workspace slices of the persistent top kernel.  The launch uses min(groups, blocks resident at once), and at
 // 256 threads and >= 123 VGPRs per lane at most 4 blocks fit a CU (3 for SHA-256): 1024 on the 256 CUs of an MI355X.
@@ -92,7 +99,8 @@ SS_HD inline bool stwo_cfg_ok(uint32_t N, uint32_t TL, uint32_t L, uint32_t Q, u
 
 SS_HD inline StwoLayout stwo_layout(uint32_t N, uint32_t TL, uint32_t L, uint32_t Q, uint32_t K,
                                     uint32_t mode, uint64_t pow_target, uint64_t n, bool dedup = true,
-                                    bool light_hash = false, uint32_t min_groups = kTopMinGroups)
+                                    bool light_hash = false, uint32_t min_groups = kTopMinGroups,
+                                    bool merkle_checks = true)
 {
     StwoLayout y{};
     y.N = N; y.TL = TL; y.L = L; y.Q = Q; y.K = K; y.mode = mode; y.pow_target = pow_target;
@@ -168,7 +176,9 @@ SS_HD inline StwoLayout stwo_layout(uint32_t N, uint32_t TL, uint32_t L, uint32_
     y.ws_top = w;   w += y.T ? (uint64_t)(K + 3) * y.nip * 8 : 0;
     y.ws_vals = w;  w += (uint64_t)y.top_blocks * 2 * (K + 3) * kTopChains * 8;
     y.ws_counter = w; w += 4;
-    y.ws_flag = w;  w += y.T ? (uint64_t)(K + 3) * y.np : 0;
+    y.ws_flag = w;  w += y.T ? (uint64_t)(K + 3) * y.np : 0;  // (directly behind the counter: one memset clears both)
+    y.mchk = y.T && merkle_checks && 64 % Q == 0;
+    y.ws_plan = w;  w += y.mchk ? (uint64_t)y.nip * 4 : 0;
     y.ws_total_words = w;
     return y;
 }

@@ -23,8 +23,15 @@ StwoLayout ss::lay_of(const ss_stwo_cfg *c, size_t n)
         const int v = e ? atoi(e) : 0;
         return v > 0 ? (uint32_t)v : kTopMinGroups;
     }();
+    // SS_MERKLE_CHECKS=0: the byte compares of the pair memoisation stay in the top kernel (the path of query counts
+    // that do not divide 64), for A/B runs and tests
+    static const bool merkle_checks = [] {
+        const char *e = getenv("SS_MERKLE_CHECKS");
+        return !(e && e[0] == '0');
+    }();
     return stwo_layout(c->n_cols, c->trace_log, c->lde_log, c->n_queries, c->n_layers, c->mode,
-                       c->pow_target, n, !(c->flags & SS_FLAG_NO_DEDUP), c->hash == SS_HASH_BLAKE2S, min_groups);
+                       c->pow_target, n, !(c->flags & SS_FLAG_NO_DEDUP), c->hash == SS_HASH_BLAKE2S, min_groups,
+                       merkle_checks);
 }
 
 extern "C" size_t ss_stwo_record_words(const ss_stwo_cfg *c)

@@ -281,6 +281,32 @@ stwo_query_kernel(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *
     const uint32_t L = lay.L, K = lay.K;
     const bool two = lay.mode == 1;
 
+    // Plan of the pair memoisation for the merkle kernel (lay.mchk, see stwo_top_kernel): at depth dd (root = 0) this
+    // chain's position in EVERY tree of the proof is query >> (L - dd).  Which query of the proof leads that position
+    // (the lowest one there, possibly this one) and which leads the sibling position (the other child of the parent).
+    if (lay.mchk) {
+        uint32_t lead[kTopMaxT], sibl[kTopMaxT];
+#pragma unroll
+        for (uint32_t j = 0; j < kTopMaxT; j++) { lead[j] = q; sibl[j] = 0xff; }
+        for (uint32_t o = lay.Q; o-- > 0;) {  // downwards: the lowest match is written last
+            const uint32_t x = CG(lay.c_queries + o) ^ query;
+#pragma unroll
+            for (uint32_t j = 0; j < kTopMaxT; j++) {
+                const uint32_t dd = j + 1;
+                if (dd > lay.T) continue;  // T <= L
+                const uint32_t v = x >> (L - dd);
+                if (v == 0 && o < q) lead[j] = o;
+                if (v == 1) sibl[j] = o;
+            }
+        }
+        uint4 pl;
+        pl.x = lead[0] | lead[1] << 8 | lead[2] << 16 | lead[3] << 24;
+        pl.y = lead[4] | lead[5] << 8 | lead[6] << 16 | lead[7] << 24;
+        pl.z = sibl[0] | sibl[1] << 8 | sibl[2] << 16 | sibl[3] << 24;
+        pl.w = sibl[4] | sibl[5] << 8 | sibl[6] << 16 | sibl[7] << 24;
+        reinterpret_cast<uint4 *>(ws + lay.ws_plan)[inst] = pl;
+    }
+
     // domain point of the even member of the query's leaf pair, and of the query itself
     const uint32_t pos0 = query & ~1u;
     const M31Point p0 = circle_point(circle_position_to_index(L, bit_reverse_position(pos0, L)));
@@ -492,6 +518,44 @@ __device__ __forceinline__ void stwo_merkle_body(const StwoLayout &lay, const ui
         uint4 *out = reinterpret_cast<uint4 *>(ws + lay.ws_top) + ((size_t)type * nip + inst) * 2;
         out[0] = make_uint4(node[0], node[1], node[2], node[3]);
         out[1] = make_uint4(node[4], node[5], node[6], node[7]);
+        if (lay.mchk) {
+            // The byte compares of the pair memoisation (stwo_top_kernel: "same", "edge", "cross at the edge"), lane
+            // against lane: 64 % Q == 0, so the Q chains of this tree of proof p are lanes lane - q .. lane - q + Q - 1
+            // of this wavefront, all live (dead lanes pad whole proofs).  Every sibling of the top levels is read once,
+            // by its own chain; what the other chain presents comes through the crossbar.  A difference flags the tree
+            // (ws_flag, cleared before this kernel): stwo_top_cold_kernel then hashes its chains one by one.
+            const uint4 pl = reinterpret_cast<const uint4 *>(ws + lay.ws_plan)[inst];
+            const uint32_t base = lane - q;
+            auto plan = [](uint32_t lo, uint32_t hi, uint32_t dd) {
+                return ((dd <= 4 ? lo : hi) >> (8 * ((dd - 1) & 3))) & 0xff;
+            };
+            const uint4 *sp = reinterpret_cast<const uint4 *>(batch + lay.off_top + (size_t)p * lay.top_words + lay.top_off[type]) +
+                              (size_t)q * 2;
+            uint32_t diff = 0;
+            {   // edge: chains at one position of depth `top` enter with the same node
+                const int src = (int)(base + plan(pl.x, pl.y, top));
+#pragma unroll
+                for (int j = 0; j < 8; j++) diff |= node[j] ^ (uint32_t)__shfl((int)node[j], src);
+            }
+            const uint32_t o = plan(pl.z, pl.w, top);  // leader of the sibling position at depth `top`
+            for (uint32_t j = 0; j < top; j++) {        // level n_lvl + j = the step from depth dd = top - j to dd - 1
+                const uint4 a = sp[(size_t)j * lay.Q * 2], b = sp[(size_t)j * lay.Q * 2 + 1];
+                const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                // same: a chain presents the sibling the leader of its position presents
+                const int src = (int)(base + plan(pl.x, pl.y, top - j));
+#pragma unroll
+                for (int i = 0; i < 8; i++) diff |= w[i] ^ (uint32_t)__shfl((int)w[i], src);
+                if (j == 0) {
+                    // cross at the edge: this chain's entering node is what the sibling position's leader presents
+                    const int so = (int)(base + (o == 0xff ? q : o));
+                    uint32_t x = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) x |= node[i] ^ Hasher<HF>::native((uint32_t)__shfl((int)w[i], so));
+                    if (o != 0xff) diff |= x;
+                }
+            }
+            if (diff) ws[lay.ws_flag + (size_t)type * np + p] = 1;
+        }
     }
     // assert!(eq_32(path, 1)), merkle.simf:42, evaluated first by the reference.  The index starts
     // in [2^len, 2^(len+1)) and loses one bit per sibling of the List<u256, 32>, so it ends at 1 iff
@@ -535,16 +599,18 @@ __device__ __forceinline__ void stwo_merkle_body(const StwoLayout &lay, const ui
 // ALU work of the same wave (blocks sharing a CU run in lockstep, so nothing else would); what a
 // shallow depth has beyond two per hash iteration is drained four in flight before its barrier.  Nodes of two consecutive depths live in the
 // block's slice of ws_vals.
-constexpr uint32_t kTopMaxT = 8;  // ceil_log2(kMaxQueries) + 2
 #ifndef SS_TOP_LIGHTS
 #define SS_TOP_LIGHTS 2
 #endif
 #ifndef SS_TOP_WAVES
 #define SS_TOP_WAVES 3
 #endif
+#ifndef SS_TOP_HASH_WAVES
+#define SS_TOP_HASH_WAVES 3
+#endif
 constexpr uint32_t kTopLights = SS_TOP_LIGHTS;  // light checks that ride along one pair hash
 
-template <int HF>
+template <int HF, bool LIGHTS>
 __device__ __forceinline__ void stwo_top_body(const StwoLayout &lay, const uint32_t *__restrict__ batch,
                                               uint32_t *__restrict__ ws, uint32_t *__restrict__ status)
 {
@@ -644,21 +710,37 @@ __device__ __forceinline__ void stwo_top_body(const StwoLayout &lay, const uint3
             s_query[tid] = ws[lay.ws_ctx + (size_t)(lay.c_queries + q) * np + p0 + g];
             s_g[tid] = (uint8_t)g;
         }
-        for (uint32_t i = tid; i < NT * (kTopChains / 2); i += kTopChains) (&s_bad[0][0])[i] = 0;
+        if (LIGHTS) {
+            for (uint32_t i = tid; i < NT * (kTopChains / 2); i += kTopChains) (&s_bad[0][0])[i] = 0;
+        } else {  // what stwo_merkle_kernel's byte compares found (lay.mchk)
+            for (uint32_t i = tid; i < gp * n_types; i += kTopChains) {
+                const uint32_t ti = i / gp, g = i - ti * gp;
+                s_bad[ti][g] = (uint8_t)ws[lay.ws_flag + (size_t)ti * np + p0 + g];
+            }
+        }
         __syncthreads();
 
         // ---- plan, all depths at once: leaders, followers, slots
         const uint32_t first = tid - tid % Q;  // first chain of this chain's proof
+        // (hash only: the query kernel has worked out who leads this chain's position and its sibling position at
+        // every depth -- byte dd - 1 of pl.xy / pl.zw, as query numbers of the proof, ss_layout.h ws_plan)
+        uint4 pl = make_uint4(0, 0, 0, 0);
+        if (!LIGHTS && tid < nch) pl = reinterpret_cast<const uint4 *>(ws + lay.ws_plan)[inst0 + tid];
+        auto plan_byte = [](uint32_t lo, uint32_t hi, uint32_t dd) { return ((dd <= 4 ? lo : hi) >> (8 * ((dd - 1) & 3))) & 0xff; };
         uint64_t votes[D];
         uint32_t lead_mask = 0;
 #pragma unroll
         for (uint32_t dd = 0; dd < D; dd++) {
             bool lead = false;
             if (dd <= Tmax && tid < nch) {
-                const uint32_t pos = s_query[tid] >> (L - dd);
                 uint32_t c0 = tid;
-                for (uint32_t c2 = first; c2 < tid; c2++)
-                    if ((s_query[c2] >> (L - dd)) == pos) { c0 = c2; break; }
+                if (LIGHTS) {
+                    const uint32_t pos = s_query[tid] >> (L - dd);
+                    for (uint32_t c2 = first; c2 < tid; c2++)
+                        if ((s_query[c2] >> (L - dd)) == pos) { c0 = c2; break; }
+                } else {
+                    c0 = first + (dd ? plan_byte(pl.x, pl.y, dd) : 0);
+                }
                 lead = c0 == tid;
                 s_lead[dd][tid] = (uint16_t)c0;
             }
@@ -682,13 +764,16 @@ __device__ __forceinline__ void stwo_top_body(const StwoLayout &lay, const uint3
                     s_slot[dd][tid] = (uint16_t)before;
                     // the chain that leads the sibling position of this depth (the other child of the parent)
                     uint16_t other = kNone;
-                    if (dd) {
+                    if (dd && LIGHTS) {
                         const uint32_t want = (s_query[tid] >> (L - dd)) ^ 1;
                         for (uint32_t c2 = first, e = first + Q; c2 < e; c2++)
                             if ((s_query[c2] >> (L - dd)) == want) { other = (uint16_t)c2; break; }
+                    } else if (dd) {
+                        const uint32_t o = plan_byte(pl.z, pl.w, dd);
+                        if (o != 0xff) other = (uint16_t)(first + o);
                     }
                     s_sibl[dd][before] = other;
-                } else {
+                } else if (LIGHTS) {
                     s_fol[dd][tid - before] = (uint16_t)tid;
                 }
             }
@@ -701,7 +786,7 @@ __device__ __forceinline__ void stwo_top_body(const StwoLayout &lay, const uint3
         }
         // ---- the light-check queue: for dd = Tmax..1, "same" over the trees of depth >= dd, then "cross
         // at the edge" and "edge" (equal entering nodes) over the trees that enter this kernel at depth dd
-        if (tid == 0) {
+        if (LIGHTS && tid == 0) {
             uint32_t ns = 0, at = 0;
             for (uint32_t dd = Tmax; dd >= 1; dd--) {
                 const uint32_t fri = L - dd < K + 1 ? L - dd : K + 1;  // FRI trees with len >= dd
@@ -781,8 +866,10 @@ __device__ __forceinline__ void stwo_top_body(const StwoLayout &lay, const uint3
             // step: the users of a 128-byte line of the proof stay close in time.  (The resident blocks'
             // working sets exceed the 4 MB L2 of an XCD either way: 13.1 GB of L2 misses per 65 536-proof
             // launch against 13.4 GB with one queue per group drained at its own pace; same run time.)
-            li = s_seg_start[3 * (Tmax - d - 1)] + tid;
-            light_end = s_seg_start[3 * (Tmax - d)];
+            if (LIGHTS) {
+                li = s_seg_start[3 * (Tmax - d - 1)] + tid;
+                light_end = s_seg_start[3 * (Tmax - d)];
+            }
             const uint32_t nlead = s_nlead[d];
             const uint32_t fri = L - 1 - d < K + 1 ? L - 1 - d : K + 1;  // FRI trees deeper than d
             const uint32_t total = nlead * (2 + fri);
@@ -807,9 +894,11 @@ __device__ __forceinline__ void stwo_top_body(const StwoLayout &lay, const uint3
                 uint32_t ti2 = 0, k2 = 0, flags2 = 0;
                 if (i + kTopChains < total) fetch(i + kTopChains, nd2, sb2, ys2, ti2, k2, flags2);
                 Light x[kTopLights];
+                if (LIGHTS) {
 #pragma unroll
-                for (uint32_t u = 0; u < kTopLights; u++) light_issue(li + u * kTopChains, x[u]);
-                li += kTopLights * kTopChains;
+                    for (uint32_t u = 0; u < kTopLights; u++) light_issue(li + u * kTopChains, x[u]);
+                    li += kTopLights * kTopChains;
+                }
                 uint32_t a[8], b[8], lft[8], rgt[8], out[8];
                 unpack(nd, a);
                 unpack(sb, b);
@@ -826,13 +915,15 @@ __device__ __forceinline__ void stwo_top_body(const StwoLayout &lay, const uint3
                 o[1] = o8.b;
                 // (ii): the leader of the sibling position presents this node as its sibling
                 if ((flags & 2) && differ(o8, ys)) s_bad[ti][s_g[s_item[d][k]]] = 1;
+                if (LIGHTS) {
 #pragma unroll
-                for (uint32_t u = 0; u < kTopLights; u++) light_settle(x[u]);
+                    for (uint32_t u = 0; u < kTopLights; u++) light_settle(x[u]);
+                }
                 nd = nd2; sb = sb2; ys = ys2; ti = ti2; k = k2; flags = flags2;
             }
             // what this step's hash iterations did not carry (the shallow depths have more checks than
             // hashes), four in flight
-            while (li - tid < light_end) {  // uniform over the block: li - tid is the same in every lane
+            while (LIGHTS && li - tid < light_end) {  // uniform over the block: li - tid is the same in every lane
                 Light x[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) light_issue(li + u * kTopChains, x[u]);
@@ -923,13 +1014,26 @@ __global__ void __launch_bounds__(kTopChains, SS_TOP_WAVES)
 stwo_top_kernel_sha(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,
                     uint32_t *__restrict__ status)
 {
-    stwo_top_body<0>(lay, batch, ws, status);
+    stwo_top_body<0, true>(lay, batch, ws, status);
 }
 __global__ void __launch_bounds__(kTopChains, SS_TOP_WAVES)
 stwo_top_kernel_b2s(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,
                     uint32_t *__restrict__ status)
 {
-    stwo_top_body<1>(lay, batch, ws, status);
+    stwo_top_body<1, true>(lay, batch, ws, status);
+}
+// lay.mchk: the byte compares were made by stwo_merkle_kernel, this one only hashes (and cross-checks what it hashes)
+__global__ void __launch_bounds__(kTopChains, SS_TOP_HASH_WAVES)
+stwo_top_hash_kernel_sha(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,
+                         uint32_t *__restrict__ status)
+{
+    stwo_top_body<0, false>(lay, batch, ws, status);
+}
+__global__ void __launch_bounds__(kTopChains, SS_TOP_HASH_WAVES)
+stwo_top_hash_kernel_b2s(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,
+                         uint32_t *__restrict__ status)
+{
+    stwo_top_body<1, false>(lay, batch, ws, status);
 }
 
 __global__ void __launch_bounds__(256)
