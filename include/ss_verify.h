@@ -105,6 +105,10 @@ typedef struct ss_stwo_cfg {
  * that every query presenting that node presents the same pair; trees where two queries disagree
  * are re-hashed query by query, so the status words are the reference's either way.        */
 #define SS_FLAG_NO_DEDUP 1u
+/* SS_FLAG_TOP_CHECKS: make those byte compares in the top kernel for every query count.  By default, when the
+ * query count divides 64, they are made by the merkle kernel (a proof's chains are lanes of one wavefront there);
+ * other query counts always take the top-kernel path.  Same status words; for A/B runs and tests.             */
+#define SS_FLAG_TOP_CHECKS 2u
 
 /* SS_HASH_SHA256 is the reference (hasher.simf:13-104, channel.simf:36-172).  SS_HASH_BLAKE2S is
  * the "Blake2s Merkle" variant BASELINE.json names: the same protocol over the same byte

@@ -324,6 +324,7 @@ def _ptr_array(records: Sequence[np.ndarray]):
 
 
 FLAG_NO_DEDUP = 1  # SS_FLAG_NO_DEDUP: hash every query's Merkle path in full (A/B and tests)
+FLAG_TOP_CHECKS = 2  # SS_FLAG_TOP_CHECKS: the memoisation's byte compares in the top kernel whatever the query count
 
 
 def stwo_cfg_struct(cfg: StwoConfig, mode: int, flags: int = 0) -> B.StwoCfg:

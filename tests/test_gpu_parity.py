@@ -587,11 +587,15 @@ def test_pair_memoisation_when_queries_disagree_about_a_node(ver, stwo_prod):
         arr[9] = arr[2]
     p.trace_paths[9], p.cp_paths[9] = p.trace_paths[2].copy(), p.cp_paths[2].copy()
     batch.append(p); notes.append("query 9 := query 2")
+    top = verifier.Verifier(0)  # the byte compares in the top kernel (the path of query counts that do not divide 64)
+    top.stwo_flags = verifier.FLAG_TOP_CHECKS
     for mode in (verifier.MODE_FIXTURE, verifier.MODE_LITERAL):
-        got = ver.verify_stwo(batch, mode, cfg=c)
         want = O.stwo_verify_batch(batch, mode)
-        bad = [(notes[i], hex(got[i]), hex(want[i])) for i in range(len(batch)) if got[i] != want[i]]
-        assert not bad, bad[:8]
+        for v in (ver, top):  # ver: Q = 16 divides 64, so the merkle kernel makes them
+            got = v.verify_stwo(batch, mode, cfg=c)
+            bad = [(notes[i], hex(got[i]), hex(want[i])) for i in range(len(batch)) if got[i] != want[i]]
+            assert not bad, (v is top, bad[:8])
+    top.close()
     assert want[0] != 0 or mode == verifier.MODE_FIXTURE
 
 
@@ -610,12 +614,12 @@ def test_pair_memoisation_equals_full_hashing(stwo_small, stwo_prod, name):
     batch = [base] * 3 + [fz.mutate_stwo(base, rng) for _ in range(150)]
     want = O.stwo_verify_batch(batch)
     results = []
-    for flags in (0, verifier.FLAG_NO_DEDUP):
+    for flags in (0, verifier.FLAG_NO_DEDUP, verifier.FLAG_TOP_CHECKS):
         v = verifier.Verifier(0)
         v.stwo_flags = flags
         results.append(v.verify_stwo(batch, cfg=base.cfg))
         v.close()
-    assert results[0].tolist() == want.tolist() and results[1].tolist() == want.tolist()
+    assert all(r.tolist() == want.tolist() for r in results)
     assert (want[:3] == 0).all() and (want != 0).sum() > 50
 
 

@@ -26,6 +26,8 @@ rng = np.random.default_rng(seed)
 ver = verifier.Verifier(0)
 plain = verifier.Verifier(0)
 plain.stwo_flags = verifier.FLAG_NO_DEDUP
+topchk = verifier.Verifier(0)
+topchk.stwo_flags = verifier.FLAG_TOP_CHECKS
 gp = prover.GpuProver(ver)
 bad = 0
 for i in range(shapes):
@@ -37,7 +39,7 @@ for i in range(shapes):
     batch = [proof] * 3 + [fz.mutate_stwo(proof, rng) for _ in range(61)]
     for mode in (verifier.MODE_FIXTURE, verifier.MODE_LITERAL):
         want = O.stwo_verify_batch(batch, mode)
-        for v, name in ((ver, "memo"), (plain, "full")):
+        for v, name in ((ver, "memo"), (plain, "full"), (topchk, "memo, compares in the top kernel")):
             got = v.verify_stwo(batch, mode, cfg=proof.cfg)
             m = int((got != want).sum())
             if m:
