@@ -125,7 +125,10 @@ SS_HD inline StwoLayout stwo_layout(uint32_t N, uint32_t TL, uint32_t L, uint32_
     // levels still merge ~1.5 pairs per tree, below that almost nothing.  With a hash half as long
     // (Blake2s: one compression per node) the second extra level no longer pays for its bookkeeping
     // (measured: configs[2] with Blake2s 4.71 M -> 4.82 M proofs/s at one level less).
-    const uint32_t want = ceil_log2(Q) + (light_hash ? 1 : 2);
+#ifndef SS_TOP_EXTRA
+#define SS_TOP_EXTRA 2
+#endif
+    const uint32_t want = ceil_log2(Q) + (light_hash ? SS_TOP_EXTRA - 1 : SS_TOP_EXTRA);
     y.T = (dedup && Q > 1) ? (want < L ? want : L) : 0;
     auto tile_len = [&](uint32_t len) { return len - (y.T < len ? y.T : len); };
     y.off_trace_path = o;  o += (uint64_t)tile_len(L) * 8 * y.nip;
