@@ -37,14 +37,15 @@ n, alg = 65536, 170296 * 65536
 cmd = ("rocprofv3 --pmc <set> --kernel-trace --output-format csv -- python3 bench.py --steps 3 --warmup 1 "
        "--no-cpu-baseline --inflight 1 --distinct 0 --e2e 0 --tail-streams 1   (tools/r03/gpu_final.sh; four separate passes: "
        "the two SQ sets of that script, FETCH_SIZE, WRITE_SIZE)")
-out = {"what": "PMC counters of the Merkle stage (stwo_merkle_kernel_sha + stwo_top_kernel_sha, top siblings stored per proof, "
-               "cold path in stwo_top_cold_kernel) on bench.py's default workload",
+TOP = "stwo_top_hash_kernel_sha"  # Q = 16 divides 64: the merkle kernel makes the byte compares, the top kernel only hashes
+out = {"what": "PMC counters of the Merkle stage (stwo_merkle_kernel_sha incl. the memoisation's byte compares + stwo_top_hash_kernel_sha, "
+               "top siblings stored per proof, cold path in stwo_top_cold_kernel) on bench.py's default workload",
        "commit": commit, "command": cmd, "workload": "stwo_2p20, 65536 proofs per launch", "per_launch_avg": {}}
 for k, v in s.items():
     if k.startswith("stwo_"):
         out["per_launch_avg"][k] = {c: (x["avg"] if isinstance(x, dict) else x) for c, x in v.items()}
 d = {}
-for k in ("stwo_merkle_kernel_sha", "stwo_top_kernel_sha"):
+for k in ("stwo_merkle_kernel_sha", TOP):
     m = out["per_launch_avg"][k]
     cyc = m["GRBM_GUI_ACTIVE"] / 8  # summed over the 8 XCDs
     d[k] = {"gpu_cycles": cyc, "clock_GHz": cyc / (m["avg_ms_with_counters"] * 1e-3) / 1e9,
@@ -56,7 +57,10 @@ for k in ("stwo_merkle_kernel_sha", "stwo_top_kernel_sha"):
 tot = sum(v["hbm_bytes (FETCH_SIZE KB x 1024 x 2 + WRITE_SIZE KB x 1024)"] for v in d.values())
 d["merkle_stage"] = {
     "hbm_bytes_per_launch": tot, "algorithmic_bytes_per_launch": alg, "ratio": tot / alg,
-    "valu_instructions": sum(out["per_launch_avg"][k]["SQ_INSTS_VALU"] for k in ("stwo_merkle_kernel_sha", "stwo_top_kernel_sha")),
+    "valu_instructions": sum(out["per_launch_avg"][k]["SQ_INSTS_VALU"] for k in ("stwo_merkle_kernel_sha", TOP)),
+    "round 3 before the byte compares moved into the merkle kernel (commit 86a5b0c..ab4f14d)": {
+        "ratio": 1.91, "top_kernel": "2.20 G VALU instructions at utilisation 0.965, 3.92-3.97 ms, 11.5 GB fetched",
+        "merkle_kernel": "8.85 G at 1.03, 14.7-14.8 ms, 8.12 GB"},
     "round 2 (profiles/r02_pmc_merkle_top.json)": {"ratio": 2.044, "top_kernel_fetch_GB": 12.99}}
 out["derived"] = d
 json.dump(out, open(os.path.join(P, "r03_pmc_merkle_top.json"), "w"), indent=1)
