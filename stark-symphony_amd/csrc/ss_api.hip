@@ -612,12 +612,14 @@ extern "C" int ss_stwo_verify_records(ss_ctx *ctx, const ss_stwo_cfg *c, size_t 
     hipStream_t s = hp.stream;
     uint32_t *rec_dev = (uint32_t *)hp.dev[0];
     int buf = 0;
-    for (size_t lo = 0; lo < n; lo += chunk, buf ^= 1) {
-        const size_t cnt = std::min(chunk, n - lo);
+    // (the first chunks are small and double: nothing overlaps the staging of the first one)
+    size_t step = std::max<size_t>(1, chunk / 16);
+    for (size_t lo = 0, cnt; lo < n; lo += cnt, buf ^= 1, step = std::min(chunk, step * 2)) {
+        cnt = std::min(step, n - lo);
         HIP_TRY(hipEventSynchronize(hp.pinned_free[buf]));  // previous upload from this buffer done
         uint32_t *stage = (uint32_t *)hp.pinned[buf];
         parallel_for(cnt, [&](size_t i) { copy_streaming(stage + i * W, records[lo + i], W * 4); },
-                     std::max<size_t>(1, std::min<size_t>(8, cnt * W * 4 / (4u << 20))));
+                     std::max<size_t>(1, std::min<size_t>(8, cnt * W * 4 / (1u << 20))));
         HIP_TRY(hipMemcpyAsync(rec_dev + lo * W, stage, cnt * W * 4, hipMemcpyHostToDevice, s));
         HIP_TRY(hipEventRecord(hp.pinned_free[buf], s));
     }
