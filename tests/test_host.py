@@ -192,6 +192,27 @@ def test_stwo_record_and_pack_layout(stwo_prod, flags):
     assert np.array_equal(batch, expect)
 
 
+def test_workspace_holds_a_plan_only_where_the_merkle_kernel_makes_the_byte_compares():
+    """csrc/ss_layout.h: when the query count divides 64 the workspace carries 16 bytes of plan per query for the
+    merkle kernel's byte compares; SS_FLAG_TOP_CHECKS (compares in the top kernel) and every other query count
+    do without, SS_FLAG_NO_DEDUP has neither memoisation nor plan.  The batch layout is the same either way."""
+    lib = binding.lib()
+    n = 1000
+    for q in (1, 2, 3, 5, 16, 17, 32, 48, 64):
+        cfg = ss.StwoConfig(4, 8, 12, q, 7, 5)
+        size, words = {}, {}
+        for flags in (0, verifier.FLAG_TOP_CHECKS, verifier.FLAG_NO_DEDUP):
+            cs = verifier.stwo_cfg_struct(cfg, verifier.MODE_FIXTURE, flags)
+            size[flags] = lib.ss_stwo_workspace_bytes(C.byref(cs), n)
+            words[flags] = lib.ss_stwo_batch_words(C.byref(cs), n)
+        plan = 16 * ((n * q + 63) // 64 * 64) if q > 1 and 64 % q == 0 else 0
+        assert size[0] - size[verifier.FLAG_TOP_CHECKS] == plan, q
+        assert words[0] == words[verifier.FLAG_TOP_CHECKS]
+        assert size[verifier.FLAG_NO_DEDUP] < size[verifier.FLAG_TOP_CHECKS] or q == 1
+    cs = verifier.stwo_cfg_struct(ss.PRODUCTION_CONFIG, verifier.MODE_FIXTURE, 4)
+    assert lib.ss_stwo_workspace_bytes(C.byref(cs), n) == 0  # unknown flag: unsupported cfg
+
+
 def test_stwo_record_reports_wrong_path_lengths(stwo_prod):
     p = stwo_prod.copy()
     p.fri_paths[2][5] = p.fri_paths[2][5][:-1]
