@@ -617,7 +617,7 @@ def main() -> None:
                              "calibrated_peak_compressions_per_s": alu_peak,
                              "frac": compr_s / alu_peak,
                              "note": alu_note + "; peak = tools/sha_bench.hip (registers only) on MI355X, "
-                                     "profiles/r01_sha_calibration.txt"},
+                                     "profiles/r01_sha_calibration.txt (34.7 G), re-measured in r03_sha_calibration.txt (34.4-34.6 G)"},
             "kernels_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in timing.items()},
         }
         if family == "stwo" and args.e2e > 0 and world == 1:
