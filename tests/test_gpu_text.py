@@ -334,3 +334,21 @@ def test_batches_of_very_different_texts_and_all_host_read(ver):
     assert status.tolist() == want and stats["host_parsed"] == 6000 - 120
     status, stats = ver.verify_stwo_texts(cfg, [odd] * 700)   # ~150 MB, several chunks, all through the host reader
     assert not status.any() and stats["host_parsed"] == 700
+
+
+def test_oversized_and_degenerate_texts(ver):
+    """Texts far from the template's size: several times its skeleton, megabytes of one byte, the densest possible
+    run of numbers (512 per window), a canonical text followed by megabytes of blanks (still canonical) or by a second
+    copy.  Nothing but the blank-padded one is taken; the kernels and the scalar rule agree on every one."""
+    cfg = ss.PRODUCTION_CONFIG
+    j = open(os.path.join(GOLDEN, "stwo_proof.json"), "rb").read().rstrip()
+    want = verifier.parse_stwo_text(cfg, j)[1]
+    texts = [j + b" " * (3 << 20), j + j, j * 3, b"1," * (2 << 20), b"7" * (4 << 20), b"[" * (4 << 20), b'"' * ((1 << 20) + 1),
+             b" " * (5 << 20), j[:len(j) // 2] + b"0," * 300000 + j[len(j) // 2:], b"x", b"", j[:1], b"\n" * 1025 + j]
+    recs, outcome = ver.read_stwo_texts(cfg, texts, JSON)
+    assert outcome.tolist() == [0] + [1] * (len(texts) - 2) + [0]
+    assert np.array_equal(recs[0], want) and np.array_equal(recs[-1], want)
+    for t in texts[1:-1]:
+        assert not canonical(cfg, t, JSON)[0]
+    status, stats = ver.verify_stwo_texts(cfg, texts)
+    assert status.tolist() == [0] + [2] * (len(texts) - 2) + [0] and stats["host_parsed"] == len(texts) - 2
