@@ -313,6 +313,12 @@ typedef struct ss_stwo_ws_layout {
                                          leaf[layer][8][nip] (even, odd member of the leaf pair) */
     uint64_t total_words;
     uint32_t c_queries, c_p, c_p2, c_fold, c_m1, n_pow;   /* ctx word indices */
+    /* pair memoisation: levels below the root it covers (0 = off), and -- when the query count divides 64 -- the
+     * per-query plan the query kernel leaves for the Merkle kernel's byte compares: plan[instance][4 words], byte
+     * d-1 of words 0..1 = the query of the proof that leads this query's position at depth d (root = 0; possibly
+     * itself), of words 2..3 = the one that leads the sibling position, 0xff = none.  has_plan = 0: no such section. */
+    uint32_t top_levels, has_plan;
+    uint64_t plan;
 } ss_stwo_ws_layout;
 int ss_stwo_ws_layout_of(const ss_stwo_cfg *cfg, size_t n, ss_stwo_ws_layout *out);
 int ss_stwo_read_intermediates(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const void *workspace_dev,

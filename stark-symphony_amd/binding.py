@@ -39,7 +39,7 @@ class StwoWsLayout(C.Structure):
     _fields_ = [("np", C.c_uint64), ("nip", C.c_uint64), ("ctx", C.c_uint64), ("alpha", C.c_uint64),
                 ("leaf", C.c_uint64), ("total_words", C.c_uint64), ("c_queries", C.c_uint32),
                 ("c_p", C.c_uint32), ("c_p2", C.c_uint32), ("c_fold", C.c_uint32), ("c_m1", C.c_uint32),
-                ("n_pow", C.c_uint32)]
+                ("n_pow", C.c_uint32), ("top_levels", C.c_uint32), ("has_plan", C.c_uint32), ("plan", C.c_uint64)]
 
 
 class IngestStats(C.Structure):

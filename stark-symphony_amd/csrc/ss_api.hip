@@ -193,6 +193,7 @@ extern "C" int ss_stwo_ws_layout_of(const ss_stwo_cfg *c, size_t n, ss_stwo_ws_l
     out->ctx = y.ws_ctx; out->alpha = y.ws_alpha; out->leaf = y.ws_leaf; out->total_words = y.ws_total_words;
     out->c_queries = y.c_queries; out->c_p = y.c_p; out->c_p2 = y.c_p2; out->c_fold = y.c_fold;
     out->c_m1 = y.c_m1; out->n_pow = y.n_pow;
+    out->top_levels = y.T; out->has_plan = y.mchk; out->plan = y.mchk ? y.ws_plan : 0;
     return SS_OK;
 }
 

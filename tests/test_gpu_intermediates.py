@@ -48,6 +48,43 @@ def test_head_kernels_leave_the_oracles_intermediates(stwo_small, stwo_prod, mod
         assert [int(ws[lay.ctx + (lay.c_queries + q) * lay.np + pi]) for q in range(Q)] == list(tr.queries[:Q])
 
 
+@pytest.mark.parametrize("name", ["prod", "stwo_trace16.npz", "stwo_wide256_blake2s.npz"])
+def test_query_kernel_leaves_the_plan_of_the_pair_memoisation(stwo_prod, name):
+    """csrc/ss_layout.h ws_plan: for every query and every depth 1..T the lowest query of the proof at the same
+    position (query >> (L - d)) and the lowest one at the sibling position (0xff: none), restated here in numpy from
+    the oracle's queries.  The merkle kernel's byte compares and the top kernel's hashing both run on this plan."""
+    from conftest import GOLDEN
+    import os
+    from stark_symphony_amd import records
+    base = stwo_prod if name == "prod" else records.load_stwo_npz(os.path.join(GOLDEN, name))[0]
+    ver = verifier.Verifier(0)
+    rng = np.random.default_rng(SEED + 22)
+    proofs = [base] + [formats.stwo_corrupt(base, rng)[0] for _ in range(5)]
+    cfg = base.cfg
+    Q, L = cfg.n_queries, cfg.lde_log
+    b = ver.stwo_batch(proofs, verifier.MODE_FIXTURE)
+    b.run(phases=verifier.PHASE_HEAD)
+    lay = _ws_layout(b)
+    assert lay.has_plan == 1 and 1 <= lay.top_levels <= 8
+    ws = b.ws.cpu().numpy().view(np.uint32)
+    for pi, proof in enumerate(proofs):
+        queries = b.intermediates(pi)["queries"].tolist()
+        assert queries == list(O.stwo_verify(proof, verifier.MODE_FIXTURE, trace=True)[1].queries[:Q])
+        for q in range(Q):
+            w = ws[lay.plan + (pi * Q + q) * 4: lay.plan + (pi * Q + q) * 4 + 4]
+            lead = int(w[0]) | int(w[1]) << 32
+            sibl = int(w[2]) | int(w[3]) << 32
+            for d in range(1, lay.top_levels + 1):
+                pos = [x >> (L - d) for x in queries]
+                want_lead = pos.index(pos[q])
+                want_sibl = pos.index(pos[q] ^ 1) if (pos[q] ^ 1) in pos else 0xff
+                assert (lead >> (8 * (d - 1))) & 0xff == want_lead, (pi, q, d)
+                assert (sibl >> (8 * (d - 1))) & 0xff == want_sibl, (pi, q, d)
+    # query counts that do not divide 64, and SS_FLAG_TOP_CHECKS, have no plan
+    ver.stwo_flags = verifier.FLAG_TOP_CHECKS
+    assert _ws_layout(ver.stwo_batch(proofs[:1], verifier.MODE_FIXTURE)).has_plan == 0
+
+
 def _ws_layout(b):
     import ctypes as C
     from stark_symphony_amd import binding
