@@ -8,6 +8,8 @@
     python -m stark_symphony_amd.cli convert --family stwo --to wit tests/data/proof.json     # generate_wit.py
     python -m stark_symphony_amd.cli convert --family stwo --to simf tests/data/proof.json    # generate_simf.py
     python -m stark_symphony_amd.cli convert --family stwo --to json-shared tests/data/proof.json   # shared Merkle paths
+    python -m stark_symphony_amd.cli prove --family stark101 --out target/proof.json      # `make proof` (python -m fibsquare)
+    python -m stark_symphony_amd.cli prove --family stwo --trace-log 20 --seed 0 --to wit --out target/proof.wit
 
 Exit 0 when every input is ACCEPTed, 1 otherwise (REJECT or malformed witness, like the
 reference, whose type errors also end in exit 1: main.rs:77-81,187-190).  Runs on GPU 0.
@@ -56,6 +58,40 @@ def convert(args) -> int:
     return 0
 
 
+def prove(args) -> int:
+    """`make proof` on the GPU.  stark101: what `cd scripts && python -m fibsquare` writes to target/proof.json
+    (stark101/Makefile:14-17; only the reference seed satisfies the verifier's hard-coded boundary value); stwo: a
+    wide-Fibonacci proof in the proof.json schema of tests/data/proof.json (the reference ships two proofs and no
+    prover; seed 0 with the reference's sizes reproduces them byte for byte).  --to wit / simf prints what
+    generate_wit.py / generate_simf.py make of it."""
+    from . import binding
+    try:
+        ver = verifier.Verifier(args.device)
+        if args.family == "stark101":
+            from . import prover101
+            gp = prover101.Stark101GpuProver(ver)
+            res = gp.prove() if args.seed is None else gp.prove(seed=args.seed)
+            p = formats.stark101_from_json(res)
+            out = {"json": lambda: json.dumps(res), "wit": lambda: formats.stark101_to_wit(p),
+                   "simf": lambda: formats.stark101_to_simf(p)}[args.to]()
+        else:
+            from . import prover as stwo_prover
+            gp = stwo_prover.GpuProver(ver)
+            proof = gp.prove_proof(n_cols=args.n_cols, trace_log=args.trace_log, log_blowup=args.log_blowup,
+                                   n_queries=args.n_queries, pow_bits=args.pow_bits, seed=args.seed or 0, hash=args.hash)
+            out = {"json": lambda: json.dumps(formats.stwo_to_json(proof)), "wit": lambda: formats.stwo_to_wit(proof),
+                   "simf": lambda: formats.stwo_to_simf(proof)}[args.to]()
+    except (binding.SsError, ValueError) as e:
+        print("Error: %s" % e, file=sys.stderr)
+        return 1
+    if args.out:
+        with open(args.out, "w") as f:
+            f.write(out + "\n")
+    else:
+        print(out)
+    return 0
+
+
 def main(argv=None) -> int:
     ap = argparse.ArgumentParser(prog="stark_symphony_amd.cli")
     sub = ap.add_subparsers(dest="cmd", required=True)
@@ -82,9 +118,24 @@ def main(argv=None) -> int:
     c.add_argument("path", help="proof.json, .wit or .simf snippet (by extension; anything else = json)")
     c.add_argument("--trace-log", type=int, default=None)
     c.add_argument("--pow-bits", type=int, default=5)
+    g = sub.add_parser("prove", help="make a proof on the GPU (`make proof`: python -m fibsquare / the stwo prover fork)")
+    g.add_argument("--family", choices=["stark101", "stwo"], required=True)
+    g.add_argument("--to", choices=["json", "wit", "simf"], default="json")
+    g.add_argument("--out", default=None, help="file to write (default: stdout)")
+    g.add_argument("--seed", type=int, default=None, help="stark101: a_1 of the trace (default: the reference's); stwo: r of "
+                                                          "the rows [1, r, ...] (default 0 = the reference's proofs)")
+    g.add_argument("--n-cols", type=int, default=4)
+    g.add_argument("--trace-log", type=int, default=9, help="stwo: log2 of the trace rows (9 = tests/data/proof.json)")
+    g.add_argument("--log-blowup", type=int, default=4)
+    g.add_argument("--n-queries", type=int, default=16)
+    g.add_argument("--pow-bits", type=int, default=5)
+    g.add_argument("--hash", choices=["sha256", "blake2s"], default="sha256")
+    g.add_argument("--device", type=int, default=0)
     args = ap.parse_args(argv)
     if args.cmd == "convert":
         return convert(args)
+    if args.cmd == "prove":
+        return prove(args)
 
     import dataclasses
     from . import binding

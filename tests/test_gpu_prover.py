@@ -129,3 +129,36 @@ def test_prove_many_is_byte_identical_to_one_at_a_time(gp):
     assert gp.timings["proofs_per_s"] > 0
     status = gp.ver.verify_stwo(got, cfg=got[0].cfg)
     assert status.tolist() == [0] * len(seeds)
+
+
+# ------------------------------------------------------------------ `make proof` from the command line
+def test_cli_prove_writes_what_the_reference_flow_writes(tmp_path):
+    """`cli prove` = stark101/Makefile:14-17 (`python -m fibsquare`, then generate_wit.py): the reference prover's
+    proof.json and its .wit, byte for byte; for stwo the two proofs the reference ships; and what it writes is what
+    `cli verify` accepts."""
+    import subprocess
+    F = os.path.join(GOLDEN, "formats")
+
+    def cli(*args):
+        return subprocess.run([sys.executable, "-m", "stark_symphony_amd.cli", *args], cwd=ROOT, capture_output=True,
+                              text=True, timeout=600)
+    r = cli("prove", "--family", "stark101")
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout) == json.load(open(os.path.join(GOLDEN, "stark101_proof.json")))
+    wit = tmp_path / "proof.wit"
+    r = cli("prove", "--family", "stark101", "--to", "wit", "--out", str(wit))
+    assert r.returncode == 0 and r.stdout == "", r.stderr
+    assert wit.read_text() == open(os.path.join(F, "stark101_proof.wit")).read()
+    assert cli("verify", "--family", "stark101", "--witness", str(wit)).returncode == 0
+    r = cli("prove", "--family", "stwo")  # defaults = the sizes of tests/data/proof.json
+    assert r.returncode == 0 and json.loads(r.stdout) == json.load(open(os.path.join(GOLDEN, "stwo_proof.json"))), r.stderr
+    r = cli("prove", "--family", "stwo", "--trace-log", "3", "--log-blowup", "1", "--n-queries", "1", "--to", "wit")
+    assert r.returncode == 0 and r.stdout == open(os.path.join(F, "stwo_proof_test.wit")).read(), r.stderr
+    pj = tmp_path / "p.json"
+    r = cli("prove", "--family", "stwo", "--trace-log", "12", "--seed", "3", "--hash", "blake2s", "--out", str(pj))
+    assert r.returncode == 0, r.stderr
+    assert cli("verify", "--family", "stwo", "--trace-log", "12", "--lde-log", "16", "--n-layers", "11", "--hash", "blake2s",
+               "--proof", str(pj)).returncode == 0
+    assert cli("verify", "--family", "stwo", "--proof", str(pj)).returncode == 1  # production config expected: other shape
+    r = cli("prove", "--family", "stark101", "--seed", "5", "--out", str(pj))    # F3: only the reference seed verifies
+    assert r.returncode == 0 and cli("verify", "--family", "stark101", "--proof", str(pj)).returncode == 1
