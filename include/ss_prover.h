@@ -49,6 +49,11 @@ int ss_p_twiddles(ss_ctx *ctx, uint32_t m, uint32_t *tw_out, uint32_t *itw_out, 
  * twiddles, forward = the opposite with the plain twiddles.                                 */
 int ss_p_fft(ss_ctx *ctx, uint32_t m, uint32_t ncols, uint32_t *data, const uint32_t *tw,
              int inverse, void *stream);
+/* Low-degree extension: `ncols` polynomials of 2^k coefficients each (coefs: stride 2^k) -> their evaluations on the
+ * canonic coset of log size m >= k (out: stride 2^m); tw = the plain twiddles of size m.  Equal to ss_p_fft (forward)
+ * of the coefficients followed by zeros, without writing or reading the zeros.                                     */
+int ss_p_lde(ss_ctx *ctx, uint32_t k, uint32_t m, uint32_t ncols, const uint32_t *coefs, uint32_t *out,
+             const uint32_t *tw, void *stream);
 
 /* out[i] = H(be4(cols[0][i]) || ... || be4(cols[w-1][i])), cols stride = col_stride words. */
 int ss_p_hash_rows(ss_ctx *ctx, uint32_t hash, size_t n, uint32_t w, const uint32_t *cols,
@@ -79,9 +84,12 @@ int ss_p_eval_at_point_batch(ss_ctx *ctx, uint32_t m, uint32_t ncols, const uint
 /* DEEP quotient row of every LDE position (two batches: trace columns sampled at P, the 16
  * composition columns at 2P; row = b1 alpha^16 + b2).  hx_hy = pair x then pair y of the LDE
  * coset (2^(lde_log-1) words each); bcoef = the b line coefficient of every column already
- * multiplied by alpha^i ((n_cols + 16) QM31); sums_alpha16 = A1, C1, A2, C2, alpha^16 (host).  */
+ * multiplied by alpha^i ((n_cols + 16) QM31); sums_alpha16 = A1, C1, A2, C2, alpha^16 (host).
+ * cp_log = lde_log: cp_lde holds one value per LDE position (stride 2^lde_log); cp_log = lde_log - 1: the
+ * composition columns depend on x only, so the two positions of a storage pair (x, +-y) carry the same
+ * value and cp_lde holds one per pair (stride 2^(lde_log-1)).                                          */
 int ss_p_quotients(ss_ctx *ctx, uint32_t lde_log, uint32_t n_cols, const uint32_t *trace_lde,
-                   const uint32_t *cp_lde, const uint32_t *hx_hy, const uint32_t *bcoef,
+                   const uint32_t *cp_lde, uint32_t cp_log, const uint32_t *hx_hy, const uint32_t *bcoef,
                    const uint32_t p[8], const uint32_t p2[8], const uint32_t sums_alpha16[20],
                    uint32_t *out, void *stream);
 

@@ -117,10 +117,16 @@ __global__ void p_fft_layer_kernel(uint32_t m, uint32_t layer, uint32_t *__restr
 // conflict free.  Operands are canonical, so the butterflies use the min-based m31 forms.
 constexpr uint32_t kFftT = 32, kFftTp = 33, kFftMaxNb = 8;
 
+// Low-degree extension (ss_p_lde): a forward transform whose input is 2^k coefficients followed by zeros.  In the top
+// pass (lo + nb = m) only the rows below 2^(k - lo) hold anything, and the top z = m - k layers pair every such row
+// with a zero row: v0 + 0 w = v0 - 0 w, i.e. they copy it.  So that pass reads the 2^k coefficients from their compact
+// array (`src`, ncols x 2^k), writes each to its 2^z rows of the tile, runs the nb - z layers that do arithmetic and
+// writes the whole tile to `data`: no zero-filled buffer, a sixteenth of the reads at blow-up 16, half the butterflies.
 template <bool CONTIG>
 __global__ void __launch_bounds__(256)
 p_fft_pass_kernel(uint32_t m, uint32_t lo, uint32_t nb, uint32_t cpb_log, uint32_t *__restrict__ data,
-                  const uint32_t *__restrict__ tw, int inverse, uint32_t scale)
+                  const uint32_t *__restrict__ tw, int inverse, uint32_t scale, const uint32_t *__restrict__ src = nullptr,
+                  uint32_t z = 0)
 {
     __shared__ uint32_t tile[(1u << kFftMaxNb) * kFftTp];
     __shared__ uint32_t twl[1u << kFftMaxNb];
@@ -149,7 +155,16 @@ p_fft_pass_kernel(uint32_t m, uint32_t lo, uint32_t nb, uint32_t cpb_log, uint32
     auto laddr = [&](uint32_t e) -> uint32_t {
         return CONTIG ? (e & (rows - 1)) * kFftTp + (e >> nb) : (e >> 5) * kFftTp + (e & 31);
     };
-    for (uint32_t e = tid; e < elems; e += 256) tile[laddr(e)] = col[gaddr(e)];
+    if (!CONTIG && src) {  // (forward, top pass, hi = 0)
+        const uint32_t *scol = src + ((size_t)blockIdx.y << (m - z));
+        const uint32_t live = rows >> z;  // rows that hold coefficients
+        for (uint32_t e = tid; e < live * kFftT; e += 256) {
+            const uint32_t v = scol[gaddr(e)], r = e >> 5, c = e & 31;
+            for (uint32_t j = 0; j < rows; j += live) tile[(r + j) * kFftTp + c] = v;
+        }
+    } else {
+        for (uint32_t e = tid; e < elems; e += 256) tile[laddr(e)] = col[gaddr(e)];
+    }
     if (!CONTIG) {  // layer ip of the tile at twl[rows - (rows >> ip) ..]
         for (uint32_t ip = 0; ip < nb; ip++) {
             const size_t goff = ((size_t)1 << m) - ((size_t)1 << (m - lo - ip));
@@ -179,7 +194,7 @@ p_fft_pass_kernel(uint32_t m, uint32_t lo, uint32_t nb, uint32_t cpb_log, uint32
         }
     };
     // Two layers per LDS round trip (four rows per thread, three twiddles), one when nb is odd.
-    for (uint32_t done = 0; done < nb;) {
+    for (uint32_t done = (!CONTIG && src) ? z : 0; done < nb;) {
         if (nb - done >= 2) {
             const uint32_t a = inverse ? done : nb - 2 - done;  // local layers a and a + 1
             const bool last = inverse && lo + a + 2 == m && scale != 1;
@@ -385,7 +400,7 @@ __device__ __forceinline__ CM31 deep_den_inv(QM31 sx, QM31 sy, uint32_t x, uint3
 // the bits of the straightforward evaluation (which tools/stwo_prover.py performs).
 __global__ void __launch_bounds__(256)
 p_quotients_kernel(uint32_t lde_log, uint32_t n_cols, const uint32_t *__restrict__ trace_lde,
-                   const uint32_t *__restrict__ cp_lde, const uint32_t *__restrict__ hx,
+                   const uint32_t *__restrict__ cp_lde, uint32_t cp_log, const uint32_t *__restrict__ hx,
                    const uint32_t *__restrict__ hy, const uint32_t *__restrict__ bcoef, QuotArgs q,
                    uint32_t *__restrict__ out)
 {
@@ -395,11 +410,14 @@ p_quotients_kernel(uint32_t lde_log, uint32_t n_cols, const uint32_t *__restrict
     const uint32_t x = hx[h], y0 = hy[h];
     const uint32_t ys[2] = {y0, m31_sub_c(0, y0)};
     // s[batch][position] = sum_k b_k v_k
-    auto dot = [&](const uint32_t *lde, const uint32_t *coef, uint32_t count, QM31 (&res)[2]) {
+    // (pairs = false: a column that depends on x only holds ONE value per storage pair, stride size / 2)
+    auto dot = [&](const uint32_t *lde, const uint32_t *coef, uint32_t count, bool pairs, QM31 (&res)[2]) {
         uint64_t acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
         uint32_t open = 0;
         for (uint32_t k = 0; k < count; k++) {
-            const uint2 v = *reinterpret_cast<const uint2 *>(lde + (size_t)k * size + 2 * h);
+            uint2 v;
+            if (pairs) v = *reinterpret_cast<const uint2 *>(lde + (size_t)k * size + 2 * h);
+            else v.x = v.y = lde[(size_t)k * (size >> 1) + h];
             const uint4 c = *reinterpret_cast<const uint4 *>(coef + 4 * k);
             acc[0][0] = m31_mac(acc[0][0], c.x, v.x); acc[0][1] = m31_mac(acc[0][1], c.y, v.x);
             acc[0][2] = m31_mac(acc[0][2], c.z, v.x); acc[0][3] = m31_mac(acc[0][3], c.w, v.x);
@@ -418,8 +436,8 @@ p_quotients_kernel(uint32_t lde_log, uint32_t n_cols, const uint32_t *__restrict
             res[p] = QM31{m31_red64(acc[p][0]), m31_red64(acc[p][1]), m31_red64(acc[p][2]), m31_red64(acc[p][3])};
     };
     QM31 s1[2], s2[2];
-    dot(trace_lde, bcoef, n_cols, s1);
-    dot(cp_lde, bcoef + 4 * n_cols, kCp, s2);
+    dot(trace_lde, bcoef, n_cols, true, s1);
+    dot(cp_lde, bcoef + 4 * n_cols, kCp, cp_log == lde_log, s2);
     // deep_quotient_denominator_inverse (deep/quotients.simf:15-22) for (P, 2P) x (y, -y)
     CM31 d[4];
     uint32_t nrm[4], pre[4];
@@ -537,10 +555,10 @@ extern "C" int ss_p_fft(ss_ctx *, uint32_t m, uint32_t ncols, uint32_t *data, co
             if (i == 0)
                 hipLaunchKernelGGL(p_fft_pass_kernel<true>, dim3((1u << (m - nb[i])) >> (5 - cpb_log), ncols >> cpb_log),
                                    dim3(256), 0, (hipStream_t)stream, m, lo[i], nb[i], cpb_log, data, tw, inverse,
-                                   scale);
+                                   scale, nullptr, 0u);
             else
                 hipLaunchKernelGGL(p_fft_pass_kernel<false>, dim3((1u << (m - nb[i])) / kFftT, ncols), dim3(256), 0,
-                                   (hipStream_t)stream, m, lo[i], nb[i], 0u, data, tw, inverse, scale);
+                                   (hipStream_t)stream, m, lo[i], nb[i], 0u, data, tw, inverse, scale, nullptr, 0u);
         }
         P_TRY(hipGetLastError());
         return SS_OK;
@@ -553,6 +571,41 @@ extern "C" int ss_p_fft(ss_ctx *, uint32_t m, uint32_t ncols, uint32_t *data, co
     } else {
         for (uint32_t i = m; i-- > 0;)
             hipLaunchKernelGGL(p_fft_layer_kernel, grid, dim3(256), 0, (hipStream_t)stream, m, i, data, tw, 0, 1u);
+    }
+    P_TRY(hipGetLastError());
+    return SS_OK;
+}
+
+// Evaluations on the canonic coset of log size m of ncols polynomials given by 2^k coefficients each (k <= m):
+// ss_p_fft of the zero-extended array, without materialising the zeros (see p_fft_pass_kernel).
+extern "C" int ss_p_lde(ss_ctx *ctx, uint32_t k, uint32_t m, uint32_t ncols, const uint32_t *coefs, uint32_t *out,
+                        const uint32_t *tw, void *stream)
+{
+    if (!coefs || !out || !tw || m < 1 || m > 28 || k > m || !ncols) return ss_internal_set_err(SS_ERR_ARG, "ss_p_lde: bad argument");
+    const uint32_t z = m - k;
+    const uint32_t np = (m + 7) / 8, base = m / np, extra = m % np;
+    uint32_t lo[4], nb[4];
+    for (uint32_t i = 0, at = 0; i < np; i++) { lo[i] = at; nb[i] = base + (i < extra ? 1 : 0); at += nb[i]; }
+    // the shortcut needs a strided top pass whose rows are whole runs of coefficients: z <= nb and k >= lo of that pass
+    if (m < 13 || np < 2 || z == 0 || z > nb[np - 1]) {
+        for (uint32_t c = 0; c < ncols; c++) {
+            P_TRY(hipMemcpyAsync(out + ((size_t)c << m), coefs + ((size_t)c << k), (size_t)4 << k, hipMemcpyDeviceToDevice,
+                                 (hipStream_t)stream));
+            if (z) P_TRY(hipMemsetAsync(out + ((size_t)c << m) + ((size_t)1 << k), 0, ((size_t)4 << m) - ((size_t)4 << k), (hipStream_t)stream));
+        }
+        return ss_p_fft(ctx, m, ncols, out, tw, 0, stream);
+    }
+    uint32_t cpb_log = 0;
+    while (cpb_log < 3 && ncols % (2u << cpb_log) == 0) cpb_log++;
+    for (uint32_t s = 0; s < np; s++) {
+        const uint32_t i = np - 1 - s;
+        if (i == 0)
+            hipLaunchKernelGGL(p_fft_pass_kernel<true>, dim3((1u << (m - nb[i])) >> (5 - cpb_log), ncols >> cpb_log),
+                               dim3(256), 0, (hipStream_t)stream, m, lo[i], nb[i], cpb_log, out, tw, 0, 1u, nullptr, 0u);
+        else
+            hipLaunchKernelGGL(p_fft_pass_kernel<false>, dim3((1u << (m - nb[i])) / kFftT, ncols), dim3(256), 0,
+                               (hipStream_t)stream, m, lo[i], nb[i], 0u, out, tw, 0, 1u, i == np - 1 ? coefs : nullptr,
+                               i == np - 1 ? z : 0u);
     }
     P_TRY(hipGetLastError());
     return SS_OK;
@@ -689,11 +742,12 @@ extern "C" int ss_p_fri_fold_dev(ss_ctx *, size_t n_out, const uint32_t *in, con
 }
 
 extern "C" int ss_p_quotients(ss_ctx *, uint32_t lde_log, uint32_t n_cols, const uint32_t *trace_lde,
-                              const uint32_t *cp_lde, const uint32_t *hx_hy, const uint32_t *bcoef,
+                              const uint32_t *cp_lde, uint32_t cp_log, const uint32_t *hx_hy, const uint32_t *bcoef,
                               const uint32_t p[8], const uint32_t p2[8], const uint32_t sums_alpha16[20],
                               uint32_t *out, void *stream)
 {
-    if (!trace_lde || !cp_lde || !hx_hy || !bcoef || !p || !p2 || !sums_alpha16 || !out || lde_log < 2 || lde_log > 28)
+    if (!trace_lde || !cp_lde || !hx_hy || !bcoef || !p || !p2 || !sums_alpha16 || !out || lde_log < 2 || lde_log > 28 ||
+        (cp_log != lde_log && cp_log + 1 != lde_log))
         return ss_internal_set_err(SS_ERR_ARG, "ss_p_quotients: bad argument");
     QuotArgs q;
     q.px = q4(p); q.py = q4(p + 4); q.p2x = q4(p2); q.p2y = q4(p2 + 4);
@@ -701,7 +755,7 @@ extern "C" int ss_p_quotients(ss_ctx *, uint32_t lde_log, uint32_t n_cols, const
     q.alpha16 = q4(sums_alpha16 + 16);
     const size_t half = (size_t)1 << (lde_log - 1);
     hipLaunchKernelGGL(p_quotients_kernel, dim3(blocks_for(half)), dim3(256), 0, (hipStream_t)stream,
-                       lde_log, n_cols, trace_lde, cp_lde, hx_hy, hx_hy + half, bcoef, q, out);
+                       lde_log, n_cols, trace_lde, cp_lde, cp_log, hx_hy, hx_hy + half, bcoef, q, out);
     P_TRY(hipGetLastError());
     return SS_OK;
 }

@@ -125,6 +125,7 @@ class GpuProver:
         sig("ss_p_trace", C.c_uint32, C.c_uint32, C.c_uint32, u32p)
         sig("ss_p_twiddles", C.c_uint32, u32p, u32p, u32p)
         sig("ss_p_fft", C.c_uint32, C.c_uint32, u32p, u32p, C.c_int)
+        sig("ss_p_lde", C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p, u32p)
         sig("ss_p_hash_rows", C.c_uint32, sz, C.c_uint32, u32p, sz, u32p)
         sig("ss_p_hash_qm31", C.c_uint32, sz, u32p, u32p)
         sig("ss_p_merkle", C.c_uint32, sz, u32p)
@@ -133,7 +134,7 @@ class GpuProver:
         sig("ss_p_eval_at_point_batch", C.c_uint32, C.c_uint32, u32p, sz, u32p, u32p, u32p)
         sig("ss_p_channel_fri_layer", C.c_uint32, u32p, u32p, u32p, u32p)
         sig("ss_p_fri_fold_dev", sz, u32p, u32p, u32p, u32p)
-        sig("ss_p_quotients", C.c_uint32, C.c_uint32, u32p, u32p, u32p, u32p, u32p, u32p, u32p, u32p)
+        sig("ss_p_quotients", C.c_uint32, C.c_uint32, u32p, u32p, C.c_uint32, u32p, u32p, u32p, u32p, u32p, u32p)
         sig("ss_p_fri_fold", sz, u32p, u32p, u32p, u32p)
         sig("ss_p_pow", C.c_uint32, u32p, C.c_uint64, C.c_uint64, C.c_uint64, u32p)
         self._dom: Dict[int, tuple] = {}
@@ -176,11 +177,20 @@ class GpuProver:
         self._call("ss_p_fft", m, data.shape[0], data.data_ptr(), (itw if inverse else tw).data_ptr(),
                    1 if inverse else 0)
 
-    def extend(self, coefs, m: int):
-        """Coefficients [ncols, 2^k] -> evaluations on the canonic coset of log size m."""
-        out = self._zeros(coefs.shape[0], 1 << m)
-        out[:, :coefs.shape[1]] = coefs
-        self.fft(m, out, False)
+    def extend(self, coefs, m: int, x_only: bool = False):
+        """Coefficients [ncols, 2^k] -> evaluations on the canonic coset of log size m.
+        x_only: the polynomials have no y term -- `coefs` holds the coefficients of x^k1 pi(x)^k2 ... only (the even
+        positions of the full array) -- so the two points (x, +-y) of a storage pair get the same value: returns ONE
+        value per pair, [ncols, 2^(m-1)].  That is the transform of size m - 1 run with the twiddles of layers 1.. of
+        size m, which lie behind its first 2^(m-1) words (include/ss_prover.h, ss_p_twiddles)."""
+        k = int(coefs.shape[1]).bit_length() - 1
+        assert coefs.shape[1] == 1 << k and coefs.is_contiguous()
+        tw = self.domain(m)[0]
+        if x_only:
+            tw, m = tw[1 << (m - 1):], m - 1
+        out = self._empty(coefs.shape[0], 1 << m)
+        # (ss_p_lde: the forward transform of the coefficients followed by zeros, without writing or reading the zeros)
+        self._call("ss_p_lde", k, m, coefs.shape[0], coefs.data_ptr(), out.data_ptr(), tw.data_ptr())
         return out
 
     def merkle(self, hsel: int, leaves_fn, n: int):
@@ -287,13 +297,21 @@ class GpuProver:
         F = self._empty(4, 1 << (n + 1))
         self._call("ss_p_composition", n, N, ev.data_ptr(), hxhy_c.data_ptr(), self._q(cp_alpha), F.data_ptr())
         self.fft(n + 1, F, True)
-        cp_coefs = self._zeros(16, 1 << n)
+        # Partition 4c + part of coordinate c takes the coefficients whose two lowest index bits are `part` and is a
+        # polynomial in x alone: in the basis of size n its coefficients sit at the even positions (no y term).  Kept
+        # compact (2^(n-1) per column); its LDE has one value per storage pair, and the two leaves of a pair are equal.
+        cp_coefs = self._empty(16, 1 << (n - 1))
         for c in range(4):
             for part in range(4):
-                cp_coefs[4 * c + part, 0::2] = F[c, part::4]
-        cp_lde = self.extend(cp_coefs, L)
-        cp_tree = self.merkle(hsel, lambda lv: self._call(
-            "ss_p_hash_rows", hsel, size_L, 16, cp_lde.data_ptr(), size_L, lv.data_ptr()), size_L)
+                cp_coefs[4 * c + part] = F[c, part::4]
+        cp_lde = self.extend(cp_coefs, L, x_only=True)  # [16, 2^(L-1)]: position i -> column value at i >> 1
+        half_L = size_L >> 1
+
+        def cp_leaves(lv):
+            pair_leaf = self._empty(half_L, 8)
+            self._call("ss_p_hash_rows", hsel, half_L, 16, cp_lde.data_ptr(), half_L, pair_leaf.data_ptr())
+            lv[:size_L].view(half_L, 2, 8).copy_(pair_leaf[:, None, :].expand(half_L, 2, 8))
+        cp_tree = self.merkle(hsel, cp_leaves, size_L)
         cp_root = self._root(cp_tree, size_L)
         mark("composition commit")
         ch.mix(cp_root)
@@ -319,8 +337,9 @@ class GpuProver:
         # all columns of a commitment are sampled at one point: one batched fold chain each
         self._call("ss_p_eval_at_point_batch", n, N, coefs.data_ptr(), 1 << n, f1.ctypes.data, scratch.data_ptr(),
                    samples.data_ptr())
-        self._call("ss_p_eval_at_point_batch", n, 16, cp_coefs.data_ptr(), 1 << n, f2.ctypes.data, scratch.data_ptr(),
-                   samples[N:].data_ptr())
+        f2x = np.ascontiguousarray(f2[4:])  # no y term: the factors x, pi(x), ... over the compact coefficients
+        self._call("ss_p_eval_at_point_batch", n - 1, 16, cp_coefs.data_ptr(), 1 << (n - 1), f2x.ctypes.data,
+                   scratch.data_ptr(), samples[N:].data_ptr())
         samp = self._host(samples).astype(np.int64)
         oods_trace = [tuple(int(x) for x in samp[k]) for k in range(N)]
         oods_cp = [tuple(int(x) for x in samp[N + k]) for k in range(16)]
@@ -348,7 +367,7 @@ class GpuProver:
         sa = (C.c_uint32 * 20)(*[x for v in sums + [a16] for x in v])
         _, itw_L, hxhy_L = self.domain(L)
         layer = self._empty(size_L, 4)
-        self._call("ss_p_quotients", L, N, lde.data_ptr(), cp_lde.data_ptr(), hxhy_L.data_ptr(),
+        self._call("ss_p_quotients", L, N, lde.data_ptr(), cp_lde.data_ptr(), L - 1, hxhy_L.data_ptr(),
                    bcoef.data_ptr(), pts, pts2, sa, layer.data_ptr())
         mark("quotients")
 
@@ -411,7 +430,7 @@ class GpuProver:
         # every gather of the decommitment is enqueued first, then downloaded at once
         g = self._Gather(self)
         lde_t, cp_lde_t = lde.T, cp_lde.T  # views: row = LDE position
-        k_tq, k_cq = g.rows(lde_t, queries), g.rows(cp_lde_t, queries)  # [Q, N], [Q, 16]
+        k_tq, k_cq = g.rows(lde_t, queries), g.rows(cp_lde_t, [q >> 1 for q in queries])  # [Q, N], [Q, 16]
         k_thw = g.rows(trace_tree, self._path_rows(size_L, queries))
         k_chw = g.rows(cp_tree, self._path_rows(size_L, queries))
         k_layers = []
