@@ -421,8 +421,10 @@ p_quotients_kernel(uint32_t lde_log, uint32_t n_cols, const uint32_t *__restrict
             const uint4 c = *reinterpret_cast<const uint4 *>(coef + 4 * k);
             acc[0][0] = m31_mac(acc[0][0], c.x, v.x); acc[0][1] = m31_mac(acc[0][1], c.y, v.x);
             acc[0][2] = m31_mac(acc[0][2], c.z, v.x); acc[0][3] = m31_mac(acc[0][3], c.w, v.x);
-            acc[1][0] = m31_mac(acc[1][0], c.x, v.y); acc[1][1] = m31_mac(acc[1][1], c.y, v.y);
-            acc[1][2] = m31_mac(acc[1][2], c.z, v.y); acc[1][3] = m31_mac(acc[1][3], c.w, v.y);
+            if (pairs) {  // (one value per pair: the second sum is the first)
+                acc[1][0] = m31_mac(acc[1][0], c.x, v.y); acc[1][1] = m31_mac(acc[1][1], c.y, v.y);
+                acc[1][2] = m31_mac(acc[1][2], c.z, v.y); acc[1][3] = m31_mac(acc[1][3], c.w, v.y);
+            }
             if (++open == 3) {
 #pragma unroll
                 for (int p = 0; p < 2; p++)
@@ -434,6 +436,7 @@ p_quotients_kernel(uint32_t lde_log, uint32_t n_cols, const uint32_t *__restrict
 #pragma unroll
         for (int p = 0; p < 2; p++)
             res[p] = QM31{m31_red64(acc[p][0]), m31_red64(acc[p][1]), m31_red64(acc[p][2]), m31_red64(acc[p][3])};
+        if (!pairs) res[1] = res[0];
     };
     QM31 s1[2], s2[2];
     dot(trace_lde, bcoef, n_cols, true, s1);
