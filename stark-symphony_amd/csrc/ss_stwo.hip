@@ -607,7 +607,7 @@ __device__ __forceinline__ void stwo_merkle_body(const StwoLayout &lay, const ui
 // from those flags, reads the same plan instead of searching for leaders, and only hashes -- with the cross check of
 // every node it produces.  The set of compares is the same, so is the exactness argument.  Other query counts
 // (and SS_FLAG_TOP_CHECKS) run everything here (LIGHTS = true).  Measured on the 2^20 config: 3.92 -> 3.46 ms, the
-// merkle kernel unchanged at 14.7 ms (its extra 0.4 % of instructions hide under its hashes).
+// merkle kernel unchanged at 14.7 ms within the run-to-run spread (+0.8 % instructions).
 #ifndef SS_TOP_LIGHTS
 #define SS_TOP_LIGHTS 2
 #endif
