@@ -243,14 +243,27 @@ p_fft_pass_kernel(uint32_t m, uint32_t lo, uint32_t nb, uint32_t cpb_log, uint32
 }
 
 // --------------------------------------------------------------------------------- hashing
-template <int HF>
+// WC = the row width when it is one of the two the stwo prover hashes 2^24 times (4 trace columns, 16 composition
+// columns): the padding words and, for 16, the whole second block's message schedule are then compile-time constants
+// (the same digest; fewer instructions).  WC = 0: any width, from the argument.
+template <int HF, uint32_t WC>
 __global__ void p_hash_rows_kernel(size_t n, uint32_t w, const uint32_t *__restrict__ cols, size_t stride,
                                    uint32_t *__restrict__ out)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t d[8];
-    Hasher<HF>::template stream<true, 0>(nullptr, [&](uint32_t k) { return cols[(size_t)k * stride + i]; }, w, d);
+    if (WC == 16) {  // 64 bytes: the message of a pair hash (second SHA-256 block = constant padding)
+        uint32_t a[8], b[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            a[k] = Hasher<HF>::native(cols[(size_t)k * stride + i]);
+            b[k] = Hasher<HF>::native(cols[(size_t)(8 + k) * stride + i]);
+        }
+        Hasher<HF>::template pair<true>(a, b, d);
+    } else {
+        Hasher<HF>::template stream<true, 0>(nullptr, [&](uint32_t k) { return cols[(size_t)k * stride + i]; }, WC ? WC : w, d);
+    }
     uint4 *o = reinterpret_cast<uint4 *>(out + i * 8);
     o[0] = make_uint4(Hasher<HF>::native(d[0]), Hasher<HF>::native(d[1]), Hasher<HF>::native(d[2]), Hasher<HF>::native(d[3]));
     o[1] = make_uint4(Hasher<HF>::native(d[4]), Hasher<HF>::native(d[5]), Hasher<HF>::native(d[6]), Hasher<HF>::native(d[7]));
@@ -618,12 +631,18 @@ extern "C" int ss_p_hash_rows(ss_ctx *, uint32_t hash, size_t n, uint32_t w, con
                               size_t col_stride, uint32_t *out, void *stream)
 {
     if (!cols || !out || !n || !w || hash > 1) return ss_internal_set_err(SS_ERR_ARG, "ss_p_hash_rows: bad argument");
-    if (hash)
-        hipLaunchKernelGGL(p_hash_rows_kernel<1>, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, n, w, cols,
-                           col_stride, out);
-    else
-        hipLaunchKernelGGL(p_hash_rows_kernel<0>, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, n, w, cols,
-                           col_stride, out);
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, n, w, cols, col_stride, out);
+    };
+    if (hash) {
+        if (w == 4) launch(p_hash_rows_kernel<1, 4>);
+        else if (w == 16) launch(p_hash_rows_kernel<1, 16>);
+        else launch(p_hash_rows_kernel<1, 0>);
+    } else {
+        if (w == 4) launch(p_hash_rows_kernel<0, 4>);
+        else if (w == 16) launch(p_hash_rows_kernel<0, 16>);
+        else launch(p_hash_rows_kernel<0, 0>);
+    }
     P_TRY(hipGetLastError());
     return SS_OK;
 }
