@@ -337,9 +337,13 @@ class GpuProver:
         # all columns of a commitment are sampled at one point: one batched fold chain each
         self._call("ss_p_eval_at_point_batch", n, N, coefs.data_ptr(), 1 << n, f1.ctypes.data, scratch.data_ptr(),
                    samples.data_ptr())
-        f2x = np.ascontiguousarray(f2[4:])  # no y term: the factors x, pi(x), ... over the compact coefficients
-        self._call("ss_p_eval_at_point_batch", n - 1, 16, cp_coefs.data_ptr(), 1 << (n - 1), f2x.ctypes.data,
-                   scratch.data_ptr(), samples[N:].data_ptr())
+        if n > 1:
+            f2x = np.ascontiguousarray(f2[4:])  # no y term: the factors x, pi(x), ... over the compact coefficients
+            self._call("ss_p_eval_at_point_batch", n - 1, 16, cp_coefs.data_ptr(), 1 << (n - 1), f2x.ctypes.data,
+                       scratch.data_ptr(), samples[N:].data_ptr())
+        else:  # a two-row trace: every partition is a constant
+            samples[N:] = 0
+            samples[N:, 0] = cp_coefs[:, 0]
         samp = self._host(samples).astype(np.int64)
         oods_trace = [tuple(int(x) for x in samp[k]) for k in range(N)]
         oods_cp = [tuple(int(x) for x in samp[N + k]) for k in range(16)]

@@ -40,6 +40,8 @@ def test_gpu_prover_reproduces_reference_fixtures(gp, name, kw):
     dict(n_cols=8, trace_log=4, log_blowup=1, n_queries=9, pow_bits=3, seed=7, hash="sha256"),
     dict(n_cols=32, trace_log=6, log_blowup=3, n_queries=5, pow_bits=8, seed=1, hash="blake2s"),
     dict(n_cols=3, trace_log=2, log_blowup=1, n_queries=2, pow_bits=0, seed=2, hash="sha256"),
+    dict(n_cols=3, trace_log=1, log_blowup=2, n_queries=3, pow_bits=1, seed=4, hash="sha256"),  # two rows: constant partitions
+    dict(n_cols=4, trace_log=11, log_blowup=2, n_queries=4, pow_bits=2, seed=6, hash="sha256"),  # LDE 2^13: first size of the LDS passes
     dict(n_cols=5, trace_log=12, log_blowup=2, n_queries=11, pow_bits=10, seed=5, hash="blake2s"),
 ])
 def test_gpu_prover_equals_numpy_prover(gp, kw):
