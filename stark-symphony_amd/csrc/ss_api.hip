@@ -110,6 +110,7 @@ extern "C" void ss_ctx_destroy(ss_ctx *ctx)
     for (auto &d : ctx->hp.dev)
         if (d) (void)hipFree(d);
     if (ctx->hp.stream) (void)hipStreamDestroy(ctx->hp.stream);
+    if (ctx->hp.vstream) (void)hipStreamDestroy(ctx->hp.vstream);
     text_path_destroy(ctx->tp);
     delete ctx;
 }
@@ -577,6 +578,7 @@ static int hp_pinned(ss_ctx *ctx, size_t bytes)
 {
     HostPath &hp = ctx->hp;
     if (!hp.stream) HIP_TRY(hipStreamCreateWithFlags(&hp.stream, hipStreamNonBlocking));
+    if (!hp.vstream) HIP_TRY(hipStreamCreateWithFlags(&hp.vstream, hipStreamNonBlocking));
     for (int i = 0; i < 2; i++)
         if (!hp.pinned_free[i]) HIP_TRY(hipEventCreateWithFlags(&hp.pinned_free[i], hipEventDisableTiming));
     if (hp.pinned_bytes >= bytes) return SS_OK;
@@ -589,8 +591,9 @@ static int hp_pinned(ss_ctx *ctx, size_t bytes)
 }
 
 // Host records -> verdicts: records are gathered into pinned staging in chunks (host threads),
-// uploaded asynchronously (two buffers in flight), re-tiled ON THE GPU (ss_stwo_pack_dev) and
-// verified.  PCIe-bound.
+// uploaded asynchronously (two buffers in flight); every chunk is re-tiled ON THE GPU (ss_stwo_pack_dev) and
+// verified on a second stream as soon as it has arrived, so only the last chunk's verification is not hidden
+// behind an upload.  PCIe-bound.
 extern "C" int ss_stwo_verify_records(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n,
                                       const uint32_t *const *records, uint32_t *status_host)
 {
@@ -600,36 +603,57 @@ extern "C" int ss_stwo_verify_records(ss_ctx *ctx, const ss_stwo_cfg *c, size_t 
     if (n * (size_t)c->n_queries > 0x7fffffffu) return set_err(SS_ERR_ARG, "batch too large");
     std::lock_guard<std::mutex> lock(ctx->mu);  // the context's scratch: one such call at a time
     HIP_TRY(hipSetDevice(ctx->device));
-    const size_t W = ss_stwo_record_words(c), words = ss_stwo_batch_words(c, n);
-    const size_t wsb = ss_stwo_workspace_bytes(c, n);
+    const size_t W = ss_stwo_record_words(c);
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, (64u << 20) / (W * 4)));
+    // (the first chunks are small and double: nothing overlaps the staging of the first one)
+    std::vector<size_t> counts;
+    for (size_t lo = 0, step = std::max<size_t>(1, chunk / 16); lo < n; step = std::min(chunk, step * 2)) {
+        counts.push_back(std::min(step, n - lo));
+        lo += counts.back();
+    }
+    size_t words = 0, wsb = 0;  // (neither is monotone in the batch size: smaller batches get smaller top-kernel groups)
+    for (size_t cnt : counts) {
+        words = std::max(words, ss_stwo_batch_words(c, cnt));
+        wsb = std::max(wsb, ss_stwo_workspace_bytes(c, cnt));
+    }
     int rc;
     if ((rc = hp_reserve(ctx, 0, n * W * 4))) return rc;
     if ((rc = hp_reserve(ctx, 1, words * 4))) return rc;
     if ((rc = hp_reserve(ctx, 2, wsb))) return rc;
     if ((rc = hp_reserve(ctx, 3, n * 4))) return rc;
-    const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, (64u << 20) / (W * 4)));
     if ((rc = hp_pinned(ctx, chunk * W * 4))) return rc;
     HostPath &hp = ctx->hp;
-    hipStream_t s = hp.stream;
-    uint32_t *rec_dev = (uint32_t *)hp.dev[0];
-    int buf = 0;
-    // (the first chunks are small and double: nothing overlaps the staging of the first one)
-    size_t step = std::max<size_t>(1, chunk / 16);
-    for (size_t lo = 0, cnt; lo < n; lo += cnt, buf ^= 1, step = std::min(chunk, step * 2)) {
-        cnt = std::min(step, n - lo);
-        HIP_TRY(hipEventSynchronize(hp.pinned_free[buf]));  // previous upload from this buffer done
-        uint32_t *stage = (uint32_t *)hp.pinned[buf];
-        parallel_for(cnt, [&](size_t i) { copy_streaming(stage + i * W, records[lo + i], W * 4); },
-                     std::max<size_t>(1, std::min<size_t>(8, cnt * W * 4 / (1u << 20))));
-        HIP_TRY(hipMemcpyAsync(rec_dev + lo * W, stage, cnt * W * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipEventRecord(hp.pinned_free[buf], s));
-    }
-    if ((rc = ss_stwo_pack_dev(ctx, c, n, rec_dev, (uint32_t *)hp.dev[1], s))) return rc;
-    rc = ss_stwo_verify_batch_dev(ctx, c, n, (const uint32_t *)hp.dev[1], hp.dev[2], wsb,
-                                  (uint32_t *)hp.dev[3], nullptr, s);
+    hipStream_t s = hp.stream, vs = hp.vstream;
+    uint32_t *rec_dev = (uint32_t *)hp.dev[0], *status_dev = (uint32_t *)hp.dev[3];
+    auto run = [&]() -> int {
+        int buf = 0;
+        size_t lo = 0;
+        for (size_t cnt : counts) {
+            HIP_TRY(hipEventSynchronize(hp.pinned_free[buf]));  // previous upload from this buffer done
+            uint32_t *stage = (uint32_t *)hp.pinned[buf];
+            parallel_for(cnt, [&](size_t i) { copy_streaming(stage + i * W, records[lo + i], W * 4); },
+                         std::max<size_t>(1, std::min<size_t>(8, cnt * W * 4 / (1u << 20))));
+            HIP_TRY(hipMemcpyAsync(rec_dev + lo * W, stage, cnt * W * 4, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipEventRecord(hp.pinned_free[buf], s));
+            // the chunk that has just been queued: re-tile and verify it behind its upload (batch and workspace are
+            // shared by the chunks, which the verify stream takes one after the other)
+            HIP_TRY(hipStreamWaitEvent(vs, hp.pinned_free[buf], 0));
+            int r = ss_stwo_pack_dev(ctx, c, cnt, rec_dev + lo * W, (uint32_t *)hp.dev[1], vs);
+            if (r) return r;
+            r = ss_stwo_verify_batch_dev(ctx, c, cnt, (const uint32_t *)hp.dev[1], hp.dev[2], wsb, status_dev + lo, nullptr, vs);
+            if (r) return r;
+            lo += cnt;
+            buf ^= 1;
+        }
+        HIP_TRY(hipMemcpyAsync(status_host, status_dev, n * 4, hipMemcpyDeviceToHost, vs));
+        return SS_OK;
+    };
+    rc = run();
+    // whatever happened, nothing of this call may still be in flight when the scratch is used again
+    const hipError_t e1 = hipStreamSynchronize(s), e2 = hipStreamSynchronize(vs);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(status_host, hp.dev[3], n * 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(e1);
+    HIP_TRY(e2);
     return SS_OK;
 }
 

@@ -36,7 +36,8 @@ struct HostPath {
     hipEvent_t pinned_free[2] = {nullptr, nullptr};
     void *dev[4] = {nullptr, nullptr, nullptr, nullptr};  // records, batch, ws, status
     size_t dev_bytes[4] = {0, 0, 0, 0};
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // uploads
+    hipStream_t vstream = nullptr;  // re-tiling and verification of the chunks already uploaded
 };
 
 // A config's text template resident on the device (ss_text.h), kept per (config, format).
