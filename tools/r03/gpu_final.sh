@@ -14,7 +14,7 @@ python bench.py --workload stark101 --steps 1920 --warmup 6 --cpu-seconds 3 > $O
 python bench.py --workload stark101 --proofs-per-gpu 8192 --steps 960 --warmup 6 --no-cpu-baseline --e2e 0 > $O/bench_stark101_8192.json 2>> $O/bench_stark101.err
 mkdir -p build
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/sha_bench.hip -o build/sha_bench 2>/dev/null && build/sha_bench 512 > $O/sha_bench.txt 2>&1
-python tools/host_path_bench.py 2048 > $O/host_path.txt 2>&1
+python tools/host_path_bench.py 2048 > $O/host_path.txt 2>&1; python tools/host_path_bench.py 16384 >> $O/host_path.txt 2>&1
 python tools/e2e_bench.py --n 4096 --reps 4 --files > $O/e2e_4096.json 2> $O/e2e.err; echo "e2e rc=$?"
 python tools/e2e_bench.py --n 4096 --reps 3 --noncanonical 0.01 > $O/e2e_4096_nc1.json 2>> $O/e2e.err
 python tools/e2e_bench.py --n 512 --reps 4 > $O/e2e_512.json 2>> $O/e2e.err

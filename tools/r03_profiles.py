@@ -111,7 +111,7 @@ json.dump({"note": "tools/e2e_bench.py: text -> verdict through ss_stwo_verify_t
                    "2^16 / Q=32 shape; _pysep: proof.json with json.dumps' default separators, 27 % more bytes)", "commit": commit, "runs": e2e}, open(os.path.join(P, "r03_e2e.json"), "w"), indent=1)
 
 for name, src, head in (("r03_sha_calibration.txt", "sha_bench.txt", "$ build/sha_bench 512      (tools/sha_bench.hip at %s; MI355X)" % commit),
-                        ("r03_host_path.txt", "host_path.txt", "$ python tools/host_path_bench.py 2048   (ss_stwo_verify_records, 2^20 shape, at %s; "
+                        ("r03_host_path.txt", "host_path.txt", "$ python tools/host_path_bench.py 2048; ... 16384   (ss_stwo_verify_records, 2^20 shape, at %s; "
                                                                "the first call allocates the scratch)" % commit)):
     body = [l for l in open(os.path.join(G, src)).read().splitlines() if "amdgpu.ids" not in l]
     open(os.path.join(P, name), "w").write("\n".join([head] + body) + "\n")
