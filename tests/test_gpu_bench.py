@@ -52,7 +52,7 @@ def test_bench_two_ranks_share_one_gpu():
     assert abs(d["value"] - 2 * 512 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
 
 
-@pytest.mark.parametrize("n", [2, 8])
+@pytest.mark.parametrize("n", [2, 4])  # the pytest process + 4 ranks: the GPU box allows 6 processes on its card
 def test_bench_spawns_its_own_ranks(n):
     """`python bench.py --gpus N` exactly as the scaling driver may type it (no torchrun, no WORLD_SIZE):
     the process turns into a launcher before touching torch / HIP, starts N ranks, relays rank 0's
