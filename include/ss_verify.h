@@ -42,8 +42,9 @@
 extern "C" {
 #endif
 
-#define SS_VERSION 0x00020001 /* 2.0: stwo records carry their Merkle path lengths; shape_status is gone.
-                                 2.1: GPU text reader behind the text entry points, ss_stwo_write_text, thread rules */
+#define SS_VERSION 0x00020002 /* 2.0: stwo records carry their Merkle path lengths; shape_status is gone.
+                                 2.1: GPU text reader behind the text entry points, ss_stwo_write_text, thread rules
+                                 2.2: shared records (every distinct Merkle sibling once), expanded on the GPU */
 
 /* return codes (all < 0 are errors; verdicts live in the status array) */
 #define SS_OK 0
@@ -149,6 +150,35 @@ size_t ss_stwo_workspace_bytes(const ss_stwo_cfg *cfg, size_t n);
 int ss_stwo_pack(const ss_stwo_cfg *cfg, size_t n, const uint32_t *const *records,
                  uint32_t *batch_host);
 
+/* Shared record: the same proof with every DISTINCT sibling of a tree stored once.  The reference presents one
+ * full path per query and hashes all of them (fri/queries.simf:41 "we do not sort and remove duplicates";
+ * scripts/generate_wit.py:36-42 splits the prover's lists per query), so the Q paths of a tree repeat the nodes
+ * where they meet: 9-21 % of a record.  Layout (ss_stwo_shared_fixed_words words, then the nodes):
+ *   roots[3][8]  oods_trace[n_cols][4]  oods_cp[16][4]  fri_roots[1+n_layers][8]  last_layer[4]  pow_nonce_hi  _lo
+ *   n_queries x { trace_vals[n_cols], cp_vals[16] }
+ *   (1+n_layers) x n_queries x witness[4]
+ *   queries[n_queries]       positions in the LDE domain -- an UNTRUSTED hint that only says which siblings coincide
+ *   count[3+n_layers]        distinct siblings per tree (kind 0 trace, 1 cp, 2+l FRI layer l)
+ *   nodes                    tree by tree, count[t] x 8 words, in the order a walk over query 0, 1, .. leaf -> root
+ *                            first needs them (csrc/ss_shared.h states the closed form)
+ * Expansion is a gather without hashing; the verifier then draws its own queries and checks every expanded path in
+ * full, so a wrong hint can only make a proof fail.  A record whose positions leave the domain, whose counts are not
+ * what its positions imply or whose size is not fixed + 8 * sum(count) is no shared record of the config:
+ * status SS_STATUS_MALFORMED.  Only proofs whose paths all have the config's lengths and agree wherever they meet
+ * have a shared form.  No bytes of such a format exist in the reference: parity is "verifies exactly as the
+ * per-query record it expands to".                                                                              */
+size_t ss_stwo_shared_fixed_words(const ss_stwo_cfg *cfg);
+size_t ss_stwo_shared_max_words(const ss_stwo_cfg *cfg);   /* fixed + 8 * n_queries * sum of the path lengths */
+/* counts[3+n_layers] for these positions; SS_ERR_ARG when one lies outside the LDE domain.  Pure. */
+int ss_stwo_shared_counts(const ss_stwo_cfg *cfg, const uint32_t *queries, uint32_t *counts);
+/* per-query record + the positions its prover drew -> shared record.  *words_out receives its size; written when it
+ * fits cap_words (SS_ERR_ARG otherwise).  Returns 0, or 1 = this proof has no shared form.  Pure.               */
+int ss_stwo_share_record(const ss_stwo_cfg *cfg, const uint32_t *record, const uint32_t *queries, uint32_t *shared_out,
+                         size_t cap_words, size_t *words_out);
+/* shared -> per-query record on the host (what the GPU does in ss_stwo_expand_shared_dev).  Returns 0 or
+ * SS_STATUS_MALFORMED (record_out zeroed).  Pure.                                                                */
+int ss_stwo_unshare_record(const ss_stwo_cfg *cfg, const uint32_t *shared, size_t words, uint32_t *record_out);
+
 /* ======================================================================= execution
  * One context per process and GPU (one process per GPU is the intended deployment).
  * Threads.  A context may be shared by threads.  Entry points that use the context's own scratch
@@ -168,6 +198,13 @@ void ss_ctx_destroy(ss_ctx *ctx);
  * point uses after uploading the raw records, so the host never re-tiles 170 KB proofs.    */
 int ss_stwo_pack_dev(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const uint32_t *records_dev,
                      uint32_t *batch_dev, void *stream);
+
+/* Shared records -> per-query records on the GPU (csrc/ss_shared.hip): shared_dev holds n shared records, record i
+ * at word offset offs_dev[i] with offs_dev[i + 1] - offs_dev[i] words (n + 1 offsets, device memory); records_dev
+ * receives n * ss_stwo_record_words words, outcome_dev[i] = 0 or SS_STATUS_MALFORMED (record i zeroed).
+ * Asynchronous on `stream`; feed records_dev to ss_stwo_pack_dev.                                                */
+int ss_stwo_expand_shared_dev(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const uint32_t *shared_dev,
+                              const uint64_t *offs_dev, uint32_t *records_dev, uint32_t *outcome_dev, void *stream);
 
 /* The same for stark101: records_dev holds n records of `shape` back to back, batch_dev receives
  * ss_s101_batch_words words (the permutation of ss_s101_pack).                                      */
@@ -211,6 +248,10 @@ int ss_s101_verify_records(ss_ctx *ctx, const ss_s101_shape *shape, size_t n,
                            const uint32_t *const *records, uint32_t *status_host);
 int ss_stwo_verify_records(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n,
                            const uint32_t *const *records, uint32_t *status_host);
+
+/* The same from shared records (shared[i] has words[i] words): fewer bytes on the host link, expanded behind it. */
+int ss_stwo_verify_shared_records(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const uint32_t *const *shared,
+                                  const size_t *words, uint32_t *status_host);
 
 /* ===================================================================== text ingestion
  * The reference's callers hand the verifier TEXT: proof.json (stwo: the schema read by

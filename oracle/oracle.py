@@ -21,7 +21,7 @@ MODE_LITERAL, MODE_FIXTURE = 0, 1
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (make).  Returns the library path."""
-    srcs = [os.path.join(HERE, f) for f in ("ss_oracle.c", "ss_oracle_batch.c", "ss_oracle.h")]
+    srcs = [os.path.join(HERE, f) for f in ("ss_oracle.c", "ss_oracle_batch.c", "ss_oracle_shared.c", "ss_oracle.h")]
     stale = (not os.path.exists(LIB_PATH)
              or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs))
     if force or stale:
@@ -190,6 +190,8 @@ def lib() -> C.CDLL:
     sig("so_stwo_verify_batch", None, C.POINTER(StwoCfg), C.POINTER(StwoProofC), C.c_size_t, i,
         u32p, i)
     sig("so_num_procs", i)
+    sig("so_shared_walk", u32, u32, u32, u32, u32p, u32p)
+    sig("so_shared_expand", i, u32, u32, u32, u32, u32p, C.c_size_t, u32p)
     _lib = L
     return L
 
@@ -365,6 +367,29 @@ def stwo_verify_batch(proofs: Sequence, mode: int = MODE_FIXTURE, threads: int =
     for idx in groups.values():
         out[idx] = StwoBatch([proofs[i] for i in idx]).verify(mode, threads)
     return out
+
+
+def shared_walk(lde_log: int, tree: int, queries: Sequence[int]):
+    """-> (plan[q][lvl], count): the first-use walk over the queries' paths of tree `tree` (0 trace, 1 cp, 2 + l FRI
+    layer l); ss_oracle_shared.c."""
+    ln = lde_log if tree < 2 else lde_log + 1 - tree
+    qs = np.ascontiguousarray(queries, dtype=np.uint32)
+    plan = np.zeros((len(qs), ln), dtype=np.uint32)
+    u32p = C.POINTER(C.c_uint32)
+    count = lib().so_shared_walk(lde_log, tree, len(qs), qs.ctypes.data_as(u32p), plan.ctypes.data_as(u32p))
+    return plan, int(count)
+
+
+def shared_expand(cfg, shared: np.ndarray):
+    """Shared record -> (outcome, per-query record) by the definitional walk (ss_oracle_shared.c)."""
+    N, L, Q, K = cfg.n_cols, cfg.lde_log, cfg.n_queries, cfg.n_layers
+    words = 24 + 4 * N + 64 + 8 * (K + 1) + 6 + Q * (N + 16 + 16 * L) + sum(Q * (4 + 8 * (L - 1 - l)) for l in range(K + 1)) \
+        + (K + 3) * Q
+    sh = np.ascontiguousarray(shared, dtype=np.uint32)
+    rec = np.zeros(words, dtype=np.uint32)
+    u32p = C.POINTER(C.c_uint32)
+    rc = lib().so_shared_expand(N, L, Q, K, sh.ctypes.data_as(u32p), sh.size, rec.ctypes.data_as(u32p))
+    return int(rc), rec
 
 
 def num_procs() -> int:

@@ -242,6 +242,14 @@ typedef struct {
 uint32_t so_stwo_verify(const so_stwo_cfg *cfg, const so_stwo_proof *p, int mode,
                         so_stwo_trace *tr);
 
+/* ----------------------------------------------------- shared records (ss_oracle_shared.c)
+ * The reference never deduplicates Merkle siblings (fri/queries.simf:41; generate_wit.py:36-42 splits per query).
+ * These two restate the DEFINITION of the product's shared-record order (first use in a walk over query 0, 1, ..
+ * leaf -> root) so that the closed form the GPU uses can be checked against it.                                   */
+uint32_t so_shared_walk(uint32_t lde_log, uint32_t tree, uint32_t n_queries, const uint32_t *queries, uint32_t *plan);
+int so_shared_expand(uint32_t n_cols, uint32_t lde_log, uint32_t n_queries, uint32_t n_layers, const uint32_t *shared,
+                     size_t words, uint32_t *record);
+
 #ifdef __cplusplus
 }
 #endif

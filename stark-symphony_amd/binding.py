@@ -63,6 +63,8 @@ EXPORTS = [
     "ss_s101_verify_records", "ss_stwo_verify_records", "ss_ctx_set_timing", "ss_ctx_collect_timing",
     "ss_selftest", "ss_stwo_write_text", "ss_stwo_text_is_canonical", "ss_stwo_read_texts",
     "ss_s101_write_text", "ss_s101_text_is_canonical", "ss_s101_pack_dev", "ss_s101_read_texts",
+    "ss_stwo_shared_fixed_words", "ss_stwo_shared_max_words", "ss_stwo_shared_counts", "ss_stwo_share_record",
+    "ss_stwo_unshare_record", "ss_stwo_expand_shared_dev", "ss_stwo_verify_shared_records",
 ]
 
 _lib = None
@@ -133,6 +135,13 @@ def lib() -> C.CDLL:
     sig("ss_stwo_text_is_canonical", C.c_int, cp, C.c_char_p, sz, C.c_int, vp)
     sig("ss_s101_write_text", sz, vp, C.c_int, C.c_int, vp, sz)
     sig("ss_s101_text_is_canonical", C.c_int, C.c_char_p, sz, C.c_int, vp)
+    sig("ss_stwo_shared_fixed_words", sz, cp)
+    sig("ss_stwo_shared_max_words", sz, cp)
+    sig("ss_stwo_shared_counts", C.c_int, cp, vp, vp)
+    sig("ss_stwo_share_record", C.c_int, cp, vp, vp, vp, sz, szp)
+    sig("ss_stwo_unshare_record", C.c_int, cp, vp, sz, vp)
+    sig("ss_stwo_expand_shared_dev", C.c_int, vp, cp, sz, vp, vp, vp, vp, vp)
+    sig("ss_stwo_verify_shared_records", C.c_int, vp, cp, sz, pp, szp, vp)
     _lib = L
     return L
 

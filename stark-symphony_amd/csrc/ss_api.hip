@@ -106,6 +106,7 @@ extern "C" void ss_ctx_destroy(ss_ctx *ctx)
     for (int i = 0; i < 2; i++) {
         if (ctx->hp.pinned[i]) (void)hipHostFree(ctx->hp.pinned[i]);
         if (ctx->hp.pinned_free[i]) (void)hipEventDestroy(ctx->hp.pinned_free[i]);
+        if (ctx->hp.shared_free[i]) (void)hipEventDestroy(ctx->hp.shared_free[i]);
     }
     for (auto &d : ctx->hp.dev)
         if (d) (void)hipFree(d);
@@ -564,7 +565,7 @@ extern "C" int ss_s101_pack_dev(ss_ctx *ctx, const ss_s101_shape *sh, size_t n, 
     return SS_OK;
 }
 
-static int hp_reserve(ss_ctx *ctx, int slot, size_t bytes)
+int ss::hp_reserve(ss_ctx *ctx, int slot, size_t bytes)
 {
     HostPath &hp = ctx->hp;
     if (hp.dev_bytes[slot] >= bytes) return SS_OK;
@@ -574,7 +575,7 @@ static int hp_reserve(ss_ctx *ctx, int slot, size_t bytes)
     return SS_OK;
 }
 
-static int hp_pinned(ss_ctx *ctx, size_t bytes)
+int ss::hp_pinned(ss_ctx *ctx, size_t bytes)
 {
     HostPath &hp = ctx->hp;
     if (!hp.stream) HIP_TRY(hipStreamCreateWithFlags(&hp.stream, hipStreamNonBlocking));

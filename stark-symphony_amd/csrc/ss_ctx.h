@@ -34,8 +34,9 @@ struct HostPath {
     void *pinned[2] = {nullptr, nullptr};
     size_t pinned_bytes = 0;
     hipEvent_t pinned_free[2] = {nullptr, nullptr};
-    void *dev[4] = {nullptr, nullptr, nullptr, nullptr};  // records, batch, ws, status
-    size_t dev_bytes[4] = {0, 0, 0, 0};
+    void *dev[7] = {};  // records, batch, ws, status; shared-record chunks (two in flight), their outcomes
+    size_t dev_bytes[7] = {};
+    hipEvent_t shared_free[2] = {nullptr, nullptr};  // the expansion that read shared chunk buffer b has run
     hipStream_t stream = nullptr;   // uploads
     hipStream_t vstream = nullptr;  // re-tiling and verification of the chunks already uploaded
 };
@@ -99,6 +100,11 @@ struct Timer {
     void begin();
     void end(const char *name);
 };
+
+int hp_reserve(ss_ctx *ctx, int slot, size_t bytes);  // grow-only device buffer `slot` of the host path (ss_api.hip)
+int hp_pinned(ss_ctx *ctx, size_t bytes);             // its two pinned staging buffers, streams and events
+int shared_expand_launch(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const uint32_t *shared_dev, const uint64_t *offs_dev,
+                         uint64_t capacity_stride, uint32_t *records_dev, uint32_t *outcome_dev, hipStream_t s);  // ss_shared.hip
 
 int grow(GrowBuf &b, size_t bytes, bool pinned);  // (re)allocates when too small; contents are not kept
 void release(GrowBuf &b);

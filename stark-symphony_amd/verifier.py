@@ -213,6 +213,47 @@ def stwo_record(p: StwoProof) -> np.ndarray:
     return np.ascontiguousarray(np.concatenate(parts), dtype=np.uint32)
 
 
+def stwo_shared_record(p: StwoProof, queries: "Sequence[int] | None" = None, mode: int = MODE_FIXTURE) -> np.ndarray:
+    """Proof -> SHARED record (include/ss_verify.h: every distinct Merkle sibling of a tree once + the query
+    positions as a hint; the reference repeats them per query, fri/queries.simf:41).  `queries` are the
+    positions the prover drew; without them the public transcript is replayed (formats.stwo_queries).
+    Raises ValueError for a proof that has no shared form (a path of another length, or two queries that
+    present different bytes for one node) -- such a proof travels as a per-query record."""
+    from .formats import stwo_queries
+    cs = stwo_cfg_struct(p.cfg, mode)
+    L = B.lib()
+    rec = stwo_record(p)
+    qs = np.ascontiguousarray(queries if queries is not None else stwo_queries(p), dtype=np.uint32)
+    if qs.size != p.cfg.n_queries:
+        raise ValueError("one position per query expected")
+    out = np.zeros(L.ss_stwo_shared_max_words(C.byref(cs)), dtype=np.uint32)
+    words = C.c_size_t(0)
+    rc = B.check(L.ss_stwo_share_record(C.byref(cs), rec.ctypes.data, qs.ctypes.data, out.ctypes.data, out.size,
+                                        C.byref(words)))
+    if rc:
+        raise ValueError("this proof has no shared form")
+    return out[:words.value].copy()
+
+
+def stwo_unshare_record(cfg: StwoConfig, shared: np.ndarray, mode: int = MODE_FIXTURE):
+    """Shared record -> (outcome, per-query record) on the host (ss_stwo_unshare_record): outcome 0 or
+    STATUS_MALFORMED.  The GPU does the same in ss_stwo_expand_shared_dev."""
+    cs = stwo_cfg_struct(cfg, mode)
+    L = B.lib()
+    sh = np.ascontiguousarray(shared, dtype=np.uint32)
+    rec = np.zeros(L.ss_stwo_record_words(C.byref(cs)), dtype=np.uint32)
+    return B.check(L.ss_stwo_unshare_record(C.byref(cs), sh.ctypes.data, sh.size, rec.ctypes.data)), rec
+
+
+def stwo_shared_counts(cfg: StwoConfig, queries: Sequence[int], mode: int = MODE_FIXTURE) -> np.ndarray:
+    """Distinct siblings per tree (trace, composition, FRI layer 0..) for these positions (ss_stwo_shared_counts)."""
+    cs = stwo_cfg_struct(cfg, mode)
+    qs = np.ascontiguousarray(queries, dtype=np.uint32)
+    out = np.zeros(cfg.n_layers + 3, dtype=np.uint32)
+    B.check(B.lib().ss_stwo_shared_counts(C.byref(cs), qs.ctypes.data, out.ctypes.data))
+    return out
+
+
 STATUS_CONFIG_MISMATCH = 1
 """Status of a proof whose shape / declared parameters are not the config the caller expects.  The
 reference fixes NUM_COLUMNS, LDE_LOG_SIZE, NUM_FRI_QUERIES, NUM_FRI_LAYERS and POW_TARGET_64 at
@@ -567,6 +608,45 @@ class Verifier:
         B.check(B.lib().ss_stwo_verify_records(self.ctx, C.byref(cs), len(records), _ptr_array(records),
                                                status.ctypes.data))
         return status
+
+    def verify_stwo_shared_records(self, cfg: StwoConfig, shared: Sequence[np.ndarray],
+                                   mode: int = MODE_FIXTURE) -> np.ndarray:
+        """Host-buffer path for SHARED records (ss_stwo_verify_shared_records): 9-21 % fewer bytes on the
+        link; each chunk is expanded to per-query records on the GPU (csrc/ss_shared.hip), re-tiled and
+        verified behind the next upload.  A record that is no shared record of `cfg` gets STATUS_MALFORMED."""
+        cs = stwo_cfg_struct(cfg, mode, self.stwo_flags)
+        if B.lib().ss_stwo_record_words(C.byref(cs)) == 0:
+            raise B.SsError(B.SS_ERR_ARG, "unsupported stwo config %r" % (cfg,))
+        for r in shared:
+            if r.dtype != np.uint32 or r.ndim != 1 or not r.flags["C_CONTIGUOUS"]:
+                raise ValueError("a shared record is a contiguous 1-d uint32 array")
+        if len(shared) == 0:
+            return np.empty(0, dtype=np.uint32)
+        status = np.full(len(shared), 0xFFFFFFFF, dtype=np.uint32)  # unwritten = REJECT
+        words = (C.c_size_t * len(shared))(*[int(r.size) for r in shared])
+        B.check(B.lib().ss_stwo_verify_shared_records(self.ctx, C.byref(cs), len(shared), _ptr_array(shared), words,
+                                                      status.ctypes.data))
+        return status
+
+    def expand_shared_on_device(self, cfg: StwoConfig, shared: Sequence[np.ndarray], mode: int = MODE_FIXTURE):
+        """The expansion kernel alone (ss_stwo_expand_shared_dev): -> (records uint32[n, W], outcome uint32[n])."""
+        torch = _torch()
+        cs = stwo_cfg_struct(cfg, mode, self.stwo_flags)
+        n = len(shared)
+        W = B.lib().ss_stwo_record_words(C.byref(cs))
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([r.size for r in shared])
+        flat = np.concatenate([np.ascontiguousarray(r, dtype=np.uint32) for r in shared] + [np.zeros(1, np.uint32)])
+        sh_dev = _to_dev(flat, self.device)
+        offs_dev = torch.from_numpy(offs.view(np.int64)).to(self.device)
+        rec_dev = torch.empty(n * W, dtype=torch.int32, device=self.device)
+        out_dev = torch.full((n,), -1, dtype=torch.int32, device=self.device)
+        B.check(B.lib().ss_stwo_expand_shared_dev(self.ctx, C.byref(cs), n, sh_dev.data_ptr(), offs_dev.data_ptr(),
+                                                  rec_dev.data_ptr(), out_dev.data_ptr(),
+                                                  int(torch.cuda.current_stream(self.device).cuda_stream)))
+        torch.cuda.synchronize(self.device)
+        return (rec_dev.cpu().numpy().view(np.uint32).reshape(n, W).copy(),
+                out_dev.cpu().numpy().view(np.uint32).copy())
 
     # -- text in, verdicts out (native readers, csrc/ss_ingest.cpp) --------------------------
     def _ingest(self, fn, head_args, items, fmt):

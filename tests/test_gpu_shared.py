@@ -1,0 +1,129 @@
+"""Shared records on the GPU (csrc/ss_shared.hip, ABI 2.2): the expansion kernel against the oracle's walk
+(oracle/ss_oracle_shared.c) and the host twin, and verdicts of shared records against the per-query records they
+stand for and against the oracle -- the reference's witness is one full path per query
+(stwo-verifier/src/fri/queries.simf:41, scripts/generate_wit.py:36-42), so "identical to the reference" means
+"identical to the per-query form".  Run with `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+from stark_symphony_amd import formats, records, verifier
+from oracle import oracle as O
+
+from test_shared_records import _random_queries, _random_record, fixtures, shared_mutants
+import stark_symphony_amd as ss
+
+pytestmark = pytest.mark.gpu
+SEED = 0x5EED2025
+
+
+@pytest.fixture(scope="module")
+def ver():
+    return verifier.Verifier(0)
+
+
+def test_expansion_kernel_equals_the_walk(ver):
+    """Random shapes and positions (uniform, clustered, all equal, neighbours): GPU expansion == oracle == host twin."""
+    rng = np.random.default_rng(SEED + 51)
+    for case in range(40):
+        L = int(rng.integers(3, 25))
+        K = int(rng.integers(0, L - 1))
+        Q = int(rng.choice([1, 2, 5, 16, 24, 32, 64]))
+        cfg = ss.StwoConfig(int(rng.choice([1, 3, 4, 9])), max(1, L - 1), L, Q, K, 5)
+        shared, want = [], []
+        for i in range(7):
+            qs = _random_queries(rng, L, Q, (case + i) % 4).astype(np.uint32)
+            p = _random_record(rng, cfg, qs)
+            shared.append(verifier.stwo_shared_record(p, qs))
+            want.append(verifier.stwo_record(p))
+        recs, outcome = ver.expand_shared_on_device(cfg, shared)
+        assert outcome.tolist() == [0] * 7, case
+        for i in range(7):
+            orc, orec = O.shared_expand(cfg, shared[i])
+            assert orc == 0 and np.array_equal(recs[i], orec) and np.array_equal(orec, want[i]), (case, i)
+
+
+def test_expansion_kernel_on_malformed_records(ver):
+    """Wrong hints, counts and sizes: outcome and record (zeroed when refused) equal the oracle's, record by record."""
+    rng = np.random.default_rng(SEED + 52)
+    for p in fixtures()[:4]:
+        sh = verifier.stwo_shared_record(p)
+        ms = [sh] + shared_mutants(p.cfg, sh, rng, 120) + [np.zeros(0, np.uint32), sh[:1].copy()]
+        recs, outcome = ver.expand_shared_on_device(p.cfg, ms)
+        refused = 0
+        for m, rec, out in zip(ms, recs, outcome):
+            orc, orec = O.shared_expand(p.cfg, m)
+            hrc, hrec = verifier.stwo_unshare_record(p.cfg, m)
+            assert int(out) == orc == hrc and np.array_equal(rec, orec) and np.array_equal(hrec, orec)
+            refused += orc != 0
+        assert outcome[0] == 0 and 30 < refused < 120
+
+
+@pytest.mark.parametrize("mode", [verifier.MODE_FIXTURE, verifier.MODE_LITERAL])
+def test_shared_records_verify_as_the_per_query_records(ver, mode):
+    """The six fixtures + 40 corruptions each that still have a shared form + wrong hints / counts / sizes:
+    status(shared record) == status(per-query record) == oracle, both modes."""
+    rng = np.random.default_rng(SEED + 53 + mode)
+    for base in fixtures():
+        cfg = base.cfg
+        qs = formats.stwo_queries(base)
+        proofs, shared = [base], [verifier.stwo_shared_record(base, qs)]
+        tries = 0
+        while len(proofs) < 41 and tries < 400:
+            tries += 1
+            p = formats.stwo_corrupt(base, rng)[0]
+            try:
+                s = verifier.stwo_shared_record(p, qs)   # the hint stays the honest prover's
+            except ValueError:
+                continue                                 # queries disagree about a node / ragged path: no shared form
+            proofs.append(p)
+            shared.append(s)
+        assert len(proofs) >= (41 if cfg.n_queries > 1 else 20), (cfg, len(proofs))
+        want = O.stwo_verify_batch(proofs, mode)
+        got_rec = ver.verify_stwo_records(cfg, [verifier.stwo_record(p) for p in proofs], mode)
+        got_sh = ver.verify_stwo_shared_records(cfg, shared, mode)
+        assert np.array_equal(got_rec, want) and np.array_equal(got_sh, want), cfg
+        assert (want == 0).sum() >= (1 if mode == verifier.MODE_FIXTURE else 0)
+        # structure mutants (hints, counts, sizes, bits anywhere -- a flipped node is seen by every query that shares
+        # it): whatever still expands is verified as the record it expands to; the rest is malformed
+        ms = shared_mutants(cfg, shared[0], rng, 64)
+        exp = []
+        for m in ms:
+            orc, orec = O.shared_expand(cfg, m)
+            exp.append(verifier.B.STATUS_MALFORMED if orc else
+                       int(O.stwo_verify_batch([records.stwo_from_record(cfg, orec)], mode)[0]))
+        got = ver.verify_stwo_shared_records(cfg, ms, mode)
+        assert got.tolist() == exp, cfg
+        assert len(set(exp)) >= 3
+
+
+def test_shared_records_across_chunks_and_sizes(ver):
+    """Several upload chunks (records of the 2^20 shape, > 64 MiB in total), a refused record in the middle of a
+    chunk, an over-long one, an empty one."""
+    import os
+    from conftest import GOLDEN
+    ps = records.load_stwo_npz(os.path.join(GOLDEN, "stwo_trace20.npz"))
+    rng = np.random.default_rng(SEED + 54)
+    distinct, want = [], []
+    for p in ps[:2]:
+        qs = formats.stwo_queries(p)
+        distinct.append(verifier.stwo_shared_record(p, qs))
+        want.append(0)
+        for _ in range(3):
+            while True:
+                c = formats.stwo_corrupt(p, rng)[0]
+                try:
+                    distinct.append(verifier.stwo_shared_record(c, qs))
+                    break
+                except ValueError:
+                    pass
+            want.append(int(O.stwo_verify_batch([c], O.MODE_FIXTURE)[0]))
+    n = 1400   # x 138 KB = 190 MB: the doubling first chunks and three full ones
+    idx = rng.integers(0, len(distinct), size=n)
+    batch = [distinct[i] for i in idx]
+    exp = [want[i] for i in idx]
+    for j, bad in ((5, distinct[0][:-8].copy()), (700, np.concatenate([distinct[0], np.zeros(1 << 18, np.uint32)])),
+                   (1399, np.zeros(0, np.uint32))):
+        batch[j] = bad
+        exp[j] = verifier.B.STATUS_MALFORMED
+    got = ver.verify_stwo_shared_records(ps[0].cfg, batch, verifier.MODE_FIXTURE)
+    assert got.tolist() == exp

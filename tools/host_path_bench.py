@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""PCIe-inclusive rate of the host-buffer entry point (records in host memory -> verdicts):
-ss_stwo_verify_records, timed around the single C call.  Not the metric of bench.py."""
+"""PCIe-inclusive rate of the host-buffer entry points (records in host memory -> verdicts):
+ss_stwo_verify_records and ss_stwo_verify_shared_records (every distinct sibling once, expanded on the GPU), timed
+around the single C call.  Not the metric of bench.py."""
 import ctypes as C
 import os
 import sys
@@ -27,3 +28,18 @@ for rep in range(3):
     assert (status == 0).all()
     print("host path: %d proofs in %.3f s = %.0f proofs/s, %.2f GB/s of records"
           % (n, dt, n / dt, n * recs[0].nbytes / dt / 1e9))
+
+from stark_symphony_amd import formats  # noqa: E402
+shared = [verifier.stwo_shared_record(p) for p in proofs]
+batch = [shared[i % len(shared)] for i in range(n)]
+sptrs = verifier._ptr_array(batch)
+words = (C.c_size_t * n)(*[int(r.size) for r in batch])
+total = sum(int(r.nbytes) for r in batch)
+for rep in range(3):
+    status[:] = 0xFFFFFFFF
+    t0 = time.perf_counter()
+    B.check(lib.ss_stwo_verify_shared_records(ver.ctx, C.byref(cfg), n, sptrs, words, status.ctypes.data))
+    dt = time.perf_counter() - t0
+    assert (status == 0).all()
+    print("shared records: %d proofs in %.3f s = %.0f proofs/s, %.2f GB/s on the link (%.1f %% of the per-query bytes)"
+          % (n, dt, n / dt, total / dt / 1e9, 100.0 * total / (n * recs[0].nbytes)))
