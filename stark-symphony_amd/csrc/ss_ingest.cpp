@@ -7,6 +7,7 @@
 // Every acceptance / rejection rule mirrors stark-symphony_amd/formats.py, which tests/test_ingest.py
 // holds this file against on the reference's own files, on random proofs and on malformed inputs.
 #include "ss_ingest.h"
+#include "ss_shared.h"
 
 #include <sched.h>
 
@@ -701,37 +702,21 @@ struct RecordMap {
 
 // The "shared paths" variant of proof.json (formats.shared_path_order): every distinct sibling of a tree once, in
 // the order a walk over query 0, 1, .. leaf -> root first needs it, plus a top-level "queries" member with the
-// positions.  expand_shared undoes the sharing for one tree: `nodes` = the tree's shared list, out = Q x len hashes.
-bool expand_shared(const Tree &t, uint32_t hw, const std::vector<uint32_t> &qpos, uint32_t shift, uint32_t len,
+// positions -- at most kMaxQueries of them (no verifier config has more; the bound keeps the plan small whatever the
+// text claims).  The order in closed form is ss_shared.h's; expand_shared undoes the sharing for tree `tree`:
+// the list must hold exactly the count the positions imply, out = Q x len hashes.
+bool expand_shared(const Tree &t, uint32_t hw, const SharedPlan &p, uint32_t tree, uint32_t Q, uint32_t L,
                    std::vector<U256> &out)
 {
-    const uint32_t Q = (uint32_t)qpos.size();
-    // plan[q][lvl] = index of (lvl, (idx >> lvl) ^ 1) in first-use order; at most Q distinct positions per level
-    std::vector<uint32_t> plan((size_t)Q * len), seen_pos((size_t)len * Q), seen_id((size_t)len * Q), seen_n(len, 0);
-    uint32_t count = 0;
-    for (uint32_t q = 0; q < Q; q++) {
-        const uint32_t idx = qpos[q] >> shift;
-        for (uint32_t lvl = 0; lvl < len; lvl++) {
-            const uint32_t pos = (idx >> lvl) ^ 1;
-            uint32_t id = ~0u;
-            for (uint32_t j = 0; j < seen_n[lvl]; j++)
-                if (seen_pos[(size_t)lvl * Q + j] == pos) { id = seen_id[(size_t)lvl * Q + j]; break; }
-            if (id == ~0u) {
-                id = count++;
-                seen_pos[(size_t)lvl * Q + seen_n[lvl]] = pos;
-                seen_id[(size_t)lvl * Q + seen_n[lvl]] = id;
-                seen_n[lvl]++;
-            }
-            plan[(size_t)q * len + lvl] = id;
-        }
-    }
+    const uint32_t len = shared_tree_len(L, tree), sh = shared_tree_shift(tree), count = p.base[tree][Q];
     if (!hw || !t.is_list(hw) || t.count(hw) != count) return false;
-    std::vector<U256> nodes(count);
+    std::vector<U256> nodes(count);  // <= kMaxQueries * kMaxList
     ListIter it(t, hw);
     for (uint32_t i = 0; i < count; i++)
         if (!it.hash(nodes[i].w)) return false;
     out.resize((size_t)Q * len);
-    for (size_t i = 0; i < out.size(); i++) out[i] = nodes[plan[i]];
+    for (uint32_t q = 0; q < Q; q++)
+        for (uint32_t lvl = 0; lvl < len; lvl++) out[(size_t)q * len + lvl] = nodes[p.base[tree][p.lead[q][sh + lvl]] + lvl];
     return true;
 }
 
@@ -804,16 +789,13 @@ ParseResult stwo_from_json(const ss_stwo_cfg &cfg, const Tree &t, uint32_t *rec)
     // ---- the shared-path variant names its query positions; the LDE size is the verifier's (paths have no ends there)
     const uint32_t qn = t.member(0, "queries");
     const bool shared = qn != 0;
-    std::vector<uint32_t> qpos;
+    uint32_t qpos[kMaxQueries];
     std::vector<U256> ex1, ex2;
     if (shared) {
-        if (!t.is_list(qn) || t.count(qn) != Q) return kMalformed;
+        if (Q > kMaxQueries || !t.is_list(qn) || t.count(qn) != Q) return kMalformed;
         ListIter it(t, qn);
-        for (uint32_t q = 0; q < Q; q++) {
-            if (!it.u32(v) || (v >> cfg.lde_log)) return kMalformed;
-            qpos.push_back(v);
-        }
-        if (!expand_shared(t, hw1, qpos, 0, cfg.lde_log, ex1) || !expand_shared(t, hw2, qpos, 0, cfg.lde_log, ex2)) return kMalformed;
+        for (uint32_t q = 0; q < Q; q++)
+            if (!it.u32(qpos[q]) || (qpos[q] >> cfg.lde_log)) return kMalformed;
     }
     if (!shared && (t.count(hw1) % Q || t.count(hw2) % Q)) return kMalformed;
     if (t.count(qv1) % Q || t.count(qv2) % Q) return kMalformed;
@@ -896,9 +878,14 @@ ParseResult stwo_from_json(const ss_stwo_cfg &cfg, const Tree &t, uint32_t *rec)
         }
         return true;
     };
+    SharedPlan plan;  // (K + 3 trees of the TEXT's shape over the verifier's LDE size: Q <= 64, K <= 31)
+    if (shared) {
+        if (K + 1 >= cfg.lde_log) return kMalformed;  // a FRI tree would have no levels left
+        shared_plan(shared_map(0, cfg.lde_log, Q, K), qpos, plan);  // (positions were range-checked above)
+        if (!expand_shared(t, hw1, plan, 0, Q, cfg.lde_log, ex1) || !expand_shared(t, hw2, plan, 1, Q, cfg.lde_log, ex2)) return kMalformed;
+    }
     if (!paths(hw1, shared ? &ex1 : nullptr, tlen, m.L, [&](uint32_t q) { return m.trace_path(r, q); }, 0)) return kMalformed;
     if (!paths(hw2, shared ? &ex2 : nullptr, clen, m.L, [&](uint32_t q) { return m.cp_path(r, q); }, 1)) return kMalformed;
-    if (shared && (K + 1 >= cfg.lde_log)) return kMalformed;  // a FRI tree would have no levels left
     uint32_t inner_c = inner ? t.first_child(inner) : 0;
     for (uint32_t l = 0; l <= K; l++) {
         const uint32_t layer = l == 0 ? first : t.next_child(inner_c);
@@ -908,7 +895,7 @@ ParseResult stwo_from_json(const ss_stwo_cfg &cfg, const Tree &t, uint32_t *rec)
         if (!w || !hw || !cm || !t.is_list(w) || !t.is_list(hw) || t.count(w) != Q) return kMalformed;
         std::vector<U256> exl;
         if (shared) {  // FRI layer l is indexed by query >> (l + 1) in a tree of depth lde_log - 1 - l
-            if (!expand_shared(t, hw, qpos, l + 1, cfg.lde_log - 1 - l, exl)) return kMalformed;
+            if (!expand_shared(t, hw, plan, 2 + l, Q, cfg.lde_log, exl)) return kMalformed;
         } else if (t.count(hw) % Q) {
             return kMalformed;
         }

@@ -75,4 +75,33 @@ SS_HD inline uint32_t shared_fresh(uint32_t s, uint32_t L, uint32_t t)
     return f < len ? f : len;
 }
 
+// The plan of one proof on the host (Q <= kMaxQueries): s(q), lead(q, a) and base_t(q) of the closed form above.
+struct SharedPlan {
+    uint32_t s[kMaxQueries];
+    uint8_t lead[kMaxQueries][32];
+    uint32_t base[kMaxList + 3][kMaxQueries + 1];  // base[t][Q] = count_t
+};
+
+// false: a position lies outside the LDE domain
+inline bool shared_plan(const SharedMap &m, const uint32_t *pos, SharedPlan &p)
+{
+    for (uint32_t q = 0; q < m.Q; q++) {
+        if (pos[q] >> m.L) return false;
+        uint32_t s = 32;
+        for (uint32_t a = 0; a < 32; a++) p.lead[q][a] = (uint8_t)q;
+        for (uint32_t e = q; e-- > 0;) {  // descending, so that the earliest query at a position wins
+            const uint32_t d = shared_bitlen(pos[q] ^ pos[e]);
+            if (d < s) s = d;
+            for (uint32_t a = d; a < 32; a++) p.lead[q][a] = (uint8_t)e;
+        }
+        p.s[q] = s;
+    }
+    for (uint32_t t = 0; t < m.K + 3; t++) {
+        uint32_t b = 0;
+        for (uint32_t q = 0; q < m.Q; q++) { p.base[t][q] = b; b += shared_fresh(p.s[q], m.L, t); }
+        p.base[t][m.Q] = b;
+    }
+    return true;
+}
+
 }  // namespace ss

@@ -35,34 +35,6 @@ struct PerQueryMap {
     }
 };
 
-struct SharedPlan {
-    uint32_t s[kMaxQueries];
-    uint8_t lead[kMaxQueries][32];
-    uint32_t base[kMaxList + 3][kMaxQueries + 1];  // base[t][Q] = count_t
-};
-
-// false: a position lies outside the LDE domain
-static bool shared_plan(const SharedMap &m, const uint32_t *pos, SharedPlan &p)
-{
-    for (uint32_t q = 0; q < m.Q; q++) {
-        if (pos[q] >> m.L) return false;
-        uint32_t s = 32;
-        for (uint32_t a = 0; a < 32; a++) p.lead[q][a] = (uint8_t)q;
-        for (uint32_t e = q; e-- > 0;) {  // descending, so that the earliest query at a position wins
-            const uint32_t d = shared_bitlen(pos[q] ^ pos[e]);
-            if (d < s) s = d;
-            for (uint32_t a = d; a < 32; a++) p.lead[q][a] = (uint8_t)e;
-        }
-        p.s[q] = s;
-    }
-    for (uint32_t t = 0; t < m.K + 3; t++) {
-        uint32_t b = 0;
-        for (uint32_t q = 0; q < m.Q; q++) { p.base[t][q] = b; b += shared_fresh(p.s[q], m.L, t); }
-        p.base[t][m.Q] = b;
-    }
-    return true;
-}
-
 }  // namespace ss
 
 extern "C" size_t ss_stwo_shared_fixed_words(const ss_stwo_cfg *c)

@@ -462,6 +462,9 @@ def _split(lst: Sequence[Any], n: int) -> List[Sequence[Any]]:
     return [lst[i * k:(i + 1) * k] for i in range(n)]
 
 
+MAX_SHARED_QUERIES = 64
+
+
 def shared_path_order(lde_log: int, n_layers: int, queries: Sequence[int]):
     """The "shared paths" variant of proof.json (what the reference notes it does not do,
     stwo-verifier/src/fri/queries.simf:41).  The per-query format repeats a sibling node for every query whose
@@ -498,6 +501,8 @@ def _expand_shared(data: dict, lde_log: int, Q: int) -> dict:
     """proof.json with "queries" and shared hash_witness lists -> the same object in the per-query form."""
     import copy
     queries = data["queries"]
+    if Q > MAX_SHARED_QUERIES:  # the format's own bound (the C ABI's n_queries limit): the plan stays small whatever a text claims
+        raise MalformedProof("shared-path proof: more than %d queries" % MAX_SHARED_QUERIES)
     if not isinstance(queries, list) or len(queries) != Q:
         raise MalformedProof("shared-path proof: one query position per query expected")
     qs = [_uint(q, 32) for q in queries]

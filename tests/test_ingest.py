@@ -295,8 +295,14 @@ def test_native_readers_under_address_and_ub_sanitizers(tmp_path):
                     "-I" + csrc, os.path.join(ROOT, "tests", "native", "ingest_fuzz.cpp"),
                     os.path.join(csrc, "ss_ingest.cpp"), "-o", exe, "-lpthread"], check=True)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
-    runs = [("production", [os.path.join(GOLDEN, "stwo_proof.json"), os.path.join(FORMATS, "stwo_proof.wit")], 400),
-            ("testing", [os.path.join(GOLDEN, "stwo_proof_test.json"), os.path.join(FORMATS, "stwo_proof_test.wit")], 1500),
+    shared = []  # the shared-path variant (expansion plan from untrusted positions) is part of the corpus
+    for name in ("stwo_proof.json", "stwo_proof_test.json"):
+        p = ss.stwo_from_json(json.load(open(os.path.join(GOLDEN, name))))
+        shared.append(str(tmp_path / ("shared_" + name)))
+        with open(shared[-1], "w") as f:
+            json.dump(ss.stwo_to_json(p, shared=True), f, separators=(",", ":"))
+    runs = [("production", [os.path.join(GOLDEN, "stwo_proof.json"), os.path.join(FORMATS, "stwo_proof.wit"), shared[0]], 400),
+            ("testing", [os.path.join(GOLDEN, "stwo_proof_test.json"), os.path.join(FORMATS, "stwo_proof_test.wit"), shared[1]], 1500),
             ("s101", [os.path.join(GOLDEN, "stark101_proof.json"), os.path.join(FORMATS, "stark101_proof.wit")], 600)]
     for profile, files, n in runs:
         r = subprocess.run([exe, "20261003", str(n), profile] + files, capture_output=True, text=True, env=env, timeout=900)

@@ -104,6 +104,34 @@ def test_wrong_hints_and_wrong_counts():
     assert verifier.parse_stwo_text(other, text)[0] == _python_outcome(text, other, "json")[0] != OK
 
 
+def test_attacker_sized_shared_texts_are_refused_quickly():
+    """the positions and their number come from the untrusted text.  The format allows at most 64
+    positions (the ABI's n_queries bound), so the plan is at most 64 x 64 x 31 steps whatever a text claims:
+    a text with half a million positions, and one with 64 positions and a hundred thousand hashes, are
+    malformed in milliseconds in both readers (the round-3 reader planned O(Q^2 len) before looking at the list)."""
+    import time
+    p = _fixtures()[0]
+    obj = ss.stwo_to_json(p, shared=True)
+    big = json.loads(json.dumps(obj))
+    big["queries"] = [5] * 500000
+    big["config"]["fri_config"]["n_queries"] = 500000
+    long_list = json.loads(json.dumps(obj))
+    long_list["decommitments"][1]["hash_witness"] = [[7] * 32] * 100000
+    q64 = json.loads(json.dumps(obj))
+    q64["queries"] = list(range(64))
+    q64["config"]["fri_config"]["n_queries"] = 64
+    q64["queried_values"][1] = [1] * (64 * p.cfg.n_cols)
+    q64["queried_values"][2] = [1] * (64 * 16)
+    for o in (big, long_list, q64):
+        text = json.dumps(o, separators=(",", ":")).encode()
+        t0 = time.perf_counter()
+        got = verifier.parse_stwo_text(p.cfg, text)[0]
+        dt = time.perf_counter() - t0
+        assert got == MALFORMED and dt < 0.5, (got, dt, len(text))
+        t0 = time.perf_counter()
+        assert _python_outcome(text, p.cfg, "json")[0] == MALFORMED and time.perf_counter() - t0 < 2.0
+
+
 def test_differential_fuzz_of_shared_texts():
     rnd = random.Random(20261006)
     p = _fixtures()[1]
