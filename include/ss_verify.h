@@ -268,6 +268,11 @@ int ss_stwo_verify_shared_records(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n,
 #define SS_TEXT_AUTO 0 /* sniff: a .wit is a JSON object with a COMMITMENTS / P_MT_ROOT member */
 #define SS_TEXT_JSON 1
 #define SS_TEXT_WIT 2
+/* The shared-path proof.json: proof.json with every DISTINCT Merkle sibling of a tree once (in the order of the shared
+ * record above) and a last member "queries" with the positions (formats.stwo_to_json(shared=True), `cli convert --to
+ * json-shared`; at most 64 positions).  The text entry points recognise it by that member under SS_TEXT_AUTO and
+ * SS_TEXT_JSON; the constant is for the writer / diagnostic calls that want that form explicitly.               */
+#define SS_TEXT_JSON_SHARED 3
 #define SS_STATUS_CONFIG_MISMATCH 1u
 #define SS_STATUS_MALFORMED 2u
 
@@ -317,8 +322,12 @@ int ss_s101_verify_files(ss_ctx *ctx, size_t n, const char *const *paths, int fm
  * pow_target that is no 2^(64-bits) - 1.  No GPU involved.                                           */
 size_t ss_stwo_write_text(const ss_stwo_cfg *cfg, const uint32_t *record, int fmt, int python_separators,
                           char *buf, size_t cap);
+/* Shared record -> the shared-path proof.json (SS_TEXT_JSON_SHARED), byte for byte what json.dumps prints for
+ * formats.stwo_to_json(proof, shared=True).  0 = `shared` is no shared record of the config.  No GPU involved. */
+size_t ss_stwo_write_shared_text(const ss_stwo_cfg *cfg, const uint32_t *shared, size_t words, int python_separators,
+                                 char *buf, size_t cap);
 /* Diagnostic: would ss_stwo_verify_texts read this text on the GPU (1) or hand it to the host reader (0)?
- * fmt is SS_TEXT_JSON or SS_TEXT_WIT.  Scalar statement of the GPU reader's rule (ss_text.h); when it
+ * fmt is SS_TEXT_JSON, SS_TEXT_WIT or SS_TEXT_JSON_SHARED (record_out: the per-query record it expands to).  Scalar statement of the GPU reader's rule (ss_text.h); when it
  * returns 1 and record_out is not NULL, record_out holds the record.  No GPU involved.              */
 int ss_stwo_text_is_canonical(const ss_stwo_cfg *cfg, const char *text, size_t len, int fmt, uint32_t *record_out);
 
@@ -329,7 +338,8 @@ int ss_stwo_text_is_canonical(const ss_stwo_cfg *cfg, const char *text, size_t l
 size_t ss_s101_write_text(const uint32_t *record, int fmt, int python_separators, char *buf, size_t cap);
 int ss_s101_text_is_canonical(const char *text, size_t len, int fmt, uint32_t *record_out);
 
-/* The GPU reader alone (diagnostic): n texts of format fmt (SS_TEXT_JSON / SS_TEXT_WIT) -> records_host
+/* The GPU reader alone (diagnostic): n texts of format fmt (SS_TEXT_JSON / SS_TEXT_WIT / SS_TEXT_JSON_SHARED: read
+ * into shared records and expanded, all on the GPU) -> records_host
  * (n * ss_stwo_record_words words) and outcome_host[i] = 0 (canonical: record i written by the GPU) or 1
  * (left to the host reader; record i unspecified).  Synchronous; outcome equals ss_stwo_text_is_canonical. */
 int ss_stwo_read_texts(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const char *const *texts, const size_t *lens,

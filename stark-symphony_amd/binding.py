@@ -49,7 +49,7 @@ class IngestStats(C.Structure):
                 ("host_parsed", C.c_uint32)]
 
 
-TEXT_AUTO, TEXT_JSON, TEXT_WIT = 0, 1, 2
+TEXT_AUTO, TEXT_JSON, TEXT_WIT, TEXT_JSON_SHARED = 0, 1, 2, 3
 STATUS_CONFIG_MISMATCH, STATUS_MALFORMED = 1, 2
 
 EXPORTS = [
@@ -64,7 +64,7 @@ EXPORTS = [
     "ss_selftest", "ss_stwo_write_text", "ss_stwo_text_is_canonical", "ss_stwo_read_texts",
     "ss_s101_write_text", "ss_s101_text_is_canonical", "ss_s101_pack_dev", "ss_s101_read_texts",
     "ss_stwo_shared_fixed_words", "ss_stwo_shared_max_words", "ss_stwo_shared_counts", "ss_stwo_share_record",
-    "ss_stwo_unshare_record", "ss_stwo_expand_shared_dev", "ss_stwo_verify_shared_records",
+    "ss_stwo_unshare_record", "ss_stwo_expand_shared_dev", "ss_stwo_verify_shared_records", "ss_stwo_write_shared_text",
 ]
 
 _lib = None
@@ -142,6 +142,7 @@ def lib() -> C.CDLL:
     sig("ss_stwo_unshare_record", C.c_int, cp, vp, sz, vp)
     sig("ss_stwo_expand_shared_dev", C.c_int, vp, cp, sz, vp, vp, vp, vp, vp)
     sig("ss_stwo_verify_shared_records", C.c_int, vp, cp, sz, pp, szp, vp)
+    sig("ss_stwo_write_shared_text", sz, cp, vp, sz, C.c_int, vp, sz)
     _lib = L
     return L
 

@@ -732,9 +732,23 @@ extern "C" size_t ss_stwo_write_text(const ss_stwo_cfg *c, const uint32_t *recor
     return out.size();
 }
 
+extern "C" size_t ss_stwo_write_shared_text(const ss_stwo_cfg *c, const uint32_t *shared, size_t words, int python_separators,
+                                            char *buf, size_t cap)
+{
+    if (!cfg_ok(c) || !shared) { set_err(SS_ERR_ARG, "bad argument"); return 0; }
+    std::string out;
+    if (!stwo_write_json_shared(*c, shared, words, python_separators ? kStylePython : kStyleCompact, out)) {
+        set_err(SS_ERR_ARG, "not a shared record of this config (or a pow_target no proof.json can declare)");
+        return 0;
+    }
+    if (buf && out.size() <= cap) memcpy(buf, out.data(), out.size());
+    return out.size();
+}
+
 extern "C" int ss_stwo_text_is_canonical(const ss_stwo_cfg *c, const char *text, size_t len, int fmt, uint32_t *record_out)
 {
-    if (!cfg_ok(c) || !text || (fmt != SS_TEXT_JSON && fmt != SS_TEXT_WIT)) return set_err(SS_ERR_ARG, "bad argument");
+    if (!cfg_ok(c) || !text || (fmt != SS_TEXT_JSON && fmt != SS_TEXT_WIT && fmt != SS_TEXT_JSON_SHARED))
+        return set_err(SS_ERR_ARG, "bad argument");
     // the template of the last (config, format) asked about is kept per thread: building one walks the whole text
     static thread_local TextTemplateHost h;
     static thread_local ss_stwo_cfg h_cfg;
@@ -747,7 +761,8 @@ extern "C" int ss_stwo_text_is_canonical(const ss_stwo_cfg *c, const char *text,
     if (!h.ok) return 0;
     std::vector<uint32_t> scratch;
     uint32_t *rec = record_out;
-    if (!rec) { scratch.resize(h.record_words); rec = scratch.data(); }
+    if (!rec) { scratch.resize(std::max<size_t>(h.record_words, ss_stwo_record_words(c))); rec = scratch.data(); }
+    if (fmt == SS_TEXT_JSON_SHARED) return shared_text_scan_reference(*c, h, text, len, rec) ? 1 : 0;
     return text_scan_reference(h.view(), text, len, rec) ? 1 : 0;
 }
 

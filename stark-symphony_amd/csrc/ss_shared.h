@@ -104,4 +104,7 @@ inline bool shared_plan(const SharedMap &m, const uint32_t *pos, SharedPlan &p)
     return true;
 }
 
+// shared record (compact, or "capacity" form: tree t's nodes at nodes + 8 Q sum_{t' < t} len_t') -> per-query record
+void shared_expand_host(const SharedMap &m, const SharedPlan &p, const uint32_t *shared, bool capacity, uint32_t *record);
+
 }  // namespace ss

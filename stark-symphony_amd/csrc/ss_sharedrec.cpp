@@ -101,23 +101,12 @@ extern "C" int ss_stwo_share_record(const ss_stwo_cfg *c, const uint32_t *rec, c
     return 0;
 }
 
-extern "C" int ss_stwo_unshare_record(const ss_stwo_cfg *c, const uint32_t *sh_rec, size_t words, uint32_t *rec)
+// shared record (compact, or capacity form: tree t's nodes at a fixed base with room for Q * len_t) -> per-query record
+void ss::shared_expand_host(const SharedMap &m, const SharedPlan &p, const uint32_t *sh_rec, bool capacity, uint32_t *rec)
 {
-    if (!cfg_ok(c)) return set_err(SS_ERR_ARG, "unsupported stwo config");
-    if (!sh_rec || !rec) return set_err(SS_ERR_ARG, "null argument");
-    const uint32_t N = c->n_cols, L = c->lde_log, Q = c->n_queries, K = c->n_layers;
-    const SharedMap m = shared_map(N, L, Q, K);
+    const uint32_t N = m.N, L = m.L, Q = m.Q, K = m.K;
     const PerQueryMap r(N, L, Q, K);
     memset(rec, 0, (size_t)r.words * 4);
-    if (words < m.nodes) return (int)SS_STATUS_MALFORMED;
-    SharedPlan p;
-    if (!shared_plan(m, sh_rec + m.qry, p)) return (int)SS_STATUS_MALFORMED;
-    size_t total = m.nodes;
-    for (uint32_t t = 0; t < K + 3; t++) {
-        if (sh_rec[m.cnt + t] != p.base[t][Q]) return (int)SS_STATUS_MALFORMED;
-        total += 8 * (size_t)p.base[t][Q];
-    }
-    if (words != total) return (int)SS_STATUS_MALFORMED;
     memcpy(rec, sh_rec, (size_t)m.head * 4);
     for (uint32_t q = 0; q < Q; q++) memcpy(rec + r.head + q * r.qstride, sh_rec + m.vals + q * (N + kCp), (size_t)(N + kCp) * 4);
     for (uint32_t l = 0; l <= K; l++)
@@ -131,7 +120,26 @@ extern "C" int ss_stwo_unshare_record(const ss_stwo_cfg *c, const uint32_t *sh_r
                 memcpy(rec + r.path(L, N, t, q, lvl), node + 8 * (size_t)(p.base[t][p.lead[q][sh + lvl]] + lvl), 32);
             rec[r.tbase + t * Q + q] = len;
         }
-        node += 8 * (size_t)p.base[t][Q];
+        node += 8 * (size_t)(capacity ? Q * len : p.base[t][Q]);
     }
+}
+
+extern "C" int ss_stwo_unshare_record(const ss_stwo_cfg *c, const uint32_t *sh_rec, size_t words, uint32_t *rec)
+{
+    if (!cfg_ok(c)) return set_err(SS_ERR_ARG, "unsupported stwo config");
+    if (!sh_rec || !rec) return set_err(SS_ERR_ARG, "null argument");
+    const uint32_t N = c->n_cols, L = c->lde_log, Q = c->n_queries, K = c->n_layers;
+    const SharedMap m = shared_map(N, L, Q, K);
+    memset(rec, 0, ss_stwo_record_words(c) * 4);
+    if (words < m.nodes) return (int)SS_STATUS_MALFORMED;
+    SharedPlan p;
+    if (!shared_plan(m, sh_rec + m.qry, p)) return (int)SS_STATUS_MALFORMED;
+    size_t total = m.nodes;
+    for (uint32_t t = 0; t < K + 3; t++) {
+        if (sh_rec[m.cnt + t] != p.base[t][Q]) return (int)SS_STATUS_MALFORMED;
+        total += 8 * (size_t)p.base[t][Q];
+    }
+    if (words != total) return (int)SS_STATUS_MALFORMED;
+    shared_expand_host(m, p, sh_rec, false, rec);
     return 0;
 }

@@ -5,6 +5,7 @@
 #include <cstring>
 
 #include "ss_layout.h"
+#include "ss_shared.h"
 
 namespace ss {
 namespace {
@@ -33,6 +34,46 @@ struct Rec {
     uint32_t trace_path(uint32_t q) const { return cp_vals(q) + kCp; }
     uint32_t cp_path(uint32_t q) const { return trace_path(q) + 8 * L; }
     uint32_t fri_wit(uint32_t l, uint32_t q) const { return fbase + foff[l] + q * (4 + 8 * (L - 1 - l)); }
+    // the hash_witness list of tree t (0 trace, 1 composition, 2 + l FRI layer l): one full path per query
+    bool shared() const { return false; }
+    uint32_t tree_len(uint32_t t) const { return t < 2 ? L : L + 1 - t; }
+    uint32_t n_entries(uint32_t t) const { return Q * tree_len(t); }
+    uint32_t entry(uint32_t t, uint32_t e) const
+    {
+        const uint32_t len = tree_len(t), q = e / len, l = e - q * len;
+        return (t == 0 ? trace_path(q) : t == 1 ? cp_path(q) : fri_wit(t - 2, q) + 4) + 8 * l;
+    }
+    uint32_t query(uint32_t) const { return 0; }
+};
+
+// word offsets of a SHARED record (include/ss_verify.h, csrc/ss_shared.h): the same members, every distinct sibling once
+struct SRec {
+    uint32_t N, L, Q, K;
+    SharedMap m;
+    uint32_t count[kMaxTrees], node0[kMaxTrees];
+    // capacity = true: the form the GPU reader writes (full-length lists, tree t's nodes at a fixed base)
+    SRec(const ss_stwo_cfg &c, const uint32_t *counts) : N(c.n_cols), L(c.lde_log), Q(c.n_queries), K(c.n_layers)
+    {
+        m = shared_map(N, L, Q, K);
+        uint32_t o = m.nodes;
+        for (uint32_t t = 0; t < K + 3; t++) {
+            count[t] = counts ? counts[t] : Q * shared_tree_len(L, t);
+            node0[t] = o;
+            o += 8 * count[t];
+        }
+    }
+    uint32_t oods_trace() const { return 24; }
+    uint32_t oods_cp() const { return 24 + 4 * N; }
+    uint32_t fri_root(uint32_t l) const { return 24 + 4 * N + 64 + 8 * l; }
+    uint32_t last() const { return fri_root(K + 1); }
+    uint32_t nonce() const { return last() + 4; }
+    uint32_t trace_vals(uint32_t q) const { return m.vals + q * (N + kCp); }
+    uint32_t cp_vals(uint32_t q) const { return trace_vals(q) + N; }
+    uint32_t fri_wit(uint32_t l, uint32_t q) const { return m.wit + (l * Q + q) * 4; }
+    bool shared() const { return true; }
+    uint32_t n_entries(uint32_t t) const { return count[t]; }
+    uint32_t entry(uint32_t t, uint32_t e) const { return node0[t] + 8 * e; }
+    uint32_t query(uint32_t q) const { return m.qry + q; }
 };
 
 bool pow_bits_of(uint64_t target, uint32_t &bits)
@@ -67,6 +108,7 @@ struct TextSink {
             for (int s = 28; s >= 0; s -= 4) out.push_back(d[(rec[w + j] >> s) & 15]);
     }
     void cst(uint32_t v) { dec(v); }
+    void list_begin(uint32_t) {}
     void dec256(uint32_t w)  // 8 words, most significant first, as a decimal integer
     {
         uint32_t limb[8];
@@ -94,6 +136,8 @@ struct SlotSink {
     std::string &out;
     std::vector<TextSlot> &slots;
     std::vector<uint32_t> &at;  // byte offset of every number in `out`
+    uint32_t list_at[kMaxTrees] = {}, list_tok[kMaxTrees] = {};  // where the first entry of a hash_witness list starts
+    void list_begin(uint32_t t) { list_at[t] = (uint32_t)out.size(); list_tok[t] = (uint32_t)slots.size(); }
     void lit(const char *s) { out += s; }
     void num(uint32_t dst, uint32_t kind, const char *sample)
     {
@@ -111,10 +155,9 @@ struct SlotSink {
 
 // ------------------------------------------------------------------------------ proof.json (format C)
 // formats.stwo_to_json: the member order of tests/data/proof.json.
-template <class S>
-void json_text(const ss_stwo_cfg &cfg, uint32_t pow_bits, TextStyle style, S &s)
+template <class S, class M>
+void json_text(const ss_stwo_cfg &cfg, const M &m, uint32_t pow_bits, TextStyle style, S &s)
 {
-    const Rec m(cfg);
     const char *cm = style == kStylePython ? ", " : ",", *co = style == kStylePython ? ": " : ":";
     auto key = [&](const char *k) { s.lit("\""); s.lit(k); s.lit("\""); s.lit(co); };
     auto hash_bytes = [&](uint32_t w) {  // a hash as a list of its 32 byte values
@@ -126,10 +169,10 @@ void json_text(const ss_stwo_cfg &cfg, uint32_t pow_bits, TextStyle style, S &s)
         s.lit("[["); s.u32(w); s.lit(cm); s.u32(w + 1); s.lit("]"); s.lit(cm);
         s.lit("["); s.u32(w + 2); s.lit(cm); s.u32(w + 3); s.lit("]]");
     };
-    auto hash_witness = [&](auto path_of, uint32_t len) {  // concatenated over the queries
+    auto hash_witness = [&](uint32_t tree) {  // concatenated over the queries (or, shared: every distinct sibling once)
         key("hash_witness"); s.lit("[");
-        for (uint32_t q = 0, first = 1; q < m.Q; q++)
-            for (uint32_t l = 0; l < len; l++, first = 0) { if (!first) s.lit(cm); hash_bytes(path_of(q) + 8 * l); }
+        s.list_begin(tree);
+        for (uint32_t e = 0, n = m.n_entries(tree); e < n; e++) { if (e) s.lit(cm); hash_bytes(m.entry(tree, e)); }
         s.lit("]"); s.lit(cm); key("column_witness"); s.lit("[]");
     };
     s.lit("{"); key("config"); s.lit("{"); key("pow_bits"); s.cst(pow_bits); s.lit(cm); key("fri_config"); s.lit("{");
@@ -146,8 +189,8 @@ void json_text(const ss_stwo_cfg &cfg, uint32_t pow_bits, TextStyle style, S &s)
     for (uint32_t k = 0; k < kCp; k++) { if (k) s.lit(cm); s.lit("["); qm31(m.oods_cp() + 4 * k); s.lit("]"); }
     s.lit("]]"); s.lit(cm);
     key("decommitments"); s.lit("[{"); key("hash_witness"); s.lit("[]"); s.lit(cm); key("column_witness"); s.lit("[]}"); s.lit(cm);
-    s.lit("{"); hash_witness([&](uint32_t q) { return m.trace_path(q); }, m.L); s.lit("}"); s.lit(cm);
-    s.lit("{"); hash_witness([&](uint32_t q) { return m.cp_path(q); }, m.L); s.lit("}]"); s.lit(cm);
+    s.lit("{"); hash_witness(0); s.lit("}"); s.lit(cm);
+    s.lit("{"); hash_witness(1); s.lit("}]"); s.lit(cm);
     key("queried_values"); s.lit("[[]"); s.lit(cm); s.lit("[");
     for (uint32_t q = 0; q < m.Q; q++)
         for (uint32_t k = 0; k < m.N; k++) { if (q | k) s.lit(cm); s.u32(m.trace_vals(q) + k); }
@@ -160,13 +203,19 @@ void json_text(const ss_stwo_cfg &cfg, uint32_t pow_bits, TextStyle style, S &s)
         s.lit("{"); key("fri_witness"); s.lit("[");
         for (uint32_t q = 0; q < m.Q; q++) { if (q) s.lit(cm); qm31(m.fri_wit(l, q)); }
         s.lit("]"); s.lit(cm); key("decommitment"); s.lit("{");
-        hash_witness([&](uint32_t q) { return m.fri_wit(l, q) + 4; }, m.L - 1 - l);
+        hash_witness(2 + l);
         s.lit("}"); s.lit(cm); key("commitment"); hash_bytes(m.fri_root(l)); s.lit("}");
     };
     key("fri_proof"); s.lit("{"); key("first_layer"); layer(0); s.lit(cm); key("inner_layers"); s.lit("[");
     for (uint32_t l = 1; l <= m.K; l++) { if (l > 1) s.lit(cm); layer(l); }
     s.lit("]"); s.lit(cm); key("last_layer_poly"); s.lit("{"); key("coeffs"); s.lit("["); qm31(m.last()); s.lit("]"); s.lit(cm);
-    key("log_size"); s.cst(0); s.lit("}}}");
+    key("log_size"); s.cst(0); s.lit("}}");
+    if (m.shared()) {  // formats.stwo_to_json(shared=True): the positions, last member
+        s.lit(cm); key("queries"); s.lit("[");
+        for (uint32_t q = 0; q < m.Q; q++) { if (q) s.lit(cm); s.u32(m.query(q)); }
+        s.lit("]");
+    }
+    s.lit("}");
 }
 
 // -------------------------------------------------------------------------------- proof.wit (format D)
@@ -375,7 +424,27 @@ bool stwo_write_json(const ss_stwo_cfg &cfg, const uint32_t *record, TextStyle s
     out.clear();
     if (!cfg_writable(cfg) || !pow_bits_of(cfg.pow_target, bits) || !uniform_paths(cfg, record)) return false;
     TextSink s{out, record};
-    json_text(cfg, bits, style, s);
+    json_text(cfg, Rec(cfg), bits, style, s);
+    return true;
+}
+
+bool stwo_write_json_shared(const ss_stwo_cfg &cfg, const uint32_t *shared, size_t words, TextStyle style, std::string &out)
+{
+    uint32_t bits;
+    out.clear();
+    if (!cfg_writable(cfg) || !pow_bits_of(cfg.pow_target, bits) || !shared) return false;
+    const SharedMap m = shared_map(cfg.n_cols, cfg.lde_log, cfg.n_queries, cfg.n_layers);
+    if (words < m.nodes) return false;
+    SharedPlan plan;
+    if (!shared_plan(m, shared + m.qry, plan)) return false;
+    size_t total = m.nodes;
+    for (uint32_t t = 0; t < m.K + 3; t++) {
+        if (shared[m.cnt + t] != plan.base[t][m.Q]) return false;
+        total += 8 * (size_t)plan.base[t][m.Q];
+    }
+    if (total != words) return false;
+    TextSink s{out, shared};
+    json_text(cfg, SRec(cfg, shared + m.cnt), bits, style, s);
     return true;
 }
 
@@ -388,7 +457,8 @@ bool stwo_write_wit(const ss_stwo_cfg &cfg, const uint32_t *record, std::string 
     return true;
 }
 
-static bool skeleton_of(const std::string &sample, const std::vector<uint32_t> &at, TextTemplateHost &out);
+static bool skeleton_of(const std::string &sample, const std::vector<uint32_t> &at, TextTemplateHost &out,
+                        const std::vector<uint32_t> *marks = nullptr, std::vector<uint32_t> *mark_skel = nullptr);
 
 bool s101_write_json(const uint32_t *record, TextStyle style, std::string &out)
 {
@@ -423,12 +493,28 @@ void stwo_build_template(const ss_stwo_cfg &cfg, int fmt, TextTemplateHost &out)
 {
     out = TextTemplateHost();
     uint32_t bits = 0;
-    if (!cfg_writable(cfg) || (fmt != SS_TEXT_JSON && fmt != SS_TEXT_WIT)) return;
-    if (fmt == SS_TEXT_JSON && !pow_bits_of(cfg.pow_target, bits)) return;  // no proof.json can declare this target
+    if (!cfg_writable(cfg) || (fmt != SS_TEXT_JSON && fmt != SS_TEXT_WIT && fmt != SS_TEXT_JSON_SHARED)) return;
+    if (fmt != SS_TEXT_WIT && !pow_bits_of(cfg.pow_target, bits)) return;  // no proof.json can declare this target
     std::string sample;
     std::vector<uint32_t> at;
     SlotSink s{sample, out.slots, at};
-    if (fmt == SS_TEXT_JSON) json_text(cfg, bits, kStyleCompact, s);
+    if (fmt == SS_TEXT_JSON_SHARED) {
+        // the full-length text over a capacity-form shared record; where its lists start, in skeleton coordinates
+        const SRec sm(cfg, nullptr);
+        json_text(cfg, sm, bits, kStyleCompact, s);
+        std::vector<uint32_t> marks(s.list_at, s.list_at + sm.K + 3), mark_skel;
+        if (!skeleton_of(sample, at, out, &marks, &mark_skel)) { out = TextTemplateHost(); return; }
+        SharedTextInfo &I = out.sinfo;
+        I.n_trees = sm.K + 3; I.Q = sm.Q; I.L = sm.L; I.K = sm.K;
+        I.entry_toks = 32;
+        I.entry_skel = 32 + 31 + 2 + 1;
+        for (uint32_t t = 0; t < I.n_trees; t++) { I.S[t] = mark_skel[t]; I.T[t] = s.list_tok[t]; I.n[t] = sm.count[t]; }
+        out.record_words = sm.m.nodes + 8 * sm.m.max_nodes;
+        out.tbase = 0;
+        out.ok = true;
+        return;
+    }
+    if (fmt == SS_TEXT_JSON) json_text(cfg, Rec(cfg), bits, kStyleCompact, s);
     else wit_text(cfg, s);
     if (!skeleton_of(sample, at, out)) { out = TextTemplateHost(); return; }
     const Rec m(cfg);
@@ -455,12 +541,15 @@ void s101_build_template(int fmt, TextTemplateHost &out)
 }
 
 // the skeleton of the sample text, by the tokenizer itself; its numbers must be exactly the sink's
-bool skeleton_of(const std::string &sample, const std::vector<uint32_t> &at, TextTemplateHost &out)
+// (marks: ascending sample offsets whose skeleton positions the caller wants)
+bool skeleton_of(const std::string &sample, const std::vector<uint32_t> &at, TextTemplateHost &out,
+                 const std::vector<uint32_t> *marks, std::vector<uint32_t> *mark_skel)
 {
     uint32_t run = kRunNone, in_str = 0;
-    size_t k = 0;
+    size_t k = 0, mk = 0;
     bool good = true;
     for (size_t i = 0; i < sample.size() && good; i++) {
+        while (marks && mk < marks->size() && (*marks)[mk] == i) { mark_skel->push_back((uint32_t)out.skel.size()); mk++; }
         const uint32_t c = (unsigned char)sample[i];
         if (txt_is_bad(c)) { good = false; break; }
         const uint32_t r = scan_byte(c, run, in_str);
@@ -553,6 +642,49 @@ bool place_number(const TextSlot &sl, const unsigned char *body, size_t n, uint3
 }
 
 }  // namespace
+
+bool shared_text_scan_reference(const ss_stwo_cfg &cfg, const TextTemplateHost &th, const char *text, size_t len, uint32_t *record)
+{
+    if (!th.ok) return false;
+    const TextTemplate t = th.view();
+    const SharedTextInfo &I = th.sinfo;
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(text);
+    // the positions, from the last KiB; what they imply
+    TextHint h;
+    const uint32_t tail = len < 1024 ? (uint32_t)len : 1024;
+    if (!shared_text_hint(p + (len - tail), tail, I.Q, h.pos)) return false;
+    const SharedMap m = shared_map(cfg.n_cols, cfg.lde_log, cfg.n_queries, cfg.n_layers);
+    SharedPlan plan;
+    if (!shared_plan(m, h.pos, plan)) return false;
+    uint32_t counts[kMaxTrees];
+    for (uint32_t k = 0; k < I.n_trees; k++) counts[k] = plan.base[k][I.Q];
+    shared_text_gaps(I, counts, t.skel_len, t.n_slots, h.g);
+    // the scan of text_scan_reference through the gap maps, into a capacity-form shared record
+    std::vector<uint32_t> cap(t.record_words, 0);
+    uint32_t run = kRunNone, in_str = 0, sk = 0, tok = 0;
+    for (size_t i = 0; i < len; i++) {
+        const uint32_t c = p[i];
+        if (txt_is_bad(c)) return false;
+        const uint32_t r = scan_byte(c, run, in_str);
+        if (r & 2) {
+            if (sk >= h.g.skel_len || tok >= h.g.n_slots || t.skel[gap_map(h.g.G, h.g.D, I.n_trees, sk)] != kSkelMark) return false;
+            sk++;
+            size_t e = i;
+            while (e < len && e - i <= kMaxTokenBytes && txt_is_alnum(p[e])) e++;
+            if (!place_number(t.slots[gap_map(h.g.Gk, h.g.Dk, I.n_trees, tok)], p + i, e - i, cap.data())) return false;
+            tok++;
+        }
+        if (r & 1) {
+            if (sk >= h.g.skel_len || t.skel[gap_map(h.g.G, h.g.D, I.n_trees, sk)] != c) return false;
+            sk++;
+        }
+    }
+    if (sk != h.g.skel_len || tok != h.g.n_slots || in_str) return false;
+    for (uint32_t q = 0; q < I.Q; q++)
+        if (cap[m.qry + q] != h.pos[q]) return false;
+    shared_expand_host(m, plan, cap.data(), true, record);
+    return true;
+}
 
 bool text_scan_reference(const TextTemplate &t, const char *text, size_t len, uint32_t *rec)
 {

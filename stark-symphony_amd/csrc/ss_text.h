@@ -97,6 +97,78 @@ struct TextTemplate {
 
 constexpr uint32_t kSkelSlack = 4096;  // zero bytes after the skeleton
 
+// ---- shared-path proof.json (every distinct Merkle sibling of a tree once + a "queries" member: formats.stwo_to_json(shared=True))
+// Such a text has no fixed skeleton: the K + 3 hash_witness lists hold count_t entries, and the counts follow from the
+// query positions the text itself names.  But every entry of a list looks the same, so the text's skeleton is the
+// skeleton of the FULL-LENGTH text (every list with its Q * len_t entries) with K + 3 runs of whole entries cut out,
+// and the k-th number lands where the (k + numbers cut before it)-th number of the full-length text lands.  The
+// template of format 3 is that full-length text, its slots pointing into a shared record in "capacity" form (tree t's
+// nodes at a fixed base, room for Q * len_t of them: csrc/ss_shared.h); SharedTextInfo says where the lists sit in it.
+constexpr uint32_t kMaxTrees = 34;  // kMaxList + 3 >= K + 3
+struct SharedTextInfo {
+    uint32_t n_trees, Q, L, K;
+    uint32_t entry_skel;        // skeleton bytes from one entry of a hash list to the next ("[" 32 markers, 31 commas "]" ",")
+    uint32_t entry_toks;        // numbers per entry (32)
+    uint32_t S[kMaxTrees];      // skeleton position of the first entry of tree t's list in the full-length text
+    uint32_t T[kMaxTrees];      // index of its first number
+    uint32_t n[kMaxTrees];      // entries of the full-length list (Q * len_t)
+};
+// What the counts of one text cut out, in the text's own (shared) coordinates: a skeleton position p >= G[t] (and below
+// the next gap) is position p + D[t] of the full-length skeleton; number k >= Gk[t] is number k + Dk[t].
+struct TextGaps {
+    uint32_t skel_len, n_slots;  // totals of this text
+    uint32_t G[kMaxTrees], D[kMaxTrees], Gk[kMaxTrees], Dk[kMaxTrees];
+};
+struct TextHint {               // per text of format 3, left by text_hint_kernel
+    TextGaps g;
+    uint32_t pos[64];           // the positions read from the text's tail (compared with what the place kernel stores)
+};
+
+SS_HD inline void shared_text_gaps(const SharedTextInfo &I, const uint32_t *counts, uint32_t full_skel, uint32_t full_slots,
+                                   TextGaps &g)
+{
+    uint32_t d = 0, dk = 0;
+    for (uint32_t t = 0; t < I.n_trees; t++) {
+        const uint32_t cut = I.n[t] - counts[t];
+        g.G[t] = I.S[t] + counts[t] * I.entry_skel - 1 - d;
+        g.Gk[t] = I.T[t] + counts[t] * I.entry_toks - dk;
+        d += cut * I.entry_skel;
+        dk += cut * I.entry_toks;
+        g.D[t] = d;
+        g.Dk[t] = dk;
+    }
+    g.skel_len = full_skel - d;
+    g.n_slots = full_slots - dk;
+}
+SS_HD inline uint32_t gap_map(const uint32_t *G, const uint32_t *D, uint32_t n_trees, uint32_t p)
+{
+    uint32_t d = 0;
+    for (uint32_t t = 0; t < n_trees && G[t] <= p; t++) d = D[t];
+    return p + d;
+}
+
+// The positions a shared-path text names, read BACKWARDS from its end: `... [p0, p1, .., pQ-1] }` with JSON whitespace
+// anywhere between the tokens.  tail[0 .. n) are the last n bytes of the text.  Only a first guess: the place pass
+// compares the whole text with the template these positions imply and stores the numbers it finds, and the two
+// readings must agree.  false = not of that form (the host reader decides).
+SS_HD inline bool shared_text_hint(const uint8_t *tail, uint32_t n, uint32_t Q, uint32_t *pos)
+{
+    uint32_t i = n;
+    auto skip = [&]() { while (i && txt_is_ws(tail[i - 1])) i--; };
+    auto expect = [&](uint8_t c) { skip(); if (!i || tail[i - 1] != c) return false; i--; return true; };
+    if (!expect('}') || !expect(']')) return false;
+    for (uint32_t q = Q; q-- > 0;) {
+        skip();
+        uint64_t v = 0, mul = 1;
+        uint32_t digits = 0;
+        while (i && txt_is_digit(tail[i - 1]) && digits < 10) { v += mul * (tail[i - 1] - '0'); mul *= 10; i--; digits++; }
+        if (!digits || v > 0xffffffffull) return false;
+        pos[q] = (uint32_t)v;
+        if (q && !expect(',')) return false;
+    }
+    return expect('[');
+}
+
 }  // namespace ss
 
 #include <string>
@@ -117,6 +189,7 @@ bool stwo_write_wit(const ss_stwo_cfg &cfg, const uint32_t *record, std::string 
 
 // Host-side owner of a template.
 struct TextTemplateHost {
+    SharedTextInfo sinfo{};        // format 3 only
     std::vector<uint8_t> skel;     // skel_len bytes + kSkelSlack zeros
     uint32_t skel_len = 0;
     std::vector<TextSlot> slots;
@@ -126,8 +199,16 @@ struct TextTemplateHost {
     bool ok = false;               // false: no canonical text exists for this config / format (fast path off)
     TextTemplate view() const;
 };
-// fmt: SS_TEXT_JSON or SS_TEXT_WIT
+// fmt: SS_TEXT_JSON, SS_TEXT_WIT or SS_TEXT_JSON_SHARED (the full-length text over a capacity-form shared record)
 void stwo_build_template(const ss_stwo_cfg &cfg, int fmt, TextTemplateHost &out);
+// shared record (include/ss_verify.h) -> the shared-path proof.json, byte for byte json.dumps(formats.stwo_to_json(p,
+// shared=True)); false when `shared` is no shared record of the config
+bool stwo_write_json_shared(const ss_stwo_cfg &cfg, const uint32_t *shared, size_t words, TextStyle style, std::string &out);
+// Scalar statement of the fast path for format 3: hint from the tail, gaps, the scan of text_scan_reference through the
+// gap maps into a capacity-form shared record, the stored positions against the hint, expansion (ss_stwo_unshare_record's
+// rule) into `record` (the per-query record).  scratch: shared_capacity_words(cfg) words.
+bool shared_text_scan_reference(const ss_stwo_cfg &cfg, const TextTemplateHost &t, const char *text, size_t len,
+                                uint32_t *record);
 
 // stark101 (stark101/scripts/fibsquare/prover.py:108,143-167 writes proof.json, stark101/scripts/generate_wit.py:13-30
 // the .wit).  The protocol fixes the proof's shape: an LDE domain of 2^13 points, so Merkle paths of 13 siblings for the

@@ -160,3 +160,93 @@ def test_cli_converts_to_the_shared_form(capsys):
     p = ss.stwo_from_json(json.loads(out), expect=ss.PRODUCTION_CONFIG)
     want = ss.stwo_from_json(json.load(open(src)))
     assert np.array_equal(verifier.stwo_record(p), verifier.stwo_record(want))
+
+
+# ---------------------------------------------------------------------- the GPU reader's rule for shared-path texts
+def _write_shared_text(cfg, shared, python_separators=0):
+    import ctypes as C
+    from stark_symphony_amd import binding
+    cs = verifier.stwo_cfg_struct(cfg, verifier.MODE_FIXTURE)
+    sh = np.ascontiguousarray(shared, dtype=np.uint32)
+    n = binding.lib().ss_stwo_write_shared_text(C.byref(cs), sh.ctypes.data, sh.size, python_separators, None, 0)
+    if n == 0:
+        return None
+    buf = C.create_string_buffer(n)
+    assert binding.lib().ss_stwo_write_shared_text(C.byref(cs), sh.ctypes.data, sh.size, python_separators, buf, n) == n
+    return buf.raw
+
+
+def _canonical_shared(cfg, text):
+    from test_text_fastpath import canonical
+    from stark_symphony_amd import binding
+    return canonical(cfg, text, binding.TEXT_JSON_SHARED)
+
+
+def _more_fixtures():
+    return _fixtures() + [records.load_stwo_npz(os.path.join(GOLDEN, "stwo_trace20.npz"))[0]]
+
+
+def test_library_writes_the_shared_text_formats_py_writes():
+    """ss_stwo_write_shared_text(shared record) == json.dumps(formats.stwo_to_json(p, shared=True)), both separator
+    styles: the template of the GPU reader is made by that writer."""
+    for p in _more_fixtures():
+        sh = verifier.stwo_shared_record(p)
+        obj = ss.stwo_to_json(p, shared=True)
+        assert _write_shared_text(p.cfg, sh, 0) == json.dumps(obj, separators=(",", ":")).encode()
+        assert _write_shared_text(p.cfg, sh, 1) == json.dumps(obj).encode()
+        bad = sh.copy()
+        bad[-1 - 8 * 3] ^= 1  # a node: still a shared record
+        assert _write_shared_text(p.cfg, bad, 0) is not None
+        cnt = sh.size - 8 * int(verifier.stwo_shared_counts(p.cfg, formats.stwo_queries(p)).sum()) - 1
+        bad = sh.copy()
+        bad[cnt] += 1         # a count that its positions do not imply: not a shared record
+        assert _write_shared_text(p.cfg, bad, 0) is None and _write_shared_text(p.cfg, sh[:-1], 0) is None
+
+
+def test_rule_takes_honest_shared_texts():
+    """The scalar statement of the GPU reader's rule for format 3 (hint from the tail, template with the gaps the
+    hint implies, stored positions against the hint, expansion) takes what honest producers write -- both separator
+    styles, trailing newline, indentation -- and yields the per-query record."""
+    for p in _more_fixtures():
+        rec = verifier.stwo_record(p)
+        obj = ss.stwo_to_json(p, shared=True)
+        for text in (json.dumps(obj, separators=(",", ":")), json.dumps(obj), json.dumps(obj) + "\n", json.dumps(obj, indent=1)):
+            took, got = _canonical_shared(p.cfg, text.encode())
+            assert took and np.array_equal(got, rec), p.cfg
+        # the per-query text of the same proof is NOT of this format, and the other way round
+        from test_text_fastpath import canonical, JSON
+        assert not _canonical_shared(p.cfg, json.dumps(ss.stwo_to_json(p)).encode())[0]
+        if p.cfg.n_queries > 1:
+            assert not canonical(p.cfg, json.dumps(obj).encode(), JSON)[0]
+
+
+def test_whatever_the_rule_takes_reads_as_the_host_reader_reads_it():
+    """Soundness of the fast path for shared texts: 1 500 byte-level and structure-level mutants; every text the rule
+    takes is parsed by the host reader (the arbiter) to exactly the same record."""
+    rnd = random.Random(0x5EED2025 + 77)
+    taken = changed = 0
+    for p in _fixtures()[:3]:
+        obj = ss.stwo_to_json(p, shared=True)
+        base = json.dumps(obj, separators=(",", ":")).encode()
+        base_rec = verifier.stwo_record(p)
+        Q = p.cfg.n_queries
+        for i in range(500):
+            kind = i % 5
+            if kind < 3:
+                text = _text_mutant(rnd, base)
+            elif kind == 3:    # another hint inside the domain / swapped hints (the lists then have the wrong lengths)
+                o = json.loads(base)
+                o["queries"][rnd.randrange(Q)] = rnd.randrange(1 << p.cfg.lde_log)
+                text = json.dumps(o, separators=(",", ":")).encode()
+            else:              # a number replaced by another canonical number somewhere
+                import re
+                ms = list(re.finditer(rb"\d+", base))
+                m = ms[rnd.randrange(len(ms))]
+                text = base[:m.start()] + str(rnd.choice([0, 1, 255, 256, 2 ** 31, 2 ** 32 - 1, 2 ** 32])).encode() + base[m.end():]
+            took, rec = _canonical_shared(p.cfg, text)
+            if took:
+                taken += 1
+                got, nrec = verifier.parse_stwo_text(p.cfg, text)
+                assert got == OK and np.array_equal(nrec, rec), (p.cfg, i)
+                changed += not np.array_equal(rec, base_rec)
+    assert taken > 120 and changed > 50, (taken, changed)
