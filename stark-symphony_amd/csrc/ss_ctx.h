@@ -46,6 +46,7 @@ struct DevTemplate {
     ss_stwo_cfg cfg;
     int fmt;
     bool ok;            // false: no fast path for this config / format
+    SharedTextInfo sinfo;  // format SS_TEXT_JSON_SHARED
     void *skel = nullptr, *slots = nullptr, *trailer = nullptr;
     TextTemplate view;  // device pointers
 };
@@ -62,6 +63,7 @@ struct TextPath {
     GrowBuf text_pin[kTextBufs], text_dev[kTextBufs];  // texts + their offsets / lengths / formats behind them
     GrowBuf rec_dev[kTextBufs], out_dev[kTextBufs], out_pin[kTextBufs];
     GrowBuf win_dev[kTextBufs];        // per-window scratch of the GPU reader (ss_textdev.h)
+    GrowBuf shrec_dev[kTextBufs], hint_dev[kTextBufs];  // shared-path texts: capacity-form shared records, per-text hints
     GrowBuf fix_pin[kTextBufs];        // records re-made by the host reader, on their way up
     GrowBuf batch_dev, ws_dev, status_dev;
     hipStream_t up = nullptr, cx = nullptr, vx = nullptr;  // upload, GPU reader, re-tile + verify
@@ -104,7 +106,8 @@ struct Timer {
 int hp_reserve(ss_ctx *ctx, int slot, size_t bytes);  // grow-only device buffer `slot` of the host path (ss_api.hip)
 int hp_pinned(ss_ctx *ctx, size_t bytes);             // its two pinned staging buffers, streams and events
 int shared_expand_launch(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const uint32_t *shared_dev, const uint64_t *offs_dev,
-                         uint64_t capacity_stride, uint32_t *records_dev, uint32_t *outcome_dev, hipStream_t s);  // ss_shared.hip
+                         uint64_t capacity_stride, uint32_t *records_dev, uint32_t *outcome_dev, hipStream_t s,
+                         const uint8_t *only_fmt = nullptr, const uint32_t *hint_pos = nullptr, uint32_t hint_stride = 0);  // ss_shared.hip
 
 int grow(GrowBuf &b, size_t bytes, bool pinned);  // (re)allocates when too small; contents are not kept
 void release(GrowBuf &b);

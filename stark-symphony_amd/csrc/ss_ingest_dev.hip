@@ -57,7 +57,7 @@ void text_path_destroy(TextPath &tp)
 {
     for (int i = 0; i < kTextBufs; i++) {
         release(tp.text_pin[i]); release(tp.text_dev[i]); release(tp.rec_dev[i]); release(tp.out_dev[i]);
-        release(tp.out_pin[i]); release(tp.fix_pin[i]); release(tp.win_dev[i]);
+        release(tp.out_pin[i]); release(tp.fix_pin[i]); release(tp.win_dev[i]); release(tp.shrec_dev[i]); release(tp.hint_dev[i]);
         if (tp.uploaded[i]) (void)hipEventDestroy(tp.uploaded[i]);
         if (tp.parsed[i]) (void)hipEventDestroy(tp.parsed[i]);
         if (tp.fixed[i]) (void)hipEventDestroy(tp.fixed[i]);
@@ -85,24 +85,37 @@ bool same_text_cfg(const ss_stwo_cfg &a, const ss_stwo_cfg &b)
 }
 
 // the device copy of (cfg, fmt)'s template, built on first use
-int template_of(ss_ctx *ctx, const ss_stwo_cfg &cfg, int fmt, hipStream_t s, TextTemplate &view)
+int template_of(ss_ctx *ctx, const ss_stwo_cfg &cfg, int fmt, hipStream_t s, TextTemplate &view, SharedTextInfo *sinfo = nullptr)
 {
     TextPath &tp = ctx->tp;
-    for (auto &t : tp.templates)
-        if (t.fmt == fmt && same_text_cfg(t.cfg, cfg)) { view = t.ok ? t.view : TextTemplate(); return SS_OK; }
-    if (tp.templates.size() >= 8) {  // a caller that cycles through many configs: drop the oldest
-        DevTemplate &o = tp.templates.front();
-        HIP_TRY(hipStreamSynchronize(s));
-        if (o.skel) (void)hipFree(o.skel);
-        if (o.slots) (void)hipFree(o.slots);
-        if (o.trailer) (void)hipFree(o.trailer);
-        tp.templates.erase(tp.templates.begin());
+    for (size_t i = 0; i < tp.templates.size(); i++) {
+        if (tp.templates[i].fmt != fmt || !same_text_cfg(tp.templates[i].cfg, cfg)) continue;
+        const DevTemplate t = tp.templates[i];  // most recently used last
+        tp.templates.erase(tp.templates.begin() + i);
+        tp.templates.push_back(t);
+        view = t.ok ? t.view : TextTemplate();
+        if (sinfo) *sinfo = t.sinfo;
+        return SS_OK;
+    }
+    if (tp.templates.size() >= 12) {  // a caller that cycles through many configs: drop the least recently used one
+        // -- of ANOTHER config: the views of this config's other formats are in use by the call that asks
+        size_t v = 0;
+        while (v < tp.templates.size() && same_text_cfg(tp.templates[v].cfg, cfg)) v++;
+        if (v < tp.templates.size()) {
+            DevTemplate &o = tp.templates[v];
+            HIP_TRY(hipStreamSynchronize(s));
+            if (o.skel) (void)hipFree(o.skel);
+            if (o.slots) (void)hipFree(o.slots);
+            if (o.trailer) (void)hipFree(o.trailer);
+            tp.templates.erase(tp.templates.begin() + v);
+        }
     }
     TextTemplateHost h;
     if (cfg.n_cols == 0) s101_build_template(fmt, h);  // the key s101_ingest_dev uses
     else stwo_build_template(cfg, fmt, h);
     DevTemplate d{};
-    d.cfg = cfg; d.fmt = fmt; d.ok = h.ok;
+    d.cfg = cfg; d.fmt = fmt; d.ok = h.ok; d.sinfo = h.sinfo;
+    if (sinfo) *sinfo = h.sinfo;
     if (h.ok) {
         HIP_TRY(hipMalloc(&d.skel, h.skel.size()));
         HIP_TRY(hipMalloc(&d.slots, h.slots.size() * sizeof(TextSlot)));
@@ -177,7 +190,9 @@ long read_into(const char *path, uint8_t *dst, size_t cap)
 // What differs between the proof families behind the one pipeline.
 struct Family {
     size_t W = 0;                 // words of a record on the device
-    TextTemplate tmpl[2];         // device views: proof.json, proof.wit
+    TextTemplate tmpl[3];         // device views: proof.json, proof.wit, shared-path proof.json (stwo only)
+    SharedTextInfo sinfo{};       // of tmpl[2]
+    const ss_stwo_cfg *shared_cfg = nullptr;  // not null: shared-path texts are read and expanded on the GPU
     const char *wit_key = "";     // the member name a .wit starts with (format sniffing for the GPU reader's first guess)
     bool zero_records = false;    // records have padding words the GPU reader does not write
     // host reader of text g into dst (W words): 0 = parsed, SS_STATUS_MALFORMED / SS_STATUS_CONFIG_MISMATCH = stage-0
@@ -200,7 +215,11 @@ static int ingest_pipeline(ss_ctx *ctx, const Family &F, size_t n, const char *c
     TextParseArgs args{};
     args.tmpl[0] = F.tmpl[0];
     args.tmpl[1] = F.tmpl[1];
+    args.tmpl[2] = F.tmpl[2];
+    args.sinfo = F.sinfo;
     args.record_words = (uint32_t)W;
+    const bool shared_ok = F.shared_cfg && F.tmpl[2].skel;
+    const size_t SW = shared_ok ? F.tmpl[2].record_words : 0;  // words of a capacity-form shared record
     const unsigned threads = effective_cpus();
     // staging is a copy: a few threads saturate it, and the thread that drives the GPU needs a core too
     unsigned stage_threads = std::max(1u, std::min(threads > 1 ? threads - 1 : 1u, 8u));
@@ -269,6 +288,8 @@ static int ingest_pipeline(ss_ctx *ctx, const Family &F, size_t n, const char *c
         if ((rc = grow(tp.out_dev[b], max_cnt * 4, false))) return rc;
         if ((rc = grow(tp.out_pin[b], max_cnt * 4, true))) return rc;
         if ((rc = grow(tp.win_dev[b], max_windows * (4 + sizeof(WinSum) + sizeof(WinIn)), false))) return rc;
+        if (shared_ok && ((rc = grow(tp.shrec_dev[b], max_cnt * SW * 4, false)) || (rc = grow(tp.hint_dev[b], max_cnt * sizeof(TextHint), false))))
+            return rc;
     }
     if ((rc = grow(tp.batch_dev, words * 4, false))) return rc;
     if ((rc = grow(tp.ws_dev, wsb, false))) return rc;
@@ -317,6 +338,14 @@ static int ingest_pipeline(ss_ctx *ctx, const Family &F, size_t n, const char *c
                 const size_t look = len < 64 ? len : 64;
                 const size_t kl = strlen(F.wit_key);
                 for (size_t p = 0; p + kl <= look && !f; p++) f = memcmp(dst + p, F.wit_key, kl) == 0;
+            }
+            // ... and a shared-path proof.json ends with its "queries" member (at most 64 short numbers: the last KiB)
+            if (shared_ok && !f && fmt != SS_TEXT_WIT) {
+                if (fmt == SS_TEXT_JSON_SHARED) f = 2;
+                else {
+                    const size_t look = len < 1024 ? len : 1024;
+                    if (look >= 9 && memmem(dst + (len - look), look, "\"queries\"", 9)) f = 2;
+                }
             }
             fmts[i] = f;
         }, stage_threads);
@@ -418,6 +447,8 @@ static int ingest_pipeline(ss_ctx *ctx, const Family &F, size_t n, const char *c
             args.win_in = (WinIn *)(args.win_sum + max_windows);
             args.records = (uint32_t *)tp.rec_dev[b].p;
             args.outcome = (uint32_t *)tp.out_dev[b].p;
+            args.hints = shared_ok ? (TextHint *)tp.hint_dev[b].p : nullptr;
+            args.shared_records = shared_ok ? (uint32_t *)tp.shrec_dev[b].p : nullptr;
             args.n = (uint32_t)ch.cnt;
             args.n_windows = chunk_windows[k];
             {
@@ -427,6 +458,11 @@ static int ingest_pipeline(ss_ctx *ctx, const Family &F, size_t n, const char *c
                 t.end("stwo_text_parse");
             }
             HIP_TRY(hipGetLastError());
+            // shared-path texts were read into capacity-form shared records: expand them into the chunk's records
+            if (shared_ok && (rc = shared_expand_launch(ctx, F.shared_cfg, ch.cnt, args.shared_records, nullptr, SW, args.records,
+                                                        args.outcome, tp.cx, args.fmt, args.hints->pos,
+                                                        (uint32_t)(sizeof(TextHint) / 4))))
+                return rc;
             HIP_TRY(hipMemcpyAsync(tp.out_pin[b].p, tp.out_dev[b].p, ch.cnt * 4, hipMemcpyDeviceToHost, tp.cx));
             HIP_TRY(hipEventRecord(tp.parsed[b], tp.cx));
             if (k > 0 && (rc = finish(k - 1))) return rc;
@@ -463,7 +499,7 @@ int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *con
     if (!ctx || !status_host || (!texts && !paths) || (texts && !lens)) return set_err(SS_ERR_ARG, "null argument");
     if (!cfg_ok(c)) return set_err(SS_ERR_ARG, "unsupported stwo config");
     if (!n) return set_err(SS_ERR_ARG, "empty batch");
-    if (fmt < SS_TEXT_AUTO || fmt > SS_TEXT_WIT) return set_err(SS_ERR_ARG, "unknown text format");
+    if (fmt < SS_TEXT_AUTO || fmt > SS_TEXT_JSON_SHARED) return set_err(SS_ERR_ARG, "unknown text format");
     if (n * (size_t)c->n_queries > 0x7fffffffu) return set_err(SS_ERR_ARG, "batch too large");
     std::lock_guard<std::mutex> lock(ctx->mu);  // the context's scratch: one such call at a time
     const double t0 = now_s();
@@ -474,10 +510,13 @@ int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *con
     F.W = ss_stwo_record_words(c);
     if ((rc = template_of(ctx, *c, SS_TEXT_JSON, ctx->tp.cx, F.tmpl[0]))) return rc;
     if ((rc = template_of(ctx, *c, SS_TEXT_WIT, ctx->tp.cx, F.tmpl[1]))) return rc;
+    if ((rc = template_of(ctx, *c, SS_TEXT_JSON_SHARED, ctx->tp.cx, F.tmpl[2], &F.sinfo))) return rc;
     F.wit_key = "\"COMMITMENTS\"";
     const ss_stwo_cfg cv = *c;
-    F.host_read = [&cv, fmt](size_t, const char *text, size_t len, uint32_t *dst) {
-        const ParseResult r = stwo_parse_text(cv, text, len, fmt, dst);
+    F.shared_cfg = &cv;
+    const int host_fmt = fmt == SS_TEXT_JSON_SHARED ? SS_TEXT_JSON : fmt;  // (the host reader knows the shared form by its member)
+    F.host_read = [&cv, host_fmt](size_t, const char *text, size_t len, uint32_t *dst) {
+        const ParseResult r = stwo_parse_text(cv, text, len, host_fmt, dst);
         return r == kParsed ? 0 : r == kConfigMismatch ? (int)SS_STATUS_CONFIG_MISMATCH : (int)SS_STATUS_MALFORMED;
     };
     F.batch_words = [&cv](size_t cnt) { return ss_stwo_batch_words(&cv, cnt); };
@@ -569,7 +608,8 @@ int stwo_read_texts_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char 
                         int fmt, uint32_t *records_host, uint32_t *outcome_host)
 {
     if (!ctx || !texts || !lens || !records_host || !outcome_host) return set_err(SS_ERR_ARG, "null argument");
-    if ((c && !cfg_ok(c)) || !n || (fmt != SS_TEXT_JSON && fmt != SS_TEXT_WIT)) return set_err(SS_ERR_ARG, "bad argument");
+    const bool sh_fmt = c && fmt == SS_TEXT_JSON_SHARED;
+    if ((c && !cfg_ok(c)) || !n || (fmt != SS_TEXT_JSON && fmt != SS_TEXT_WIT && !sh_fmt)) return set_err(SS_ERR_ARG, "bad argument");
     std::lock_guard<std::mutex> lock(ctx->mu);
     HIP_TRY(hipSetDevice(ctx->device));
     TextPath &tp = ctx->tp;
@@ -582,6 +622,8 @@ int stwo_read_texts_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char 
     TextParseArgs args{};
     if ((rc = template_of(ctx, c ? *c : key, SS_TEXT_JSON, tp.cx, args.tmpl[0]))) return rc;
     if ((rc = template_of(ctx, c ? *c : key, SS_TEXT_WIT, tp.cx, args.tmpl[1]))) return rc;
+    if (sh_fmt && (rc = template_of(ctx, *c, SS_TEXT_JSON_SHARED, tp.cx, args.tmpl[2], &args.sinfo))) return rc;
+    if (sh_fmt && !args.tmpl[2].skel) return set_err(SS_ERR_ARG, "no shared-path text exists for this config");
     args.record_words = (uint32_t)W;
     auto aligned = [](size_t v) { return (v + 15) & ~(size_t)15; };
     size_t total = 0;
@@ -604,14 +646,18 @@ int stwo_read_texts_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char 
         l32[i] = (uint32_t)lens[i];
         wb[i] = n_windows;
         n_windows += (uint32_t)((lens[i] + 1023) >> 10);
-        f8[i] = fmt == SS_TEXT_WIT;
+        f8[i] = sh_fmt ? 2 : fmt == SS_TEXT_WIT;
     }
     wb[n] = n_windows;
-    GrowBuf text, rec, out, win;
-    auto done = [&](int code) { release(text); release(rec); release(out); release(win); return code; };
+    GrowBuf text, rec, out, win, shrec, hint;
+    auto done = [&](int code) { release(text); release(rec); release(out); release(win); release(shrec); release(hint); return code; };
     if ((rc = grow(text, bytes, false)) || (rc = grow(rec, n * W * 4, false)) || (rc = grow(out, n * 4, false)) ||
         (rc = grow(win, (size_t)(n_windows + 4) * (4 + sizeof(WinSum) + sizeof(WinIn)), false)))
         return done(rc);
+    if (sh_fmt && ((rc = grow(shrec, n * (size_t)args.tmpl[2].record_words * 4, false)) || (rc = grow(hint, n * sizeof(TextHint), false))))
+        return done(rc);
+    args.hints = (TextHint *)hint.p;
+    args.shared_records = (uint32_t *)shrec.p;
     const size_t wcap = ((size_t)n_windows + 4) & ~(size_t)3;
     if (hipMemcpy(text.p, host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(rec.p, c ? 0xee : 0, n * W * 4) != hipSuccess)  // (stark101 records have zero padding the reader leaves alone)
@@ -630,6 +676,9 @@ int stwo_read_texts_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char 
     args.n = (uint32_t)n;
     args.n_windows = n_windows;
     launch_text_parse(args, tp.cx);
+    if (sh_fmt && (rc = shared_expand_launch(ctx, c, n, args.shared_records, nullptr, args.tmpl[2].record_words, args.records,
+                                             args.outcome, tp.cx, args.fmt, args.hints->pos, (uint32_t)(sizeof(TextHint) / 4))))
+        return done(rc);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(tp.cx) != hipSuccess ||
         hipMemcpy(records_host, rec.p, n * W * 4, hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(outcome_host, out.p, n * 4, hipMemcpyDeviceToHost) != hipSuccess)

@@ -33,7 +33,13 @@ struct SharedArgs {
     const uint64_t *offs;     // compact form: n + 1 word offsets of the records inside `shared`
     const uint32_t *shared;
     uint32_t *records;
-    uint32_t *outcome;        // 0 = expanded, SS_STATUS_MALFORMED = no shared record of this config
+    uint32_t *outcome;        // 0 = expanded, `refuse` = no shared record of this config
+    uint32_t refuse;          // SS_STATUS_MALFORMED; the GPU text reader: 1 = "the host reader decides"
+    // the GPU text reader (capacity form): only texts of format 2 whose outcome is still 0 are expanded, and the positions
+    // the place pass stored must be the ones the template was cut with (hint_pos + p * hint_stride words)
+    const uint8_t *only_fmt;
+    const uint32_t *hint_pos;
+    uint32_t hint_stride;
 };
 
 __global__ void __launch_bounds__(256) stwo_shared_expand_kernel(SharedArgs a)
@@ -45,6 +51,7 @@ __global__ void __launch_bounds__(256) stwo_shared_expand_kernel(SharedArgs a)
     __shared__ uint32_t s_short, s_bad;
     const uint32_t p = blockIdx.x, tid = threadIdx.x;
     if (p >= a.n) return;
+    if (a.only_fmt && (a.only_fmt[p] != 2 || a.outcome[p] != 0)) return;
     const SharedMap &m = a.m;
     const uint32_t N = m.N, L = m.L, Q = m.Q, K = m.K;
     const uint64_t off = a.capacity ? (uint64_t)p * a.stride : a.offs[p];
@@ -55,7 +62,7 @@ __global__ void __launch_bounds__(256) stwo_shared_expand_kernel(SharedArgs a)
     __syncthreads();
     if (s_short) {  // (too short to hold even the fixed words: nothing of it is read)
         for (uint32_t i = tid; i < a.record_words; i += 256) rec[i] = 0;
-        if (tid == 0) a.outcome[p] = SS_STATUS_MALFORMED;
+        if (tid == 0) a.outcome[p] = a.refuse;
         return;
     }
     // ---- the plan (wave 0; lane = query)
@@ -63,6 +70,7 @@ __global__ void __launch_bounds__(256) stwo_shared_expand_kernel(SharedArgs a)
         const uint32_t q = tid;
         const uint32_t pos = q < Q ? sh[m.qry + q] : 0;
         bool bad = (pos >> L) != 0;
+        if (a.hint_pos && q < Q) bad |= pos != a.hint_pos[(uint64_t)p * a.hint_stride + q];
         uint32_t s = 32;
         for (uint32_t e = 0; e < Q; e++) {
             const uint32_t other = __shfl(pos, e);
@@ -97,7 +105,7 @@ __global__ void __launch_bounds__(256) stwo_shared_expand_kernel(SharedArgs a)
     __syncthreads();
     if (s_bad) {
         for (uint32_t i = tid; i < a.record_words; i += 256) rec[i] = 0;
-        if (tid == 0) a.outcome[p] = SS_STATUS_MALFORMED;
+        if (tid == 0) a.outcome[p] = a.refuse;
         return;
     }
     // lead(q, a) = the first e < q with d(q, e) <= a, else q
@@ -161,7 +169,8 @@ static SharedArgs shared_args(const ss_stwo_cfg *c, size_t n)
 }
 
 int shared_expand_launch(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const uint32_t *shared_dev, const uint64_t *offs_dev,
-                         uint64_t capacity_stride, uint32_t *records_dev, uint32_t *outcome_dev, hipStream_t s)
+                         uint64_t capacity_stride, uint32_t *records_dev, uint32_t *outcome_dev, hipStream_t s,
+                         const uint8_t *only_fmt, const uint32_t *hint_pos, uint32_t hint_stride)
 {
     SharedArgs a = shared_args(c, n);
     a.capacity = offs_dev ? 0 : 1;
@@ -170,6 +179,10 @@ int shared_expand_launch(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const uint
     a.shared = shared_dev;
     a.records = records_dev;
     a.outcome = outcome_dev;
+    a.refuse = only_fmt ? 1u : SS_STATUS_MALFORMED;
+    a.only_fmt = only_fmt;
+    a.hint_pos = hint_pos;
+    a.hint_stride = hint_stride;
     Timer t(ctx, s);
     t.begin();
     hipLaunchKernelGGL(stwo_shared_expand_kernel, dim3((unsigned)n), dim3(256), 0, s, a);

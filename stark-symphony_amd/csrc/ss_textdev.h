@@ -25,8 +25,13 @@ struct TextParseArgs {
     const uint64_t *offs;      // [n] byte offset of text i in `texts`
     const uint32_t *lens;      // [n] its length
     const uint32_t *win_base;  // [n + 1] windows (ceil(len / 1024)) of the texts before text i
-    const uint8_t *fmt;        // [n] 0 = tmpl[0] (proof.json), 1 = tmpl[1] (proof.wit)
-    TextTemplate tmpl[2];      // device pointers inside; skel == nullptr: no fast path for that format
+    const uint8_t *fmt;        // [n] 0 = tmpl[0] (proof.json), 1 = tmpl[1] (proof.wit), 2 = tmpl[2] (shared-path proof.json)
+    TextTemplate tmpl[3];      // device pointers inside; skel == nullptr: no fast path for that format
+    // format 2 (ss_text.h, "shared-path proof.json"): where the hash lists sit in tmpl[2]; per text the positions read
+    // from its tail and the gaps they imply; the capacity-form shared records the place pass writes for such texts
+    SharedTextInfo sinfo;
+    TextHint *hints;           // [n] scratch
+    uint32_t *shared_records;  // [n][tmpl[2].record_words]
     uint32_t *win_text;        // [n_windows] scratch: the text a window belongs to
     WinSum *win_sum;           // [n_windows] scratch
     WinIn *win_in;             // [n_windows] scratch

@@ -32,6 +32,7 @@
 
 #include "ss_text.h"
 #include "ss_textdev.h"
+#include "ss_shared.h"
 
 namespace ss {
 
@@ -124,6 +125,49 @@ __global__ void __launch_bounds__(64) text_index_kernel(TextParseArgs a)
     for (uint32_t w = a.win_base[t] + threadIdx.x; w < a.win_base[t + 1]; w += 64) a.win_text[w] = t;
 }
 
+// Format 2 only: the positions a shared-path text names (read backwards from its last KiB by one lane: <= 64 short
+// numbers), the distinct siblings per tree they imply (the closed form of ss_shared.h: lane = query) and the gaps those
+// counts cut out of the full-length template.  A text whose tail is not `[p0, .., pQ-1] }` gets totals that nothing matches.
+__global__ void __launch_bounds__(64) text_hint_kernel(TextParseArgs a)
+{
+    __shared__ uint4 s_tail4[68];
+    __shared__ uint32_t s_pos[64], s_cnt[kMaxTrees], s_ok;
+    const uint32_t t = blockIdx.x, lane = threadIdx.x;
+    if (t >= a.n || a.fmt[t] != 2) return;
+    const SharedTextInfo &I = a.sinfo;
+    const uint32_t len = a.lens[t];
+    const uint32_t base = len > 1024 ? (len - 1024) & ~15u : 0;
+    const uint4 *text4 = reinterpret_cast<const uint4 *>(a.texts + a.offs[t] + base);  // (kTextSlack readable behind the chunk)
+    s_tail4[lane] = text4[lane];
+    if (lane < 4) s_tail4[64 + lane] = text4[64 + lane];
+    __syncthreads();
+    if (lane == 0) {
+        const uint32_t tail = len < 1024 ? len : 1024;
+        bool ok = a.tmpl[2].skel != nullptr && shared_text_hint(reinterpret_cast<const uint8_t *>(s_tail4) + (len - base - tail), tail, I.Q, s_pos);
+        for (uint32_t q = 0; q < I.Q && ok; q++) ok = (s_pos[q] >> I.L) == 0;
+        s_ok = ok;
+    }
+    __syncthreads();
+    TextHint *h = a.hints + t;
+    if (!s_ok) {
+        if (lane == 0) { h->g.skel_len = 0xffffffffu; h->g.n_slots = 0xffffffffu; }
+        return;
+    }
+    const uint32_t q = lane, pos = q < I.Q ? s_pos[q] : 0;
+    uint32_t s = 32;
+    for (uint32_t e = 0; e < q && e < I.Q; e++) {
+        const uint32_t x = pos ^ s_pos[e], d = x ? 32 - __clz(x) : 0;
+        s = d < s ? d : s;
+    }
+    for (uint32_t k = 0; k < I.n_trees; k++) {
+        const uint32_t c = wave_sum(q < I.Q ? shared_fresh(s, I.L, k) : 0);
+        if (lane == 0) s_cnt[k] = c;
+    }
+    __syncthreads();
+    if (lane == 0) shared_text_gaps(I, s_cnt, a.tmpl[2].skel_len, a.tmpl[2].n_slots, h->g);
+    if (q < I.Q) h->pos[q] = pos;
+}
+
 __global__ void __launch_bounds__(64) text_summary_kernel(TextParseArgs a)
 {
     const uint32_t gw = blockIdx.x, lane = threadIdx.x;
@@ -200,12 +244,14 @@ __global__ void __launch_bounds__(64) text_scan_kernel(TextParseArgs a)
     const uint32_t t = blockIdx.x, lane = threadIdx.x;
     if (t >= a.n) return;
     const uint32_t w0 = a.win_base[t], nwin = a.win_base[t + 1] - w0;
-    const bool wit = a.fmt[t] & 1;
-    const uint8_t *skel = wit ? a.tmpl[1].skel : a.tmpl[0].skel;
-    const uint32_t skel_len = wit ? a.tmpl[1].skel_len : a.tmpl[0].skel_len;
-    const uint32_t n_slots = wit ? a.tmpl[1].n_slots : a.tmpl[0].n_slots;
+    const uint32_t f = a.fmt[t];
+    const bool wit = f == 1;
+    const uint8_t *skel = a.tmpl[f].skel;
+    // (a shared-path text has the totals its own positions imply: text_hint_kernel)
+    const uint32_t skel_len = f == 2 ? a.hints[t].g.skel_len : a.tmpl[f].skel_len;
+    const uint32_t n_slots = f == 2 ? a.hints[t].g.n_slots : a.tmpl[f].n_slots;
     uint32_t carry_run = kRunNone, carry_str = 0, skel_pos = 0, tok_pos = 0;
-    bool bad = skel == nullptr || nwin == 0;
+    bool bad = skel == nullptr || nwin == 0 || skel_len == 0xffffffffu;
     const uint64_t below = (1ull << lane) - 1;
     for (uint32_t g = 0; g < nwin && !bad; g += 64) {
         const uint32_t w = g + lane;
@@ -241,7 +287,7 @@ __global__ void __launch_bounds__(64) text_scan_kernel(TextParseArgs a)
         bad = __ballot(s.flags & 1) != 0 || skel_pos > skel_len || tok_pos > n_slots;
     }
     const bool good = !bad && skel_pos == skel_len && tok_pos == n_slots && carry_str == 0;
-    if (good) {  // the path-length trailer of a canonical text is the config's
+    if (good && f != 2) {  // the path-length trailer of a canonical text is the config's (format 2: written by the expansion)
         const TextTemplate &T = wit ? a.tmpl[1] : a.tmpl[0];
         uint32_t *rec = a.records + (size_t)t * a.record_words;
         for (uint32_t i = lane; i < T.n_trailer; i += 64) rec[T.tbase + i] = T.trailer[i];
@@ -263,11 +309,22 @@ __global__ void __launch_bounds__(64) text_place_kernel(TextParseArgs a)
     const uint32_t t = a.win_text[gw];
     if (a.outcome[t] != 0) return;  // the scan (or another window) has already sent this text to the host reader
     const uint32_t w = gw - a.win_base[t], nwin = a.win_base[t + 1] - a.win_base[t], len = a.lens[t];
-    const bool wit = a.fmt[t] & 1;
-    const uint8_t *skel = wit ? a.tmpl[1].skel : a.tmpl[0].skel;
-    const TextSlot *slots = wit ? a.tmpl[1].slots : a.tmpl[0].slots;
-    const uint32_t n_slots = wit ? a.tmpl[1].n_slots : a.tmpl[0].n_slots;
-    uint32_t *rec = a.records + (size_t)t * a.record_words;
+    const uint32_t f = a.fmt[t];
+    const bool shared = f == 2;
+    const uint8_t *skel = a.tmpl[f].skel;
+    const TextSlot *slots = a.tmpl[f].slots;
+    const uint32_t n_slots = shared ? a.hints[t].g.n_slots : a.tmpl[f].n_slots;
+    uint32_t *rec = shared ? a.shared_records + (size_t)t * a.tmpl[2].record_words : a.records + (size_t)t * a.record_words;
+    // format 2: positions in this text -> positions in the full-length template (ss_text.h, TextGaps)
+    __shared__ uint32_t s_G[kMaxTrees], s_D[kMaxTrees], s_Gk[kMaxTrees], s_Dk[kMaxTrees];
+    const uint32_t n_trees = a.sinfo.n_trees;
+    if (shared) {
+        if (lane < n_trees) {
+            const TextGaps &g = a.hints[t].g;
+            s_G[lane] = g.G[lane]; s_D[lane] = g.D[lane]; s_Gk[lane] = g.Gk[lane]; s_Dk[lane] = g.Dk[lane];
+        }
+        __syncthreads();
+    }
     const uint4 *text4 = reinterpret_cast<const uint4 *>(a.texts + a.offs[t]);  // 16-byte aligned by the host
     const WinIn in = a.win_in[gw];
 
@@ -281,10 +338,25 @@ __global__ void __launch_bounds__(64) text_place_kernel(TextParseArgs a)
     s_text4[64 + lane] = nxt;
     // the template's skeleton from where this window starts in it (zero padded behind its end)
     const uint32_t sk_base = in.skel_pos & ~15u;
-    {
+    if (!shared) {
         const uint4 *src = reinterpret_cast<const uint4 *>(skel + sk_base);
         s_skel4[lane] = src[lane];
         s_skel4[64 + lane] = src[64 + lane];
+    } else {
+        // the same 2 KiB through the gap map: a 16-byte group that no gap cuts is one (unaligned) load
+        uint8_t *dst = reinterpret_cast<uint8_t *>(s_skel4);
+#pragma unroll
+        for (uint32_t h = 0; h < 2; h++) {
+            const uint32_t j = lane + 64 * h, p0 = sk_base + 16 * j;
+            const uint32_t m0 = gap_map(s_G, s_D, n_trees, p0), m1 = gap_map(s_G, s_D, n_trees, p0 + 15);
+            if (m1 - m0 == 15) {
+                uint4 v;
+                __builtin_memcpy(&v, skel + m0, 16);
+                s_skel4[j] = v;
+            } else {
+                for (uint32_t b = 0; b < 16; b++) dst[16 * j + b] = skel[gap_map(s_G, s_D, n_trees, p0 + b)];
+            }
+        }
     }
 
     // ---- the states entering this lane
@@ -321,7 +393,8 @@ __global__ void __launch_bounds__(64) text_place_kernel(TextParseArgs a)
     bool mism = in.tok_pos + n_tok > n_slots;
     if (!mism)
         for (uint32_t i = lane; i < n_tok; i += 64) {
-            const TextSlot sl = slots[in.tok_pos + i];
+            const uint32_t k = in.tok_pos + i;
+            const TextSlot sl = slots[shared ? gap_map(s_Gk, s_Dk, n_trees, k) : k];
             s_slot[i] = make_uint2(sl.dst, sl.kind);
         }
     __syncthreads();
@@ -434,6 +507,7 @@ void launch_text_parse(const TextParseArgs &a, hipStream_t s)
 {
     if (!a.n) return;
     hipLaunchKernelGGL(text_index_kernel, dim3(a.n), dim3(64), 0, s, a);
+    if (a.hints) hipLaunchKernelGGL(text_hint_kernel, dim3(a.n), dim3(64), 0, s, a);
     if (a.n_windows) hipLaunchKernelGGL(text_summary_kernel, dim3(a.n_windows), dim3(64), 0, s, a);
     hipLaunchKernelGGL(text_scan_kernel, dim3(a.n), dim3(64), 0, s, a);
     if (a.n_windows) hipLaunchKernelGGL(text_place_kernel, dim3(a.n_windows), dim3(64), 0, s, a);

@@ -127,3 +127,136 @@ def test_shared_records_across_chunks_and_sizes(ver):
         exp[j] = verifier.B.STATUS_MALFORMED
     got = ver.verify_stwo_shared_records(ps[0].cfg, batch, verifier.MODE_FIXTURE)
     assert got.tolist() == exp
+
+
+# ------------------------------------------------------------------------------- shared-path proof.json on the GPU
+import json
+import random
+
+from stark_symphony_amd import binding
+from test_ingest import _text_mutant
+from test_shared_paths import _canonical_shared, _write_shared_text
+
+SHARED = binding.TEXT_JSON_SHARED
+
+
+def _agree_shared(ver, cfg, texts):
+    """GPU outcome == scalar rule (csrc/ss_text.cpp shared_text_scan_reference) for every text; same record where taken."""
+    recs, outcome = ver.read_stwo_texts(cfg, texts, SHARED)
+    taken = 0
+    for i, t in enumerate(texts):
+        want, rec = _canonical_shared(cfg, t)
+        assert (outcome[i] == 0) == want, (i, int(outcome[i]), want, t[:120], t[-120:])
+        if want:
+            assert np.array_equal(recs[i], rec), (i, np.nonzero(recs[i] != rec)[0][:8])
+            taken += 1
+    return taken
+
+
+def test_gpu_reader_takes_honest_shared_texts(ver):
+    """Six shapes (1 to 32 queries, 4 to 256 columns, both hashes, LDE 2^4 to 2^24), both separator styles, trailing
+    newline, indentation: read into shared records and expanded on the GPU; the record is the per-query record."""
+    for p in fixtures():
+        rec = verifier.stwo_record(p)
+        obj = ss.stwo_to_json(p, shared=True)
+        texts = [json.dumps(obj, separators=(",", ":")).encode(), json.dumps(obj).encode(), json.dumps(obj).encode() + b"\n",
+                 json.dumps(obj, indent=1).encode(), _write_shared_text(p.cfg, verifier.stwo_shared_record(p), 0)]
+        recs, outcome = ver.read_stwo_texts(p.cfg, texts, SHARED)
+        assert outcome.tolist() == [0] * len(texts), p.cfg
+        assert all(np.array_equal(r, rec) for r in recs), p.cfg
+        # the per-query text is not of this format: left to the host reader
+        _, out2 = ver.read_stwo_texts(p.cfg, [json.dumps(ss.stwo_to_json(p)).encode()], SHARED)
+        assert out2.tolist() == [1] or p.cfg.n_queries == 1
+
+
+def test_gpu_reader_equals_the_scalar_rule_on_shared_mutants(ver):
+    """Byte-level mutants, other hints, other numbers, texts shifted against the 1 KiB window / 16-byte lane grid (the
+    gap maps cut the template at arbitrary byte offsets), tails of every alignment."""
+    rnd = random.Random(SEED + 61)
+    total = 0
+    for p, n in zip(fixtures()[:3], (500, 2500, 300)):
+        obj = ss.stwo_to_json(p, shared=True)
+        base = json.dumps(obj, separators=(",", ":")).encode()
+        texts = [base] + [b" " * k + base for k in range(1, 40)] + [base + b" " * k for k in range(1, 40)]
+        texts += [base[:-1] + b" " * k + b"}" for k in (1, 15, 16, 17, 1000, 1023, 1024, 1025)]   # blanks inside the tail
+        for i in range(n):
+            kind = i % 4
+            if kind < 2:
+                t = _text_mutant(rnd, base)
+            elif kind == 2:
+                o = json.loads(base)
+                o["queries"][rnd.randrange(p.cfg.n_queries)] = rnd.randrange(1 << p.cfg.lde_log)
+                t = json.dumps(o, separators=(",", ":")).encode()
+            else:
+                import re
+                ms = list(re.finditer(rb"\d+", base))
+                m = ms[rnd.randrange(len(ms))]
+                t = base[:m.start()] + str(rnd.choice([0, 1, 255, 256, 2 ** 31, 2 ** 32 - 1, 2 ** 32])).encode() + base[m.end():]
+            if i % 7 == 0:
+                t = b"\n" * rnd.randrange(1, 30) + t
+            texts.append(t)
+        texts += [b"", b"}", b"]}", b"[1]}", b"1" * 3000, b" " * 5000, base[:len(base) // 2], base[len(base) // 2:]]
+        total += _agree_shared(ver, p.cfg, texts)
+    assert total > 400
+
+
+def test_shared_texts_through_the_entry_point(ver):
+    """ss_stwo_verify_texts on one batch of shared texts (GPU reader + expansion), per-query texts and .wit (GPU reader),
+    shared texts with another member order or a hint that does not fit the lists (host reader), corrupted proofs,
+    garbage: the status words of the oracle on the per-query proofs / the stage-0 codes."""
+    base = fixtures()[0]
+    cfg = base.cfg
+    qs = formats.stwo_queries(base)
+    rng = np.random.default_rng(SEED + 62)
+    proofs = [base]
+    while len(proofs) < 9:
+        c = formats.stwo_corrupt(base, rng)[0]
+        try:
+            ss.stwo_to_json(c, shared=True, queries=qs)
+            proofs.append(c)
+        except ss.MalformedProof:
+            pass
+    want_d = O.stwo_verify_batch(proofs).tolist()
+    variants, want, host = [], [], []
+    for p, w in zip(proofs, want_d):
+        obj = ss.stwo_to_json(p, shared=True, queries=qs)
+        wrong = dict(obj)
+        wrong["queries"] = [qs[1]] + qs[1:]              # two equal positions: the lists no longer have the lengths the hint implies
+        variants += [json.dumps(obj).encode(), json.dumps(obj, separators=(",", ":")).encode(), json.dumps(ss.stwo_to_json(p)).encode(),
+                     ss.stwo_to_wit(p).encode(), json.dumps(dict(reversed(list(obj.items())))).encode(), json.dumps(wrong).encode()]
+        want += [w, w, w, w, w, 2]
+        host += [0, 0, 0, 0, 1, 1]
+    variants += [b"{\"queries\":[1]}", b"nonsense", b""]
+    want += [2, 2, 2]
+    host += [1, 1, 1]
+    for n in (len(variants), 1500):
+        batch = [variants[i % len(variants)] for i in range(n)]
+        status, stats = ver.verify_stwo_texts(cfg, batch)
+        assert status.tolist() == [want[i % len(variants)] for i in range(n)]
+        assert stats["host_parsed"] == sum(host[i % len(variants)] for i in range(n))
+    status, stats = ver.verify_stwo_texts(cfg, variants[:2], fmt=SHARED)
+    assert status.tolist() == want[:2] and stats["host_parsed"] == 0
+
+
+def test_full_size_shared_texts_end_to_end(ver):
+    """2^20-row proofs as shared-path text (0.5 MB each), valid and corrupted, 400 texts over several chunks."""
+    import os
+    from conftest import GOLDEN
+    p = records.load_stwo_npz(os.path.join(GOLDEN, "stwo_trace20.npz"))[0]
+    qs = formats.stwo_queries(p)
+    rng = np.random.default_rng(SEED + 63)
+    proofs = [p]
+    while len(proofs) < 4:
+        c = formats.stwo_corrupt(p, rng)[0]
+        try:
+            verifier.stwo_shared_record(c, qs)
+            proofs.append(c)
+        except ValueError:
+            pass
+    want = O.stwo_verify_batch(proofs).tolist()
+    texts = [_write_shared_text(q.cfg, verifier.stwo_shared_record(q, qs), i % 2) for i, q in enumerate(proofs)]
+    full = len(json.dumps(ss.stwo_to_json(p), separators=(",", ":")))
+    assert len(texts[0]) < 0.86 * full
+    batch = [texts[i % 4] for i in range(400)]
+    status, stats = ver.verify_stwo_texts(p.cfg, batch)
+    assert status.tolist() == [want[i % 4] for i in range(400)] and stats["host_parsed"] == 0 and want[0] == 0

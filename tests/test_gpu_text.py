@@ -270,8 +270,10 @@ def test_stark101_device_pack_equals_host_pack(ver):
 
 
 def test_shared_path_texts_verify_like_their_per_query_form(ver):
-    """The shared-path variant of proof.json (tests/test_shared_paths.py) through ss_stwo_verify_texts: the host reader
-    undoes the sharing, the kernels verify the expanded proof; status words equal the oracle's on the per-query form."""
+    """The shared-path variant of proof.json (tests/test_shared_paths.py) through ss_stwo_verify_texts: since round 4
+    the GPU reader takes canonical ones (tests/test_gpu_shared.py; round 3: the host reader undid the sharing), the
+    expansion kernel undoes the sharing, the kernels verify the expanded proof; status words equal the oracle's on the
+    per-query form.  A shared text with its members in another order still takes the host reader."""
     base = ss.stwo_from_json(json.load(open(os.path.join(GOLDEN, "stwo_proof.json"))))
     rng = np.random.default_rng(SEED + 93)
     qs = formats.stwo_queries(base)
@@ -285,7 +287,10 @@ def test_shared_path_texts_verify_like_their_per_query_form(ver):
     want = O.stwo_verify_batch(proofs).tolist()
     status, stats = ver.verify_stwo_texts(base.cfg, texts)
     assert status.tolist() == want and want[0] == 0 and sum(1 for w in want if w) > 10
-    assert stats["host_parsed"] == len(texts)
+    assert stats["host_parsed"] == 0
+    odd = [json.dumps(dict(reversed(list(json.loads(t).items())))).encode() for t in texts[:6]]
+    status, stats = ver.verify_stwo_texts(base.cfg, odd)
+    assert status.tolist() == want[:6] and stats["host_parsed"] == 6
 
 
 def test_long_runs_and_blank_blocks_across_windows(ver):
@@ -352,3 +357,21 @@ def test_oversized_and_degenerate_texts(ver):
         assert not canonical(cfg, t, JSON)[0]
     status, stats = ver.verify_stwo_texts(cfg, texts)
     assert status.tolist() == [0] + [2] * (len(texts) - 2) + [0] and stats["host_parsed"] == len(texts) - 2
+
+
+def test_template_cache_eviction_keeps_the_templates_in_use(ver):
+    """A context keeps the device templates of a dozen (config, format) pairs.  Cycling through eight configs (three
+    formats each) must never evict a template of the config being verified: every canonical text stays on the GPU
+    reader (host_parsed 0) whatever was verified before (round 3 evicted the oldest entry even when the same call had
+    just been handed a view of it)."""
+    ps = [ss.stwo_from_json(json.load(open(os.path.join(GOLDEN, "stwo_proof.json")))),
+          ss.stwo_from_json(json.load(open(os.path.join(GOLDEN, "stwo_proof_test.json"))))]
+    for npz in ("stwo_trace16.npz", "stwo_wide256.npz", "stwo_trace16_blake2s.npz", "stwo_wide256_blake2s.npz", "stwo_trace20.npz",
+                "stwo_trace20_blake2s.npz"):
+        ps.append(records.load_stwo_npz(os.path.join(GOLDEN, npz))[0])
+    texts = [[json.dumps(ss.stwo_to_json(p), separators=(",", ":")).encode(), ss.stwo_to_wit(p).encode(),
+              json.dumps(ss.stwo_to_json(p, shared=True)).encode()] for p in ps]
+    for rnd in range(3):
+        for p, ts in zip(ps, texts):
+            status, stats = ver.verify_stwo_texts(p.cfg, ts * 2)
+            assert status.tolist() == [0] * 6 and stats["host_parsed"] == 0, (rnd, p.cfg)
