@@ -198,51 +198,113 @@ def end_to_end_s101(ver, proof, n: int):
     return out
 
 
-def end_to_end(ver, proofs, n: int):
+def end_to_end(ver, proofs, n: int, rank: int = 0, world: int = 1, dist=None):
     """Text in, verdicts out (never `value`): what a caller holding proof.json / proof.wit files sees.
-    n texts of this workload's proofs go through ss_stwo_verify_texts -- native readers on the host
-    threads, pinned staging, upload, GPU re-tiling, verification, download -- timed around the call;
-    beside it the same texts through the Python reader (formats.py) for a few proofs, one thread."""
+    n texts of this workload's proofs go through ss_stwo_verify_texts -- raw bytes staged into pinned memory, uploaded,
+    turned into records by the GPU reader, re-tiled, verified, verdicts downloaded -- timed around the call; beside it the
+    same texts through the Python reader (formats.py) for a few proofs, one thread.  Also the host-memory record paths
+    (ss_stwo_verify_records / ss_stwo_verify_shared_records).  With world > 1 every rank runs its share of the n inputs
+    at the same time (rank-local ingest, SURVEY.md 8e: the ranks share the host's cores and its links): the rates are
+    total inputs / the slowest rank's time, and `per_rank_link_GB_s` lists what each rank moved."""
+    import numpy as np
     import stark_symphony_amd as ss
-    from stark_symphony_amd import binding, verifier
+    from stark_symphony_amd import binding, distributed, verifier
     cfg = proofs[0].cfg
     distinct = proofs[:8]
-    # proof.json as the external prover prints it (compact separators, tests/data/proof.json) and proof.wit as
-    # generate_wit.py prints it
+    lo, hi = distributed.shard_range(n, rank, world)
+    n_local = hi - lo
+    # proof.json as the external prover prints it (compact separators, tests/data/proof.json), proof.wit as
+    # generate_wit.py prints it, and the shared-path proof.json (every distinct Merkle sibling once; read and expanded
+    # on the GPU since round 4)
     texts = {"json": [json.dumps(ss.stwo_to_json(p), separators=(",", ":")).encode() for p in distinct],
-             "wit": [ss.stwo_to_wit(p).encode() for p in distinct]}
+             "wit": [ss.stwo_to_wit(p).encode() for p in distinct],
+             "json_shared": [json.dumps(ss.stwo_to_json(p, shared=True), separators=(",", ":")).encode() for p in distinct]}
     out = {"proofs": n, "note": "proof text -> verdict through ss_stwo_verify_texts: raw bytes staged into pinned memory, "
                                 "uploaded, turned into records by the GPU reader (csrc/ss_textdev.hip), re-tiled, verified; "
                                 "bound by the host link, not what `value` measures"}
-    for kind, fmt in (("json", binding.TEXT_JSON), ("wit", binding.TEXT_WIT)):
-        # every text its own buffer (a copy): the staging copy then reads host memory, not eight cache-resident strings
-        batch = [texts[kind][i % len(distinct)][:1] + texts[kind][i % len(distinct)][1:] for i in range(n)]
-        ver.verify_stwo_texts(cfg, batch[:64], fmt=fmt)  # warm-up: scratch allocation, templates
-        ver.verify_stwo_texts(cfg, batch, fmt=fmt)
+    if world > 1:
+        out["ranks"] = world
+        out["host_threads_per_rank"] = int(os.environ.get("SS_HOST_THREADS", "0")) or None
+
+    def timed(call):
+        """best of three; with several ranks: all start together, the slowest one's time counts"""
         best = None
         for _ in range(3):
+            if world > 1:
+                dist.barrier()
             t0 = time.perf_counter()
-            status, st = ver.verify_stwo_texts(cfg, batch, fmt=fmt)
+            status, st = call()
             dt = time.perf_counter() - t0
             assert (status == 0).all(), "e2e: a benchmark proof was not accepted"
             if best is None or dt < best[0]:
                 best = (dt, st)
-        dt, st = best
-        t1 = time.perf_counter()
-        k = 0
-        while k < 3 or time.perf_counter() - t1 < 0.5:
-            t = texts[kind][k % len(distinct)]
-            p = ss.stwo_from_json(json.loads(t), expect=cfg) if kind == "json" else \
-                ss.stwo_from_wit(t.decode(), cfg.trace_log, cfg.pow_bits, cfg.hash)
-            verifier.stwo_record(p)
-            k += 1
-        py = k / (time.perf_counter() - t1)
-        out[kind] = {"proofs_per_s": n / dt, "total_s": dt, "text_GB_per_s": st["text_bytes"] / dt / 1e9,
-                     "stage_s": st["read_s"], "host_reader_s": st["parse_s"],
-                     "parse_share": st["parse_s"] / st["total_s"], "host_parsed_texts": st["host_parsed"],
-                     "host_threads": st["threads"], "text_bytes_per_proof": st["text_bytes"] // n,
-                     "python_reader_proofs_per_s_one_thread": py}
+        return best
+
+    def across_ranks(dt: float, link_bytes: int):
+        """-> (slowest rank's time, per-rank GB/s on the host link)"""
+        if world == 1:
+            return dt, [link_bytes / dt / 1e9]
+        import torch
+        mine = torch.tensor([dt, float(link_bytes)], dtype=torch.float64, device=ver.device)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        rows = [p.cpu().tolist() for p in parts]
+        return max(r[0] for r in rows), [r[1] / r[0] / 1e9 for r in rows]
+    for kind, fmt in (("json", binding.TEXT_JSON), ("wit", binding.TEXT_WIT), ("json_shared", binding.TEXT_AUTO)):
+        # every text its own buffer (a copy): the staging copy then reads host memory, not eight cache-resident strings
+        batch = [texts[kind][(lo + i) % len(distinct)][:1] + texts[kind][(lo + i) % len(distinct)][1:] for i in range(n_local)]
+        ver.verify_stwo_texts(cfg, batch[:64], fmt=fmt)  # warm-up: scratch allocation, templates
+        ver.verify_stwo_texts(cfg, batch, fmt=fmt)
+        dt, st = timed(lambda: ver.verify_stwo_texts(cfg, batch, fmt=fmt))
+        slowest, links = across_ranks(dt, st["text_bytes"])
+        row = {"proofs_per_s": n / slowest, "total_s": slowest, "text_GB_per_s": sum(len(b) for b in batch) * (n / max(n_local, 1)) / slowest / 1e9,
+               "stage_s": st["read_s"], "host_reader_s": st["parse_s"],
+               "parse_share": st["parse_s"] / st["total_s"], "host_parsed_texts": st["host_parsed"],
+               "host_threads": st["threads"], "text_bytes_per_proof": st["text_bytes"] // max(n_local, 1)}
+        if world > 1:
+            row["per_rank_link_GB_s"] = links
+        if rank == 0 and kind != "json_shared":
+            t1 = time.perf_counter()
+            k = 0
+            while k < 3 or time.perf_counter() - t1 < 0.5:
+                t = texts[kind][k % len(distinct)]
+                p = ss.stwo_from_json(json.loads(t), expect=cfg) if kind == "json" else \
+                    ss.stwo_from_wit(t.decode(), cfg.trace_log, cfg.pow_bits, cfg.hash)
+                verifier.stwo_record(p)
+                k += 1
+            row["python_reader_proofs_per_s_one_thread"] = k / (time.perf_counter() - t1)
+        out[kind] = row
+        del batch
+    # records in host memory -> verdicts: per-query records, and shared records (19 % fewer bytes at this shape,
+    # expanded by the GPU behind the link)
+    recs = [verifier.stwo_record(p) for p in distinct]
+    shared = [verifier.stwo_shared_record(p) for p in distinct]
+    for kind, src, call in (("records", recs, ver.verify_stwo_records), ("shared_records", shared, ver.verify_stwo_shared_records)):
+        batch = [src[(lo + i) % len(distinct)].copy() for i in range(n_local)]
+        call(cfg, batch)
+        dt, _ = timed(lambda: (call(cfg, batch), None))
+        nbytes = sum(int(b.nbytes) for b in batch)
+        slowest, links = across_ranks(dt, nbytes)
+        row = {"proofs_per_s": n / slowest, "total_s": slowest, "link_GB_per_s": nbytes * (n / max(n_local, 1)) / slowest / 1e9,
+               "bytes_per_proof": nbytes // max(n_local, 1)}
+        if world > 1:
+            row["per_rank_link_GB_s"] = links
+        out[kind] = row
+        del batch
     return out
+
+
+def granted_cores() -> int:
+    """Cores this process may really use: scheduler affinity capped by the cgroup CPU quota (what the library's
+    effective_cpus() computes)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
 
 
 def spawn_ranks(n: int) -> int:
@@ -363,6 +425,8 @@ def main() -> None:
     backend = os.environ.get("SS_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(dev_index)
     if world > 1:
+        # the ranks of one host share its granted cores: each library instance gets its share for staging / host reading
+        os.environ.setdefault("SS_HOST_THREADS", str(max(2, granted_cores() // world)))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
@@ -549,6 +613,8 @@ def main() -> None:
         total_accept = batch.accepted()
     assert total_accept == job_proofs, "accept-reduce mismatch (%d of %d)" % (total_accept, job_proofs)
 
+    # text / records in host memory -> verdicts, every rank its share at the same time (never `value`)
+    e2e = end_to_end(ver, proofs, args.e2e, rank, world, dist if world > 1 else None) if family == "stwo" and args.e2e > 0 else None
     if rank == 0:
         total = job_proofs * args.steps
         value = total / elapsed
@@ -620,8 +686,8 @@ def main() -> None:
                                      "profiles/r01_sha_calibration.txt (34.7 G), re-measured in r03_sha_calibration.txt (34.4-34.6 G)"},
             "kernels_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in timing.items()},
         }
-        if family == "stwo" and args.e2e > 0 and world == 1:
-            out["e2e"] = end_to_end(ver, proofs, args.e2e)
+        if e2e is not None:
+            out["e2e"] = e2e
         elif family == "stark101" and args.e2e > 0 and world == 1:
             out["e2e"] = end_to_end_s101(ver, proofs[0], max(args.e2e, 16384))
         if not args.no_cpu_baseline and world == 1:

@@ -82,7 +82,8 @@ extern "C" int ss_ctx_create(int device, ss_ctx **out)
     int n = ss_device_count();
     if (n <= 0) return set_err(SS_ERR_NO_DEVICE, "no HIP device visible (%s)", g_err);
     if (device < 0 || device >= n) return set_err(SS_ERR_ARG, "device %d out of range (0..%d)", device, n - 1);
-    HIP_TRY(hipSetDevice(device));
+    DeviceGuard guard(device);  // (the caller's current device is left as it was)
+    if (guard.err != hipSuccess) return set_err(SS_ERR_HIP, "cannot make device %d current: %s", device, hipGetErrorString(guard.err));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -207,7 +208,7 @@ extern "C" int ss_stwo_read_intermediates(ss_ctx *ctx, const ss_stwo_cfg *c, siz
     if (!cfg_ok(c) || !n || proof >= n) return set_err(SS_ERR_ARG, "bad config or proof index");
     const StwoLayout y = lay_of(c, n);
     const uint32_t *ws = (const uint32_t *)workspace;
-    HIP_TRY(hipSetDevice(ctx->device));
+    SS_DEVICE_GUARD(ctx);
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream_));
     // ctx[w][proof]: `rows` consecutive w of one proof are a column of a (rows x np) matrix
     auto column = [&](uint32_t *dst, const uint32_t *src, size_t pitch_words, size_t rows) {
@@ -234,7 +235,7 @@ extern "C" int ss_stwo_verify_phase_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_
                                         uint32_t *status, uint32_t *accept_count, int phases,
                                         void *stream_)
 {
-    if (!ctx) return set_err(SS_ERR_ARG, "ctx is null");
+    SS_DEVICE_GUARD(ctx);  // a caller with one context per GPU: launch on THIS context's device whatever is current
     if (!cfg_ok(c)) return set_err(SS_ERR_ARG, "unsupported stwo config");
     if (!n || !batch || !workspace || !status) return set_err(SS_ERR_ARG, "null/empty argument");
     if (n * (size_t)c->n_queries > 0x7fffffffu) return set_err(SS_ERR_ARG, "batch too large");
@@ -304,7 +305,7 @@ extern "C" int ss_s101_verify_phase_dev(ss_ctx *ctx, const ss_s101_shape *sh, si
                                         uint32_t *status, uint32_t *accept_count, int phases,
                                         void *stream_)
 {
-    if (!ctx) return set_err(SS_ERR_ARG, "ctx is null");
+    SS_DEVICE_GUARD(ctx);
     if (!shape_ok(sh)) return set_err(SS_ERR_ARG, "unsupported stark101 shape");
     if (!n || !batch || !workspace || !status) return set_err(SS_ERR_ARG, "null/empty argument");
     if (n > 0x7fffffffu) return set_err(SS_ERR_ARG, "batch too large");
@@ -483,7 +484,7 @@ static StwoRecordMap record_map(const StwoLayout &y)
 extern "C" int ss_stwo_pack_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const uint32_t *records_dev,
                                 uint32_t *batch_dev, void *stream_)
 {
-    if (!ctx) return set_err(SS_ERR_ARG, "ctx is null");
+    SS_DEVICE_GUARD(ctx);
     if (!cfg_ok(c)) return set_err(SS_ERR_ARG, "unsupported stwo config");
     if (!n || !records_dev || !batch_dev) return set_err(SS_ERR_ARG, "null/empty argument");
     if (n * (size_t)c->n_queries > 0x7fffffffu) return set_err(SS_ERR_ARG, "batch too large");
@@ -549,7 +550,7 @@ __global__ void s101_pack_kernel(S101Layout y, const uint32_t *__restrict__ rec,
 extern "C" int ss_s101_pack_dev(ss_ctx *ctx, const ss_s101_shape *sh, size_t n, const uint32_t *records_dev,
                                 uint32_t *batch_dev, void *stream_)
 {
-    if (!ctx) return set_err(SS_ERR_ARG, "ctx is null");
+    SS_DEVICE_GUARD(ctx);
     if (!shape_ok(sh)) return set_err(SS_ERR_ARG, "unsupported stark101 shape");
     if (!n || !records_dev || !batch_dev) return set_err(SS_ERR_ARG, "null/empty argument");
     if (n > 0x7fffffffu) return set_err(SS_ERR_ARG, "batch too large");
@@ -563,6 +564,17 @@ extern "C" int ss_s101_pack_dev(ss_ctx *ctx, const ss_s101_shape *sh, size_t n, 
     t.end("s101_pack");
     HIP_TRY(hipGetLastError());
     return SS_OK;
+}
+
+// threads of a staging copy into pinned memory (a few saturate it; SS_STAGE_THREADS: tuning knob of the evidence scripts)
+size_t ss::stage_threads()
+{
+    static const size_t n = [] {
+        const char *e = getenv("SS_STAGE_THREADS");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? (size_t)v : (size_t)8;
+    }();
+    return n;
 }
 
 int ss::hp_reserve(ss_ctx *ctx, int slot, size_t bytes)
@@ -603,7 +615,7 @@ extern "C" int ss_stwo_verify_records(ss_ctx *ctx, const ss_stwo_cfg *c, size_t 
     if (!n) return set_err(SS_ERR_ARG, "empty batch");
     if (n * (size_t)c->n_queries > 0x7fffffffu) return set_err(SS_ERR_ARG, "batch too large");
     std::lock_guard<std::mutex> lock(ctx->mu);  // the context's scratch: one such call at a time
-    HIP_TRY(hipSetDevice(ctx->device));
+    SS_DEVICE_GUARD(ctx);
     const size_t W = ss_stwo_record_words(c);
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, (64u << 20) / (W * 4)));
     // (the first chunks are small and double: nothing overlaps the staging of the first one)
@@ -633,7 +645,7 @@ extern "C" int ss_stwo_verify_records(ss_ctx *ctx, const ss_stwo_cfg *c, size_t 
             HIP_TRY(hipEventSynchronize(hp.pinned_free[buf]));  // previous upload from this buffer done
             uint32_t *stage = (uint32_t *)hp.pinned[buf];
             parallel_for(cnt, [&](size_t i) { copy_streaming(stage + i * W, records[lo + i], W * 4); },
-                         std::max<size_t>(1, std::min<size_t>(8, cnt * W * 4 / (1u << 20))));
+                         std::max<size_t>(1, std::min<size_t>(stage_threads(), cnt * W * 4 / (1u << 20))));
             HIP_TRY(hipMemcpyAsync(rec_dev + lo * W, stage, cnt * W * 4, hipMemcpyHostToDevice, s));
             HIP_TRY(hipEventRecord(hp.pinned_free[buf], s));
             // the chunk that has just been queued: re-tile and verify it behind its upload (batch and workspace are
@@ -675,7 +687,7 @@ int ss::s101_verify_records_locked(ss_ctx *ctx, const ss_s101_shape *sh, size_t 
     if (!shape_ok(sh)) return set_err(SS_ERR_ARG, "unsupported stark101 shape");
     if (!n) return set_err(SS_ERR_ARG, "empty batch");
     if (n > 0x7fffffffu) return set_err(SS_ERR_ARG, "batch too large");
-    HIP_TRY(hipSetDevice(ctx->device));
+    SS_DEVICE_GUARD(ctx);
     const size_t words = ss_s101_batch_words(sh, n), wsb = ss_s101_workspace_bytes(sh, n);
     int rc;
     if ((rc = hp_reserve(ctx, 1, words * 4))) return rc;
@@ -915,7 +927,7 @@ extern "C" int ss_selftest(ss_ctx *ctx, int op, size_t n, const uint32_t *in_hos
     static const int in_w[6] = {16, 2, 8, 1, 2, 8}, out_w[6] = {8, 4, 8, 2, 4, 16};
     if (!ctx || !in_host || !out_host || op < 0 || op > 5 || !n) return set_err(SS_ERR_ARG, "bad argument");
     std::lock_guard<std::mutex> lock(ctx->mu);
-    HIP_TRY(hipSetDevice(ctx->device));
+    SS_DEVICE_GUARD(ctx);
     DevBuf a, b;
     HIP_TRY(hipMalloc(&a.p, n * in_w[op] * 4));
     HIP_TRY(hipMalloc(&b.p, n * out_w[op] * 4));

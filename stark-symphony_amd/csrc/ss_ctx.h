@@ -22,6 +22,31 @@ namespace ss {
             return ss::set_err(SS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));    \
     } while (0)
 
+// Makes the context's device current for the calling thread while an entry point runs and restores the caller's
+// afterwards: a process that holds one context per GPU (the C / Rust caller of INTEGRATION.md) may call any entry
+// point of any context from any thread, whatever device is current there.  Not a stream operation: capturable.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err;
+    explicit DeviceGuard(int device)
+    {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) {
+            err = hipSetDevice(device);
+            switched = err == hipSuccess;
+        }
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define SS_DEVICE_GUARD(ctx)                                                                                   \
+    if (!(ctx)) return ss::set_err(SS_ERR_ARG, "ctx is null");                                                 \
+    ss::DeviceGuard device_guard_((ctx)->device);                                                              \
+    if (device_guard_.err != hipSuccess)                                                                       \
+        return ss::set_err(SS_ERR_HIP, "cannot make device %d current: %s", (ctx)->device, hipGetErrorString(device_guard_.err))
+
 struct TimedSpan {
     const char *name;
     hipEvent_t start, stop;
@@ -105,6 +130,7 @@ struct Timer {
 
 int hp_reserve(ss_ctx *ctx, int slot, size_t bytes);  // grow-only device buffer `slot` of the host path (ss_api.hip)
 int hp_pinned(ss_ctx *ctx, size_t bytes);             // its two pinned staging buffers, streams and events
+size_t stage_threads();
 int shared_expand_launch(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const uint32_t *shared_dev, const uint64_t *offs_dev,
                          uint64_t capacity_stride, uint32_t *records_dev, uint32_t *outcome_dev, hipStream_t s,
                          const uint8_t *only_fmt = nullptr, const uint32_t *hint_pos = nullptr, uint32_t hint_stride = 0);  // ss_shared.hip

@@ -12,6 +12,7 @@
 #include <sched.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -1199,6 +1200,12 @@ unsigned effective_cpus()
             const unsigned cores = (unsigned)((quota + period - 1) / period);
             if (cores >= 1 && cores < n) n = cores;
         }
+    }
+    // Several library processes on one host (one per GPU: bench.py --gpus N, torch.distributed.run) share the granted
+    // cores: each is told its share, or every rank would start a pool as large as the whole grant.
+    if (const char *e = getenv("SS_HOST_THREADS")) {
+        const long v = atol(e);
+        if (v >= 1 && (unsigned long)v < n) n = (unsigned)v;
     }
     return n ? n : 1;
 }

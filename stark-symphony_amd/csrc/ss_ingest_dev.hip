@@ -503,7 +503,7 @@ int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *con
     if (n * (size_t)c->n_queries > 0x7fffffffu) return set_err(SS_ERR_ARG, "batch too large");
     std::lock_guard<std::mutex> lock(ctx->mu);  // the context's scratch: one such call at a time
     const double t0 = now_s();
-    HIP_TRY(hipSetDevice(ctx->device));
+    SS_DEVICE_GUARD(ctx);
     int rc;
     if ((rc = ensure_streams(ctx->tp))) return rc;
     Family F;
@@ -540,7 +540,7 @@ int s101_ingest_dev(ss_ctx *ctx, size_t n, const char *const *texts, const size_
     if (n > 0x7fffffffu) return set_err(SS_ERR_ARG, "batch too large");
     std::lock_guard<std::mutex> lock(ctx->mu);
     const double t0 = now_s();
-    HIP_TRY(hipSetDevice(ctx->device));
+    SS_DEVICE_GUARD(ctx);
     int rc;
     if ((rc = ensure_streams(ctx->tp))) return rc;
     ss_stwo_cfg key{};  // the template cache is keyed by a config: stark101 uses an impossible one (0 columns)
@@ -611,7 +611,7 @@ int stwo_read_texts_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char 
     const bool sh_fmt = c && fmt == SS_TEXT_JSON_SHARED;
     if ((c && !cfg_ok(c)) || !n || (fmt != SS_TEXT_JSON && fmt != SS_TEXT_WIT && !sh_fmt)) return set_err(SS_ERR_ARG, "bad argument");
     std::lock_guard<std::mutex> lock(ctx->mu);
-    HIP_TRY(hipSetDevice(ctx->device));
+    SS_DEVICE_GUARD(ctx);
     TextPath &tp = ctx->tp;
     int rc;
     if ((rc = ensure_streams(tp))) return rc;

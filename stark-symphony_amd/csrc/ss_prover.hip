@@ -10,6 +10,7 @@
 
 #include "../../include/ss_prover.h"
 #include "ss_channel.h"
+#include "ss_ctx.h"
 #include "ss_fields.h"
 #include "ss_hash.h"
 #include "ss_layout.h"
@@ -532,9 +533,10 @@ __global__ void p_pow_kernel(Dig digest_native, uint64_t target, uint64_t start,
 // =============================================================================== C ABI
 static QM31 q4(const uint32_t v[4]) { return QM31{v[0], v[1], v[2], v[3]}; }
 
-extern "C" int ss_p_trace(ss_ctx *, uint32_t n_log, uint32_t n_cols, uint32_t seed_term, uint32_t *cols_out,
+extern "C" int ss_p_trace(ss_ctx *ctx, uint32_t n_log, uint32_t n_cols, uint32_t seed_term, uint32_t *cols_out,
                           void *stream)
 {
+    SS_DEVICE_GUARD(ctx);
     if (!cols_out || n_log > 26 || !n_cols) return ss_internal_set_err(SS_ERR_ARG, "ss_p_trace: bad argument");
     const uint32_t n = 1u << n_log;
     hipLaunchKernelGGL(p_trace_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, n, n_cols,
@@ -543,9 +545,10 @@ extern "C" int ss_p_trace(ss_ctx *, uint32_t n_log, uint32_t n_cols, uint32_t se
     return SS_OK;
 }
 
-extern "C" int ss_p_twiddles(ss_ctx *, uint32_t m, uint32_t *tw_out, uint32_t *itw_out, uint32_t *hx_out,
+extern "C" int ss_p_twiddles(ss_ctx *ctx, uint32_t m, uint32_t *tw_out, uint32_t *itw_out, uint32_t *hx_out,
                              void *stream)
 {
+    SS_DEVICE_GUARD(ctx);
     if (!tw_out || !itw_out || m < 1 || m > 28) return ss_internal_set_err(SS_ERR_ARG, "ss_p_twiddles: bad argument");
     hipLaunchKernelGGL(p_twiddles_kernel, dim3(blocks_for(1u << (m - 1))), dim3(256), 0, (hipStream_t)stream, m,
                        tw_out, itw_out, hx_out);
@@ -553,9 +556,10 @@ extern "C" int ss_p_twiddles(ss_ctx *, uint32_t m, uint32_t *tw_out, uint32_t *i
     return SS_OK;
 }
 
-extern "C" int ss_p_fft(ss_ctx *, uint32_t m, uint32_t ncols, uint32_t *data, const uint32_t *tw, int inverse,
+extern "C" int ss_p_fft(ss_ctx *ctx, uint32_t m, uint32_t ncols, uint32_t *data, const uint32_t *tw, int inverse,
                         void *stream)
 {
+    SS_DEVICE_GUARD(ctx);
     if (!data || !tw || m < 1 || m > 28 || !ncols) return ss_internal_set_err(SS_ERR_ARG, "ss_p_fft: bad argument");
     // 2^-m mod P = 2^(31-m) because 2^31 == 1
     const uint32_t scale = (1u << ((31 - (m % 31)) % 31)) % M31_P;
@@ -597,6 +601,7 @@ extern "C" int ss_p_fft(ss_ctx *, uint32_t m, uint32_t ncols, uint32_t *data, co
 extern "C" int ss_p_lde(ss_ctx *ctx, uint32_t k, uint32_t m, uint32_t ncols, const uint32_t *coefs, uint32_t *out,
                         const uint32_t *tw, void *stream)
 {
+    SS_DEVICE_GUARD(ctx);
     if (!coefs || !out || !tw || m < 1 || m > 28 || k > m || !ncols) return ss_internal_set_err(SS_ERR_ARG, "ss_p_lde: bad argument");
     const uint32_t z = m - k;
     const uint32_t np = (m + 7) / 8, base = m / np, extra = m % np;
@@ -627,9 +632,10 @@ extern "C" int ss_p_lde(ss_ctx *ctx, uint32_t k, uint32_t m, uint32_t ncols, con
     return SS_OK;
 }
 
-extern "C" int ss_p_hash_rows(ss_ctx *, uint32_t hash, size_t n, uint32_t w, const uint32_t *cols,
+extern "C" int ss_p_hash_rows(ss_ctx *ctx, uint32_t hash, size_t n, uint32_t w, const uint32_t *cols,
                               size_t col_stride, uint32_t *out, void *stream)
 {
+    SS_DEVICE_GUARD(ctx);
     if (!cols || !out || !n || !w || hash > 1) return ss_internal_set_err(SS_ERR_ARG, "ss_p_hash_rows: bad argument");
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, n, w, cols, col_stride, out);
@@ -647,8 +653,9 @@ extern "C" int ss_p_hash_rows(ss_ctx *, uint32_t hash, size_t n, uint32_t w, con
     return SS_OK;
 }
 
-extern "C" int ss_p_hash_qm31(ss_ctx *, uint32_t hash, size_t n, const uint32_t *vals, uint32_t *out, void *stream)
+extern "C" int ss_p_hash_qm31(ss_ctx *ctx, uint32_t hash, size_t n, const uint32_t *vals, uint32_t *out, void *stream)
 {
+    SS_DEVICE_GUARD(ctx);
     if (!vals || !out || !n || hash > 1) return ss_internal_set_err(SS_ERR_ARG, "ss_p_hash_qm31: bad argument");
     if (hash)
         hipLaunchKernelGGL(p_hash_qm31_kernel<1>, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, n, vals, out);
@@ -658,8 +665,9 @@ extern "C" int ss_p_hash_qm31(ss_ctx *, uint32_t hash, size_t n, const uint32_t 
     return SS_OK;
 }
 
-extern "C" int ss_p_merkle(ss_ctx *, uint32_t hash, size_t n_leaves, uint32_t *levels, void *stream)
+extern "C" int ss_p_merkle(ss_ctx *ctx, uint32_t hash, size_t n_leaves, uint32_t *levels, void *stream)
 {
+    SS_DEVICE_GUARD(ctx);
     if (!levels || !n_leaves || (n_leaves & (n_leaves - 1)) || hash > 1)
         return ss_internal_set_err(SS_ERR_ARG, "ss_p_merkle: bad argument");
     size_t off = 0;
@@ -678,9 +686,10 @@ extern "C" int ss_p_merkle(ss_ctx *, uint32_t hash, size_t n_leaves, uint32_t *l
     return SS_OK;
 }
 
-extern "C" int ss_p_composition(ss_ctx *, uint32_t n_log, uint32_t n_cols, const uint32_t *ev, const uint32_t *hx_c,
+extern "C" int ss_p_composition(ss_ctx *ctx, uint32_t n_log, uint32_t n_cols, const uint32_t *ev, const uint32_t *hx_c,
                                 const uint32_t alpha[4], uint32_t *out, void *stream)
 {
+    SS_DEVICE_GUARD(ctx);
     if (!ev || !hx_c || !alpha || !out || n_log < 1 || n_log > 26)
         return ss_internal_set_err(SS_ERR_ARG, "ss_p_composition: bad argument");
     hipLaunchKernelGGL(p_composition_kernel, dim3(blocks_for(1u << (n_log + 1))), dim3(256), 0, (hipStream_t)stream,
@@ -690,9 +699,10 @@ extern "C" int ss_p_composition(ss_ctx *, uint32_t n_log, uint32_t n_cols, const
 }
 
 // factors: m QM31 values on the HOST (y, x, pi(x), pi^2(x), ...), bit 0 first
-extern "C" int ss_p_eval_at_point(ss_ctx *, uint32_t m, const uint32_t *coeffs, const uint32_t *factors_host,
+extern "C" int ss_p_eval_at_point(ss_ctx *ctx, uint32_t m, const uint32_t *coeffs, const uint32_t *factors_host,
                                   uint32_t *scratch, uint32_t *out, void *stream)
 {
+    SS_DEVICE_GUARD(ctx);
     if (!coeffs || !factors_host || !scratch || !out || m < 1 || m > 28)
         return ss_internal_set_err(SS_ERR_ARG, "ss_p_eval_at_point: bad argument");
     hipStream_t s = (hipStream_t)stream;
@@ -713,10 +723,11 @@ extern "C" int ss_p_eval_at_point(ss_ctx *, uint32_t m, const uint32_t *coeffs, 
 
 // all `ncols` columns (stride col_stride words) at one point: m launches instead of m per column;
 // scratch: ncols * 3 * 2^m words; out[ncols][4]
-extern "C" int ss_p_eval_at_point_batch(ss_ctx *, uint32_t m, uint32_t ncols, const uint32_t *coeffs,
+extern "C" int ss_p_eval_at_point_batch(ss_ctx *ctx, uint32_t m, uint32_t ncols, const uint32_t *coeffs,
                                         size_t col_stride, const uint32_t *factors_host, uint32_t *scratch,
                                         uint32_t *out, void *stream)
 {
+    SS_DEVICE_GUARD(ctx);
     if (!coeffs || !factors_host || !scratch || !out || m < 1 || m > 28 || !ncols || ncols > 65535)
         return ss_internal_set_err(SS_ERR_ARG, "ss_p_eval_at_point_batch: bad argument");
     hipStream_t s = (hipStream_t)stream;
@@ -737,9 +748,10 @@ extern "C" int ss_p_eval_at_point_batch(ss_ctx *, uint32_t m, uint32_t ncols, co
     return SS_OK;
 }
 
-extern "C" int ss_p_channel_fri_layer(ss_ctx *, uint32_t hash, uint32_t *state_dev, const uint32_t *root_dev,
+extern "C" int ss_p_channel_fri_layer(ss_ctx *ctx, uint32_t hash, uint32_t *state_dev, const uint32_t *root_dev,
                                       uint32_t *alpha_out_dev, uint32_t *root_out_dev, void *stream)
 {
+    SS_DEVICE_GUARD(ctx);
     if (!state_dev || !root_dev || !alpha_out_dev || !root_out_dev || hash > 1)
         return ss_internal_set_err(SS_ERR_ARG, "ss_p_channel_fri_layer: bad argument");
     if (hash)
@@ -752,9 +764,10 @@ extern "C" int ss_p_channel_fri_layer(ss_ctx *, uint32_t hash, uint32_t *state_d
     return SS_OK;
 }
 
-extern "C" int ss_p_fri_fold_dev(ss_ctx *, size_t n_out, const uint32_t *in, const uint32_t *coord_inv,
+extern "C" int ss_p_fri_fold_dev(ss_ctx *ctx, size_t n_out, const uint32_t *in, const uint32_t *coord_inv,
                                  const uint32_t *alpha_dev, uint32_t *out, void *stream)
 {
+    SS_DEVICE_GUARD(ctx);
     if (!in || !coord_inv || !alpha_dev || !out || !n_out)
         return ss_internal_set_err(SS_ERR_ARG, "ss_p_fri_fold_dev: bad argument");
     hipLaunchKernelGGL(p_fri_fold_dev_kernel, dim3(blocks_for(n_out)), dim3(256), 0, (hipStream_t)stream, n_out, in,
@@ -763,11 +776,12 @@ extern "C" int ss_p_fri_fold_dev(ss_ctx *, size_t n_out, const uint32_t *in, con
     return SS_OK;
 }
 
-extern "C" int ss_p_quotients(ss_ctx *, uint32_t lde_log, uint32_t n_cols, const uint32_t *trace_lde,
+extern "C" int ss_p_quotients(ss_ctx *ctx, uint32_t lde_log, uint32_t n_cols, const uint32_t *trace_lde,
                               const uint32_t *cp_lde, uint32_t cp_log, const uint32_t *hx_hy, const uint32_t *bcoef,
                               const uint32_t p[8], const uint32_t p2[8], const uint32_t sums_alpha16[20],
                               uint32_t *out, void *stream)
 {
+    SS_DEVICE_GUARD(ctx);
     if (!trace_lde || !cp_lde || !hx_hy || !bcoef || !p || !p2 || !sums_alpha16 || !out || lde_log < 2 || lde_log > 28 ||
         (cp_log != lde_log && cp_log + 1 != lde_log))
         return ss_internal_set_err(SS_ERR_ARG, "ss_p_quotients: bad argument");
@@ -782,9 +796,10 @@ extern "C" int ss_p_quotients(ss_ctx *, uint32_t lde_log, uint32_t n_cols, const
     return SS_OK;
 }
 
-extern "C" int ss_p_fri_fold(ss_ctx *, size_t n_out, const uint32_t *in, const uint32_t *coord_inv,
+extern "C" int ss_p_fri_fold(ss_ctx *ctx, size_t n_out, const uint32_t *in, const uint32_t *coord_inv,
                              const uint32_t alpha[4], uint32_t *out, void *stream)
 {
+    SS_DEVICE_GUARD(ctx);
     if (!in || !coord_inv || !alpha || !out || !n_out) return ss_internal_set_err(SS_ERR_ARG, "ss_p_fri_fold: bad argument");
     hipLaunchKernelGGL(p_fri_fold_kernel, dim3(blocks_for(n_out)), dim3(256), 0, (hipStream_t)stream, n_out, in,
                        coord_inv, q4(alpha), out);
@@ -792,9 +807,10 @@ extern "C" int ss_p_fri_fold(ss_ctx *, size_t n_out, const uint32_t *in, const u
     return SS_OK;
 }
 
-extern "C" int ss_p_pow(ss_ctx *, uint32_t hash, const uint32_t digest[8], uint64_t target, uint64_t start,
+extern "C" int ss_p_pow(ss_ctx *ctx, uint32_t hash, const uint32_t digest[8], uint64_t target, uint64_t start,
                         uint64_t count, uint64_t *nonce_out_dev, void *stream)
 {
+    SS_DEVICE_GUARD(ctx);
     if (!digest || !nonce_out_dev || !count || hash > 1) return ss_internal_set_err(SS_ERR_ARG, "ss_p_pow: bad argument");
     hipStream_t s = (hipStream_t)stream;
     P_TRY(hipMemsetAsync(nonce_out_dev, 0xff, 8, s));

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/ss_prover.h"
+#include "ss_ctx.h"
 #include "ss_fields.h"
 
 extern "C" int ss_internal_set_err(int code, const char *msg);
@@ -131,25 +132,28 @@ using namespace ss;
         if (e_ != hipSuccess) return ss_internal_set_err(SS_ERR_HIP, hipGetErrorString(e_)); \
     } while (0)
 
-extern "C" int ss_p101_trace_poly(ss_ctx *, uint32_t seed, uint32_t *trace_out, uint32_t *coef_out, void *stream)
+extern "C" int ss_p101_trace_poly(ss_ctx *ctx, uint32_t seed, uint32_t *trace_out, uint32_t *coef_out, void *stream)
 {
+    SS_DEVICE_GUARD(ctx);
     if (!trace_out || !coef_out) return ss_internal_set_err(SS_ERR_ARG, "ss_p101_trace_poly: null pointer");
     hipLaunchKernelGGL(p101_trace_poly_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, seed, trace_out, coef_out);
     P101_TRY(hipGetLastError());
     return SS_OK;
 }
 
-extern "C" int ss_p101_lde(ss_ctx *, const uint32_t *coef, uint32_t *out, void *stream)
+extern "C" int ss_p101_lde(ss_ctx *ctx, const uint32_t *coef, uint32_t *out, void *stream)
 {
+    SS_DEVICE_GUARD(ctx);
     if (!coef || !out) return ss_internal_set_err(SS_ERR_ARG, "ss_p101_lde: null pointer");
     hipLaunchKernelGGL(p101_lde_kernel, dim3((1u << kLdeLog) / 256), dim3(256), 0, (hipStream_t)stream, coef, out);
     P101_TRY(hipGetLastError());
     return SS_OK;
 }
 
-extern "C" int ss_p101_composition(ss_ctx *, const uint32_t *p_ev, const uint32_t alphas[3], uint32_t claim,
+extern "C" int ss_p101_composition(ss_ctx *ctx, const uint32_t *p_ev, const uint32_t alphas[3], uint32_t claim,
                                    uint32_t *out, void *stream)
 {
+    SS_DEVICE_GUARD(ctx);
     if (!p_ev || !alphas || !out) return ss_internal_set_err(SS_ERR_ARG, "ss_p101_composition: null pointer");
     hipLaunchKernelGGL(p101_composition_kernel, dim3((1u << kLdeLog) / 256), dim3(256), 0, (hipStream_t)stream, p_ev,
                        alphas[0], alphas[1], alphas[2], claim, out);
@@ -157,9 +161,10 @@ extern "C" int ss_p101_composition(ss_ctx *, const uint32_t *p_ev, const uint32_
     return SS_OK;
 }
 
-extern "C" int ss_p101_fold(ss_ctx *, uint32_t layer, uint32_t len, uint32_t beta, const uint32_t *in,
+extern "C" int ss_p101_fold(ss_ctx *ctx, uint32_t layer, uint32_t len, uint32_t beta, const uint32_t *in,
                             uint32_t *out, void *stream)
 {
+    SS_DEVICE_GUARD(ctx);
     if (!in || !out || len < 2 || (len & (len - 1)) || len != (1u << kLdeLog) >> layer)
         return ss_internal_set_err(SS_ERR_ARG, "ss_p101_fold: bad argument");
     const uint32_t half = len / 2;

@@ -202,7 +202,7 @@ extern "C" int ss_stwo_expand_shared_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size
     if (!cfg_ok(c)) return set_err(SS_ERR_ARG, "unsupported stwo config");
     if (!n || !shared_dev || !offs_dev || !records_dev || !outcome_dev) return set_err(SS_ERR_ARG, "null/empty argument");
     if (n > 0x7fffffffu) return set_err(SS_ERR_ARG, "batch too large");
-    HIP_TRY(hipSetDevice(ctx->device));
+    SS_DEVICE_GUARD(ctx);
     return shared_expand_launch(ctx, c, n, shared_dev, offs_dev, 0, records_dev, outcome_dev, (hipStream_t)stream);
 }
 
@@ -220,7 +220,7 @@ extern "C" int ss_stwo_verify_shared_records(ss_ctx *ctx, const ss_stwo_cfg *c, 
     for (size_t i = 0; i < n; i++)
         if (!shared[i]) return set_err(SS_ERR_ARG, "record %zu is null", i);
     std::lock_guard<std::mutex> lock(ctx->mu);  // the context's scratch: one such call at a time
-    HIP_TRY(hipSetDevice(ctx->device));
+    SS_DEVICE_GUARD(ctx);
     // A record longer than any shared record of this config can be is malformed whatever it holds: only its
     // fixed words travel (the kernel then sees a size that cannot match and refuses it).
     const size_t fixed = ss_stwo_shared_fixed_words(c);
@@ -276,7 +276,7 @@ extern "C" int ss_stwo_verify_shared_records(ss_ctx *ctx, const ss_stwo_cfg *c, 
             for (size_t i = 0; i < cnt; i++) { offs[i] = o; o += sent(lo + i); }
             offs[cnt] = o;
             parallel_for(cnt, [&](size_t i) { copy_streaming(stage + offs[i], shared[lo + i], sent(lo + i) * 4); },
-                         std::max<size_t>(1, std::min<size_t>(8, o * 4 / (1u << 20))));
+                         std::max<size_t>(1, std::min<size_t>(stage_threads(), o * 4 / (1u << 20))));
             for (size_t i = 0; i < cnt; i++)
                 if (words[lo + i] > max_words)  // only the fixed words were sent: an impossible count makes the kernel refuse them
                     stage[offs[i] + shared_map(c->n_cols, c->lde_log, c->n_queries, c->n_layers).cnt] = 0xffffffffu;

@@ -58,6 +58,68 @@ def test_sharded_verify_gloo(tmp_path, world, n):
     assert [(s == 0) for s in allst] == [bool(i % 3) for i in range(n)]
 
 
+def _files_worker(rank: int, world: int, port: int, paths, out_dir: str) -> None:
+    sys.path.insert(0, ROOT)
+    import builtins
+    import json
+    import torch.distributed as dist
+    import stark_symphony_amd as ss
+    from stark_symphony_amd import distributed
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    opened = []
+
+    def verify_files(ps):  # stands in for Verifier.verify_stwo_files: reads each file it is given, once
+        out = []
+        for p in ps:
+            opened.append(p)
+            try:
+                proof = ss.stark101_from_json(json.load(builtins.open(p)))
+                out.append(int(O.s101_verify_batch([proof], 1)[0]))
+            except (OSError, ValueError, ss.MalformedProof):
+                out.append(2)
+        return np.array(out, dtype=np.uint32)
+    local, accepted, total, allst = distributed.verify_files_sharded(paths, verify_files, gather_status=True)
+    np.savez(os.path.join(out_dir, "f%d.npz" % rank), local=local, accepted=accepted, total=total, allst=allst,
+             opened=np.array(opened, dtype=object))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_files_each_rank_opens_only_its_slice(tmp_path, world):
+    """verify_files_sharded: the names are global, the reads are rank-local (stwo-verifier/Makefile:17-18
+    hands one file per process).  Files of OTHER ranks' slices do not even have to exist on this rank's box: here each
+    rank's foreign files are checked never to have been opened."""
+    import json
+    import stark_symphony_amd as ss
+    from stark_symphony_amd import formats
+    from stark_symphony_amd.distributed import shard_range
+    base = ss.stark101_from_json(json.load(open(os.path.join(ROOT, "tests", "golden", "stark101_proof.json"))))
+    rng = np.random.default_rng(77)
+    n, paths, want = 11, [], []
+    for i in range(n):
+        p = tmp_path / ("p%02d.json" % i)
+        if i == 4:
+            want.append(2)                                  # absent file: stage-0 verdict, no exception
+        else:
+            proof = base if i % 3 else formats.stark101_corrupt(base, rng)[0]
+            p.write_text(json.dumps(ss.stark101_to_json(proof)))
+            want.append(None)
+        paths.append(str(p))
+    port = _free_port()
+    mp.spawn(_files_worker, args=(world, port, paths, str(tmp_path)), nprocs=world, join=True)
+    res = [np.load(os.path.join(tmp_path, "f%d.npz" % r), allow_pickle=True) for r in range(world)]
+    for r, d in enumerate(res):
+        lo, hi = shard_range(n, r, world)
+        assert list(d["opened"]) == paths[lo:hi]
+        assert int(d["total"]) == n and np.array_equal(d["allst"], res[0]["allst"])
+    allst = res[0]["allst"]
+    assert allst[4] == 2 and all((allst[i] == 0) == bool(i % 3) for i in range(n) if i != 4)
+    assert int(res[0]["accepted"]) == int((allst == 0).sum())
+
+
 def test_shard_range_is_a_partition():
     from stark_symphony_amd.distributed import shard_range
     for n in (0, 1, 7, 64, 65536):

@@ -45,11 +45,19 @@ def test_bench_two_ranks_share_one_gpu():
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
                         "--gpus", "2", "--workload", "stwo_fixture", "--proofs-per-gpu", "512", "--steps", "4",
-                        "--warmup", "1"], capture_output=True, text=True, timeout=900, env=env)
+                        "--warmup", "1", "--e2e", "301"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["proofs_per_gpu"] == 512 and "cpu_baseline" not in d
     assert abs(d["value"] - 2 * 512 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    # rank-local ingest under world > 1: every rank its share of the 301 inputs at the same time, the
+    # host's cores divided between the ranks, what each rank moved over its link reported
+    e = d["e2e"]
+    assert e["ranks"] == 2 and e["proofs"] == 301 and e["host_threads_per_rank"] >= 2
+    for kind in ("json", "wit", "json_shared", "records", "shared_records"):
+        assert e[kind]["proofs_per_s"] > 0 and len(e[kind]["per_rank_link_GB_s"]) == 2, kind
+    assert e["json"]["host_threads"] == e["host_threads_per_rank"] and e["json_shared"]["host_parsed_texts"] == 0
+    assert e["shared_records"]["bytes_per_proof"] < e["records"]["bytes_per_proof"]
 
 
 @pytest.mark.parametrize("n", [2, 4])  # the pytest process + 4 ranks: the GPU box allows 6 processes on its card
@@ -60,7 +68,7 @@ def test_bench_spawns_its_own_ranks(n):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(SS_BENCH_SHARE_GPU="1", SS_BENCH_BACKEND="gloo")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--workload",
-                        "stwo_fixture", "--proofs-per-gpu", "256", "--steps", "3", "--warmup", "1"],
+                        "stwo_fixture", "--proofs-per-gpu", "256", "--steps", "3", "--warmup", "1", "--e2e", "64"],
                        capture_output=True, text=True, timeout=1200, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
@@ -76,7 +84,7 @@ def test_bench_strong_scaling_splits_one_batch(n, batch):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(SS_BENCH_SHARE_GPU="1", SS_BENCH_BACKEND="gloo")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--workload",
-                        "stwo_fixture", "--batch", str(batch), "--steps", "3", "--warmup", "1"],
+                        "stwo_fixture", "--batch", str(batch), "--steps", "3", "--warmup", "1", "--e2e", "0"],
                        capture_output=True, text=True, timeout=1200, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)

@@ -789,3 +789,52 @@ def test_empty_batches_have_empty_answers(ver, stwo_prod):
     assert st.shape == (0,) and stats["text_bytes"] == 0
     st, stats = ver.verify_stark101_files([])
     assert st.shape == (0,)
+
+
+def test_two_contexts_in_one_process(ver, stwo_prod):
+    """the device entry points bind the context's device themselves (csrc/ss_ctx.h DeviceGuard), so a
+    process may hold several contexts -- the C / Rust caller of INTEGRATION.md holds one per GPU.  On a one-GPU box:
+    two contexts on device 0, used alternately and from two threads at once, each with its own batches and streams,
+    give the oracle's status words; the caller's current device is what it was."""
+    import threading
+    import torch
+    rng = np.random.default_rng(SEED + 300)
+    proofs = [stwo_prod] + [formats.stwo_corrupt(stwo_prod, rng)[0] for _ in range(23)]
+    want = O.stwo_verify_batch(proofs, O.MODE_FIXTURE)
+    other = verifier.Verifier(0)
+    before = torch.cuda.current_device()
+    got = {}
+
+    def work(name, v, reps):
+        for r in range(reps):
+            got[(name, r)] = v.verify_stwo(proofs, verifier.MODE_FIXTURE, cfg=stwo_prod.cfg)
+    work("a", ver, 1)
+    work("b", other, 1)
+    ts = [threading.Thread(target=work, args=(n, v, 4)) for n, v in (("ta", ver), ("tb", other))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert len(got) == 10 and all(np.array_equal(g, want) for g in got.values())
+    assert torch.cuda.current_device() == before
+    other.close()
+
+
+@pytest.mark.skipif(__import__("torch").cuda.device_count() < 2, reason="needs two GPUs")
+def test_context_on_a_device_that_is_not_current(stwo_prod):
+    """A context on device 1 while device 0 is current: the library launches on device 1 (records path: its own
+    streams and buffers) and leaves device 0 current."""
+    import torch
+    torch.cuda.set_device(0)
+    v1 = verifier.Verifier.__new__(verifier.Verifier)
+    import ctypes as C
+    ctx = C.c_void_p()
+    verifier.B.check(verifier.B.lib().ss_ctx_create(1, C.byref(ctx)))
+    v1.ctx, v1.index, v1.device, v1.timing, v1.stwo_flags = ctx, 1, torch.device("cuda", 1), False, 0
+    rng = np.random.default_rng(SEED + 301)
+    proofs = [stwo_prod] + [formats.stwo_corrupt(stwo_prod, rng)[0] for _ in range(7)]
+    want = O.stwo_verify_batch(proofs, O.MODE_FIXTURE)
+    assert torch.cuda.current_device() == 0
+    got = v1.verify_stwo_records(stwo_prod.cfg, [verifier.stwo_record(p) for p in proofs])
+    assert np.array_equal(got, want) and torch.cuda.current_device() == 0
+    v1.close()

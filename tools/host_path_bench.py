@@ -14,11 +14,13 @@ sys.path.insert(0, ROOT)
 from stark_symphony_amd import binding as B, records, verifier  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+distinct = len(sys.argv) > 2 and sys.argv[2] == "distinct"   # every record its own buffer: the staging copy reads host DRAM
 proofs = records.load_stwo_npz(os.path.join(ROOT, "tests", "golden", "stwo_trace20.npz"))
 recs = [verifier.stwo_record(p) for p in proofs]
 cfg = verifier.stwo_cfg_struct(proofs[0].cfg, verifier.MODE_FIXTURE)
 ver = verifier.Verifier(0)
-ptrs = verifier._ptr_array([recs[i % len(recs)] for i in range(n)])
+rec_batch = [recs[i % len(recs)].copy() if distinct else recs[i % len(recs)] for i in range(n)]
+ptrs = verifier._ptr_array(rec_batch)
 status = np.zeros(n, dtype=np.uint32)
 lib = B.lib()
 for rep in range(3):
@@ -26,12 +28,12 @@ for rep in range(3):
     B.check(lib.ss_stwo_verify_records(ver.ctx, C.byref(cfg), n, ptrs, status.ctypes.data))
     dt = time.perf_counter() - t0
     assert (status == 0).all()
-    print("host path: %d proofs in %.3f s = %.0f proofs/s, %.2f GB/s of records"
+    print(("distinct buffers; " if distinct else "") + "host path: %d proofs in %.3f s = %.0f proofs/s, %.2f GB/s of records"
           % (n, dt, n / dt, n * recs[0].nbytes / dt / 1e9))
 
 from stark_symphony_amd import formats  # noqa: E402
 shared = [verifier.stwo_shared_record(p) for p in proofs]
-batch = [shared[i % len(shared)] for i in range(n)]
+batch = [shared[i % len(shared)].copy() if distinct else shared[i % len(shared)] for i in range(n)]
 sptrs = verifier._ptr_array(batch)
 words = (C.c_size_t * n)(*[int(r.size) for r in batch])
 total = sum(int(r.nbytes) for r in batch)
