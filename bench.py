@@ -91,23 +91,46 @@ def load_workload(name: str):
     raise SystemExit("unknown workload %r" % name)
 
 
-def pmc_traffic(wname: str, n_local: int):
-    """HBM bytes per launch of the dominant kernel from the PMC counters.  Counters cannot be
-    read from inside this process: they come from the separate rocprofv3 `--pmc FETCH_SIZE` /
-    `--pmc WRITE_SIZE` passes over this same command, summarised (with the guide's gfx950
-    correction) in profiles/*_hbm_traffic.json together with the commit they were measured at.
-    Traffic is linear in the proofs per launch.  -> (bytes or None, provenance string)."""
+MERKLE_STAGE_SOURCES = ("ss_stwo.hip", "ss_stwo_checks.h", "ss_sha256.h", "ss_hash.h", "ss_layout.h", "ss_fields.h", "ss_channel.h",
+                        "ss_stark101.hip")
+
+
+def kernel_sources_digest() -> str:
+    """sha256 over the sources that define the verifier kernels: what ties a committed counter profile to the code
+    that is running (the GPU box has no .git to ask for a commit)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in MERKLE_STAGE_SOURCES:
+        with open(os.path.join(ROOT, "stark-symphony_amd", "csrc", name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()
+
+
+def pmc_profile(wname: str, n_local: int):
+    """Counter figures of the dominant kernels per launch.  Counters cannot be read from inside this process: they come
+    from separate rocprofv3 `--pmc` passes over this same command (tools/evidence.sh), summarised -- FETCH_SIZE /
+    WRITE_SIZE with the guide's gfx950 correction, SQ_INSTS_VALU -- in profiles/*_hbm_traffic.json together with the
+    digest of the kernel sources they were taken on.  They are used ONLY when that digest is the one of the sources in
+    this tree; otherwise the figures are null.  Both are linear in the proofs per launch.
+    -> (hbm bytes or None, VALU wave-instructions or None, provenance string)."""
     import glob
+    digest = kernel_sources_digest()
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")), reverse=True):
         try:
             d = json.load(open(path))
         except (OSError, ValueError):
             continue
-        if d.get("workload") == wname:
-            src = "%s (rocprofv3 --pmc passes taken at commit %s; stale if the Merkle kernels changed after it)" % (
-                os.path.relpath(path, ROOT), d.get("commit", "unrecorded"))
-            return d["hbm_bytes_per_proof"] * n_local, src
-    return None, "no PMC profile of this workload under profiles/"
+        if d.get("workload") != wname:
+            continue
+        rel = os.path.relpath(path, ROOT)
+        if d.get("kernel_sources_sha256") != digest:
+            return None, None, "%s was taken on other kernel sources (digest %s..., this tree %s...): not used" % (
+                rel, str(d.get("kernel_sources_sha256"))[:12], digest[:12])
+        insts = d.get("valu_instructions_per_proof")
+        return (d["hbm_bytes_per_proof"] * n_local, insts * n_local if insts else None,
+                "%s (rocprofv3 --pmc passes at commit %s, kernel sources %s...: the ones in this tree)" % (
+                    rel, d.get("commit", "unrecorded"), digest[:12]))
+    return None, None, "no PMC profile of this workload under profiles/"
 
 
 def cpu_baseline(family, proofs, seconds: float):
@@ -292,6 +315,10 @@ def end_to_end(ver, proofs, n: int, rank: int = 0, world: int = 1, dist=None):
         out[kind] = row
         del batch
     return out
+
+
+N_SIMDS = 1024               # 256 CUs x 4 SIMDs
+NOMINAL_CLOCK_HZ = 2.4e9      # MI355X peak engine clock
 
 
 def granted_cores() -> int:
@@ -638,7 +665,7 @@ def main() -> None:
                 saved.append((full - done) * per_node)
             executed = compr_per_proof - sum(saved) / len(saved)
         launch_bytes = bytes_per_proof * n_local
-        traffic, traffic_src = pmc_traffic(wname, n_local)
+        traffic, valu_insts, traffic_src = pmc_profile(wname, n_local)
         achieved = launch_bytes / k_avg_s / 1e9 if k_avg_s else 0.0
         compr_s = executed * n_local / k_avg_s if k_avg_s else 0.0
         alu_note = "compressions the Merkle stage executes per launch / its kernel time"
@@ -682,6 +709,14 @@ def main() -> None:
                                  compr_per_proof * n_local / k_avg_s if k_avg_s else 0.0,
                              "calibrated_peak_compressions_per_s": alu_peak,
                              "frac": compr_s / alu_peak,
+                             # the absolute figure beside the calibrated one: VALU wave-instructions the Merkle stage issues
+                             # (SQ_INSTS_VALU of the committed counter passes) x 2 cycles -- what a wave64 VALU operation
+                             # occupies a SIMD for (MI355X_MICROARCH.md) -- over SIMD-cycles at the nominal clock
+                             "issue_frac": (valu_insts * 2 / (N_SIMDS * NOMINAL_CLOCK_HZ * k_avg_s)) if valu_insts and k_avg_s else None,
+                             "issue_note": "SQ_INSTS_VALU x 2 cycles / (%d SIMDs x %.1f GHz x kernel time); the rotates and 3-input "
+                                           "adds SHA-256 is made of issue at half that rate on this chip (profiles/r01_valu_mixing.txt, "
+                                           "r03_sha_formulations.txt), which is why `frac` is taken against a measured calibration"
+                                           % (N_SIMDS, NOMINAL_CLOCK_HZ / 1e9),
                              "note": alu_note + "; peak = tools/sha_bench.hip (registers only) on MI355X, "
                                      "profiles/r01_sha_calibration.txt (34.7 G), re-measured in r03_sha_calibration.txt (34.4-34.6 G)"},
             "kernels_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in timing.items()},

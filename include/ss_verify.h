@@ -393,7 +393,10 @@ int ss_ctx_collect_timing(ss_ctx *ctx, int cap, const char **names, float *total
  *   op 4  stark101 field: in (a, b) -> out (add, sub, mul, div(a,b) or 0xffffffff on abort)
  *   op 5  lazily reduced M31 forms on words in [0, P]: in (a[4], b[4]) -> out 16 words
  *         (a*b [4], a*a [4], a*(0 + im(b) u) [4], then for x = a[0] mod P, y = b[0] mod P:
- *         x+y, x-y, x*y, and (a[1] * 2^32 + b[1]) mod P)                                      */
+ *         x+y, x-y, x*y, and (a[1] * 2^32 + b[1]) mod P)
+ *   op 6  the asserts behind the FRI layer loop as the query kernel evaluates them (fri/verify.simf:124-128,
+ *         fri/layers.simf:73-78): in (mode, lde_log, n_layers, query, folded position, folded value[4], last layer[4])
+ *         -> out the first failing status code, 0 = none (stages 8 / 9 of the stwo status codes)            */
 int ss_selftest(ss_ctx *ctx, int op, size_t n, const uint32_t *in_host, uint32_t *out_host);
 
 #ifdef __cplusplus

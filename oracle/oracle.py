@@ -190,6 +190,7 @@ def lib() -> C.CDLL:
     sig("so_stwo_verify_batch", None, C.POINTER(StwoCfg), C.POINTER(StwoProofC), C.c_size_t, i,
         u32p, i)
     sig("so_num_procs", i)
+    sig("so_stwo_fri_tail", u32, i, u32, u32, u32, u32, QM31, QM31)
     sig("so_shared_walk", u32, u32, u32, u32, u32p, u32p)
     sig("so_shared_expand", i, u32, u32, u32, u32, u32p, C.c_size_t, u32p)
     _lib = L

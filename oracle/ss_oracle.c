@@ -1102,6 +1102,30 @@ void so_channel_draw_queries_8(so_channel *s, uint32_t mask, uint32_t out[8])
                      ((uint32_t)(query) << 4) | (uint32_t)(sub);                        \
     } while (0)
 
+/* What is asserted once the layer loop is through, as seen from one query (the first failing code in the reference's
+ * order, 0 = none): `assert!(jet::eq_8(log_size_ex, 0))` fri/verify.simf:127 -- evaluated once, before the last-layer
+ * loop, so it precedes every query's asserts --, then fri_verify_last_layer fri/layers.simf:73-78:
+ * `assert!(jet::eq_32(folded_query, 0))` :75 and `assert!(qm31_eq(folded_eval, last_layer_eval))` :76.  The first two
+ * are what the repository's own proofs violate: LITERAL mode only. */
+static uint32_t stwo_fri_tail(int mode, uint8_t log_size_ex, uint32_t q, uint32_t folded_query, so_qm31 eval, so_qm31 last)
+{
+    uint32_t status = 0;
+    if (mode == SO_MODE_LITERAL && log_size_ex != 0) STWO_FAIL(8, 0, 0, 0);
+    if (mode == SO_MODE_LITERAL && folded_query != 0) STWO_FAIL(9, 0, q, 0);
+    if (!qm31_eq(eval, last)) STWO_FAIL(9, 0, q, 1);
+    return status;
+}
+
+/* the same for a caller that has (lde_log, n_layers) instead of the running u8: fri/verify.simf:73-74 subtracts 1 per
+ * layer in 8-bit arithmetic */
+uint32_t so_stwo_fri_tail(int mode, uint32_t lde_log, uint32_t n_layers, uint32_t q, uint32_t folded_query, so_qm31 eval,
+                          so_qm31 last)
+{
+    uint8_t log_size_ex = (uint8_t)lde_log;
+    for (uint32_t l = 0; l <= n_layers; l++) log_size_ex = (uint8_t)(log_size_ex - 1);
+    return stwo_fri_tail(mode, log_size_ex, q, folded_query, eval, last);
+}
+
 /* fri/answers.simf:97-130, literal: ONE batch over trace+CP columns at the OODS point,
  * alpha powers alpha^1.. running across both groups, result * alpha^(n+16). */
 static int fri_answer_literal(const so_stwo_cfg *cfg, const so_stwo_proof *p, uint32_t qi,
@@ -1300,10 +1324,9 @@ uint32_t so_stwo_verify(const so_stwo_cfg *cfg, const so_stwo_proof *p, int mode
         }
         log_size_ex = (uint8_t)(log_size_ex - 1); /* fri/verify.simf:73-74 */
     }
-    if (mode == SO_MODE_LITERAL && log_size_ex != 0) STWO_FAIL(8, 0, 0, 0); /* :127 */
-    for (uint32_t q = 0; q < Q; q++) { /* fri/layers.simf:73-78 */
-        if (mode == SO_MODE_LITERAL && queries[q] != 0) STWO_FAIL(9, 0, q, 0);
-        if (!qm31_eq(evals[q], p->last_layer)) STWO_FAIL(9, 0, q, 1);
+    for (uint32_t q = 0; q < Q; q++) { /* fri/verify.simf:127 (once, before the queries), fri/layers.simf:73-78 */
+        const uint32_t c = stwo_fri_tail(mode, log_size_ex, q, queries[q], evals[q], p->last_layer);
+        if (c && !status) status = c;
         if (tr) { tr->folded[q] = evals[q]; tr->folded_query[q] = queries[q]; }
     }
     if (tr) tr->final_log_size = log_size_ex;

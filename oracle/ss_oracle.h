@@ -242,6 +242,12 @@ typedef struct {
 uint32_t so_stwo_verify(const so_stwo_cfg *cfg, const so_stwo_proof *p, int mode,
                         so_stwo_trace *tr);
 
+/* The asserts behind the FRI layer loop for one query (fri/verify.simf:127, fri/layers.simf:75-76): first failing code,
+ * 0 = none.  Exported because no honest proof reaches them in LITERAL mode (stage 7 fails first), so end-to-end batches
+ * compare them only vacuously; tests/test_gpu_intermediates.py feeds the GPU's twin the same random cases.        */
+uint32_t so_stwo_fri_tail(int mode, uint32_t lde_log, uint32_t n_layers, uint32_t q, uint32_t folded_query, so_qm31 eval,
+                          so_qm31 last);
+
 /* ----------------------------------------------------- shared records (ss_oracle_shared.c)
  * The reference never deduplicates Merkle siblings (fri/queries.simf:41; generate_wit.py:36-42 splits per query).
  * These two restate the DEFINITION of the product's shared-record order (first use in a walk over query 0, 1, ..

@@ -19,6 +19,7 @@
 #include "ss_kernels.h"
 #include "ss_layout.h"
 #include "ss_sha256.h"
+#include "ss_stwo_checks.h"
 
 using namespace ss;
 
@@ -918,14 +919,21 @@ __global__ void selftest_kernel(int op, uint32_t n, const uint32_t *in, uint32_t
         o[15] = m31_red64(((uint64_t)a.b << 32) | b.b);
         break;
     }
+    case 6: {  // the asserts behind the FRI layer loop, as the query kernel evaluates them (ss_stwo_checks.h); 0 = none fails
+        const uint32_t *x = in + 13 * i;
+        const QM31 eval = {x[5], x[6], x[7], x[8]}, last = {x[9], x[10], x[11], x[12]};
+        const uint32_t c = stwo_last_layer_code(x[0], x[1], x[2], x[3], x[4], eval, last);
+        out[i] = c == 0xffffffffu ? 0 : c;
+        break;
+    }
     }
 }
 }  // namespace ss
 
 extern "C" int ss_selftest(ss_ctx *ctx, int op, size_t n, const uint32_t *in_host, uint32_t *out_host)
 {
-    static const int in_w[6] = {16, 2, 8, 1, 2, 8}, out_w[6] = {8, 4, 8, 2, 4, 16};
-    if (!ctx || !in_host || !out_host || op < 0 || op > 5 || !n) return set_err(SS_ERR_ARG, "bad argument");
+    static const int in_w[7] = {16, 2, 8, 1, 2, 8, 13}, out_w[7] = {8, 4, 8, 2, 4, 16, 1};
+    if (!ctx || !in_host || !out_host || op < 0 || op > 6 || !n) return set_err(SS_ERR_ARG, "bad argument");
     std::lock_guard<std::mutex> lock(ctx->mu);
     SS_DEVICE_GUARD(ctx);
     DevBuf a, b;

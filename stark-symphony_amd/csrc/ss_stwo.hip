@@ -27,13 +27,9 @@
 #include "ss_fields.h"
 #include "ss_hash.h"
 #include "ss_layout.h"
+#include "ss_stwo_checks.h"
 
 namespace ss {
-
-__device__ __forceinline__ uint32_t stwo_code(uint32_t stage, uint32_t layer, uint32_t query, uint32_t sub)
-{
-    return (stage << 24) | (layer << 16) | (query << 4) | sub;
-}
 
 // ========================================================================== transcript
 template <int HF>
@@ -412,15 +408,12 @@ stwo_query_kernel(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *
     }
 
     // ---- last layer (fri/verify.simf:124-128, fri/layers.simf:73-78)
-    if (lay.mode == 0) {
-        if (((L - (K + 1)) & 0xff) != 0) FAIL(stwo_code(8, 0, 0, 0));
-        if (cur != 0) FAIL(stwo_code(9, 0, q, 0));
-    }
     {
         const uint32_t *head = batch + lay.off_head;
         QM31 last = {head[(size_t)(lay.h_last + 0) * np + p], head[(size_t)(lay.h_last + 1) * np + p],
                      head[(size_t)(lay.h_last + 2) * np + p], head[(size_t)(lay.h_last + 3) * np + p]};
-        if (!qm31_eq(eval, last)) FAIL(stwo_code(9, 0, q, 1));
+        const uint32_t c = stwo_last_layer_code(lay.mode, L, K, q, cur, eval, last);
+        if (c != 0xffffffffu) FAIL(c);
     }
     if (fail != 0xffffffffu) atomicMin(&status[p], fail);
 }

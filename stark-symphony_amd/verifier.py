@@ -729,7 +729,7 @@ class Verifier:
 
     # -- primitives self-test (tests only) ------------------------------------------------
     def selftest(self, op: int, inputs: np.ndarray) -> np.ndarray:
-        in_w, out_w = [16, 2, 8, 1, 2, 8][op], [8, 4, 8, 2, 4, 16][op]
+        in_w, out_w = [16, 2, 8, 1, 2, 8, 13][op], [8, 4, 8, 2, 4, 16, 1][op]
         inputs = np.ascontiguousarray(inputs, dtype=np.uint32).reshape(-1, in_w)
         out = np.empty((inputs.shape[0], out_w), dtype=np.uint32)
         B.check(B.lib().ss_selftest(self.ctx, op, inputs.shape[0], inputs.ctypes.data, out.ctypes.data))

@@ -91,3 +91,38 @@ def _ws_layout(b):
     lay = binding.StwoWsLayout()
     binding.check(binding.lib().ss_stwo_ws_layout_of(C.byref(b.cs), b.n, C.byref(lay)))
     return lay
+
+
+def test_last_layer_asserts_in_isolation():
+    """in LITERAL mode `log_size_ex == 0` (fri/verify.simf:127, code 8) and `folded_query == 0`
+    (fri/layers.simf:75, code 9.0) can never be the FIRST failing assert of any batch a prover can make (stage 7 fails
+    earlier), so end-to-end status words compare them only vacuously.  ss_selftest op 6 runs the query kernel's own
+    last-layer block (csrc/ss_stwo_checks.h) on chosen (mode, lde_log, n_layers, query, folded position, folded value,
+    last layer); the oracle exports the same lines (so_stwo_fri_tail).  4 000 random cases, every outcome in both modes,
+    including the 8-bit wrap of log_size_ex."""
+    import ctypes as C
+    ver = verifier.Verifier(0)
+    rng = np.random.default_rng(SEED + 88)
+    n = 4000
+    cases = np.zeros((n, 13), dtype=np.uint32)
+    cases[:, 0] = rng.integers(0, 2, n)                                  # mode
+    cases[:, 1] = rng.integers(1, 32, n)                                 # lde_log
+    cases[:, 2] = rng.integers(0, 31, n)                                 # n_layers
+    cases[:, 3] = rng.integers(0, 64, n)                                 # query number
+    cases[:, 4] = np.where(rng.integers(0, 2, n) == 0, 0, rng.integers(0, 1 << 31, n))   # folded position
+    cases[:, 5:9] = rng.integers(0, (1 << 31) - 1, (n, 4))
+    same = rng.integers(0, 3, n)
+    cases[:, 9:13] = cases[:, 5:9]
+    for i in np.nonzero(same == 0)[0]:
+        cases[i, 9 + int(rng.integers(0, 4))] ^= np.uint32(1 << int(rng.integers(0, 31)))
+    exact = rng.integers(0, 4, n) == 0
+    cases[exact, 2] = (cases[exact, 1].astype(np.int64) - 1) % 256 % 31   # around lde_log == n_layers + 1
+    cases[:40, 1], cases[:40, 2] = 256 + np.arange(40) % 3, 255 + np.arange(40) % 3   # log_size_ex wraps to 0 in 8 bits
+    got = ver.selftest(6, cases).reshape(-1)
+    L = O.lib()
+    want = [L.so_stwo_fri_tail(int(c[0]), int(c[1]), int(c[2]), int(c[3]), int(c[4]), O.qm(c[5:9].tolist()), O.qm(c[9:13].tolist()))
+            for c in cases]
+    assert got.tolist() == want
+    kinds = {(int(c[0]), w >> 24, w & 15) for c, w in zip(cases, want)}
+    assert {(0, 8, 0), (0, 9, 0), (0, 9, 1), (0, 0, 0), (1, 9, 1), (1, 0, 0)} <= kinds
+    assert not any(m == 1 and (stage, sub) in ((8, 0), (9, 0)) for m, stage, sub in kinds)   # FIXTURE mode never raises D2 / D3
