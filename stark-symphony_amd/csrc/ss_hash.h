@@ -183,6 +183,30 @@ struct Hasher<0> {
     {
         return ((uint64_t)__builtin_bswap32(d[7]) << 32) | __builtin_bswap32(d[6]);
     }
+
+    // H(prefix (8 native words) || value words) block by block, for a caller that keeps ONE inlined compression in a
+    // loop (the transcript kernels): `total` = message words, block b of n_blocks(total).  get(j, i) = value word i for
+    // slot j (j is a compile-time index, so a caller may keep short messages in registers).
+    static __device__ __forceinline__ void iv(uint32_t (&h)[8]) { sha_iv(h); }
+    static __device__ __forceinline__ uint32_t n_blocks(uint32_t total) { return (total + 2) / 16 + 1; }  // + 0x80 word + 64-bit length
+    template <class G>
+    static __device__ __forceinline__ void fill(W16 &w, uint32_t b, uint32_t nblk, uint32_t total, const uint32_t (&prefix)[8], G get)
+    {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t i = b * 16 + j;
+            uint32_t v = 0;
+            if (i < total) { if (i >= 8) v = get(j, i - 8); }
+            else if (i == total) v = 0x80000000u;
+            else if (i == nblk * 16 - 1) v = 32u * total;
+            w.v[j] = v;
+        }
+        if (b == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) w.v[j] = prefix[j];
+        }
+    }
+    static __device__ __forceinline__ void compress(Dig &st, W16 &w, uint32_t, uint32_t, uint32_t) { sha256_compress(st.v, w.v); }  // (w is the rolling schedule: consumed)
 };
 
 // ================================================================================ Blake2s
@@ -256,6 +280,28 @@ struct Hasher<1> {
     static __device__ __forceinline__ uint64_t pow_value(const uint32_t (&d)[8])
     {
         return ((uint64_t)d[7] << 32) | d[6];
+    }
+
+    // (see Hasher<0>) Blake2s pads with zeros and carries the byte count in the compression itself
+    static __device__ __forceinline__ void iv(uint32_t (&h)[8]) { b2s_iv(h); }
+    static __device__ __forceinline__ uint32_t n_blocks(uint32_t total) { return total ? (total + 15) / 16 : 1; }
+    template <class G>
+    static __device__ __forceinline__ void fill(W16 &w, uint32_t b, uint32_t, uint32_t total, const uint32_t (&prefix)[8], G get)
+    {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t i = b * 16 + j;
+            w.v[j] = (i >= 8 && i < total) ? native(get(j, i - 8)) : 0u;
+        }
+        if (b == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) w.v[j] = prefix[j];
+        }
+    }
+    static __device__ __forceinline__ void compress(Dig &st, W16 &w, uint32_t b, uint32_t nblk, uint32_t total)
+    {
+        const bool last = b + 1 == nblk;
+        blake2s_compress(st.v, w.v, last ? 4u * total : 64u * (b + 1), last);
     }
 };
 

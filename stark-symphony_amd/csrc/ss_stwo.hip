@@ -47,125 +47,166 @@ __device__ __forceinline__ void stwo_transcript_body(const StwoLayout &lay, cons
     auto CQ = [&](uint32_t w, QM31 q) { CW(w, q.a); CW(w + 1, q.b); CW(w + 2, q.c); CW(w + 3, q.d); };
     uint32_t fail = 0xffffffffu;
     auto FAIL = [&](uint32_t code) { fail = code < fail ? code : fail; };
-    uint32_t draw_ord = 0;
-
-    Channel<HF> ch;
-    ch.init();
-
-    // ---- stage I: evals_commit (evals/commit.simf:20-35)
-    QM31 cp_alpha, deep_alpha;
-    {
-        uint32_t r[8];
-        for (int i = 0; i < 8; i++) r[i] = H(lay.h_roots + i);
-        ch.mix(r);
-        for (int i = 0; i < 8; i++) r[i] = H(lay.h_roots + 8 + i);
-        ch.mix(r);
-        if (!ch.draw_qm31(cp_alpha)) FAIL(stwo_code(1, 0, 0, draw_ord));
-        draw_ord++;
-        for (int i = 0; i < 8; i++) r[i] = H(lay.h_roots + 16 + i);
-        ch.mix(r);
-    }
-
-    // ---- stage II: oods (deep/oods.simf:44-64)
-    QM31Point P;
-    {
-        // channel_draw_qm31_point (channel.simf:143-151)
-        QM31 t, inv;
-        if (!ch.draw_qm31(t)) FAIL(stwo_code(1, 0, 0, draw_ord));
-        draw_ord++;
-        QM31 t_sq = qm31_mul(t, t);
-        if (!qm31_inv(qm31_add(qm31_one(), t_sq), inv)) FAIL(stwo_code(2, 0, 0, 1));
-        P.x = qm31_mul(qm31_sub(qm31_one(), t_sq), inv);
-        P.y = qm31_mul(qm31_add(t, t), inv);
-
-        // channel_mix_oods_evals (deep/oods.simf:23-39): H(digest || 4(N+16) value words);
-        // oods_trace and oods_cp are adjacent in the head section
-        {
-            const uint32_t base = lay.h_oods_trace;
-            Hasher<HF>::template stream<false, 8>(ch.dig.v, [&](uint32_t i) { return H(base + i); },
-                                                  4 * (lay.N + kCp), ch.dig.v);
-            ch.ctr = 0;
-        }
-
-        // eval_composition_poly (constraints/wide_fibonacci.simf:24-62).  A column value reaches
-        // the squares through multiplications only, so it is reduced first and squared once
-        // (the reference squares it as `b` and again as `a`); it reaches the subtraction raw.
-        QM31 acc = qm31_zero(), sq_a = qm31_zero(), sq_b = qm31_zero();
-        uint32_t skip = 0;
-        for (uint32_t k = 0; k < lay.N; k++) {
-            const QM31 c = HQ(lay.h_oods_trace + 4 * k);
-            if (skip == 2) {
-                const QM31 constraint = qm31_sub(c, qm31_add(sq_b, sq_a));
-                acc = qm31_add(qm31_mul_c(acc, cp_alpha), constraint);
-            } else {
-                skip++;
-            }
-            sq_a = sq_b;
-            sq_b = qm31_sqr_c(qm31_red(c));
-        }
-        // vanishing_poly_eval (evals/composition_poly.simf:27-35,66-71): u8 loop counter
-        QM31 van = P.x;
-        {
-            const uint32_t n_iter = (lay.TL - 1) & 0xff;
-            for (uint32_t counter = 0; counter < 256; counter++) {
-                if (counter == n_iter) break;
-                van = qm31_dbl_x(van);
-            }
-        }
-        QM31 van_inv;
-        if (!qm31_inv(van, van_inv)) FAIL(stwo_code(2, 0, 0, 2));
-        QM31 cp_eval = qm31_mul(acc, van_inv);
-        // composition_poly_eval_from_decomposed (evals/composition_poly.simf:38-59)
-        QM31 part[4];
+    // The Fiat-Shamir chain (channel.simf:31-172) is ~3K + 30 hashes, each depending on the one before.  Every one of
+    // them is H(digest || a few value words) -- channel_mix_u256 / _u64 / _line_poly / _oods_evals hash the digest
+    // followed by their argument, channel_draw_words hashes it followed by the counter -- so the whole transcript is a
+    // state machine around ONE inlined compression: a phase names the value words, the block loop hashes them, the
+    // phase's tail consumes the digest.  (Round 3 called an out-of-line compression from ~12 sites: 184 VGPRs and an
+    // 80-byte call frame in scratch per lane; one site costs neither.)
+    enum : uint32_t { kRoot0, kRoot1, kDrawCp, kRoot2, kDrawT, kOods, kDrawDeep, kFriRoot, kFriDraw, kLast, kNonce, kQueries, kEnd };
+    uint32_t dig[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // channel_init, channel.simf:31 (native words of the hash family)
+    uint32_t ctr = 0, phase = kRoot0, fri_l = 0, tries = 0;  // (fri_l: the FRI layer, afterwards the first query of a draw)
+    // cp_alpha, deep_alpha and the OODS point live through dozens of compressions without being touched: parked in the
+    // lane's own LDS column instead of 16 VGPRs
+    __shared__ uint32_t s_park[16][64];
+    auto park = [&](uint32_t k, const QM31 &v) {
+        s_park[k][threadIdx.x] = v.a; s_park[k + 1][threadIdx.x] = v.b; s_park[k + 2][threadIdx.x] = v.c; s_park[k + 3][threadIdx.x] = v.d;
+    };
+    auto parked = [&](uint32_t k) {
+        return QM31{s_park[k][threadIdx.x], s_park[k + 1][threadIdx.x], s_park[k + 2][threadIdx.x], s_park[k + 3][threadIdx.x]};
+    };
+    enum : uint32_t { kParkCpAlpha = 0, kParkDeepAlpha = 4, kParkPx = 8, kParkPy = 12 };
+    const uint32_t qmask = shl32(lay.L, 1) - 1;
+    while (phase != kEnd) {
+        // ---- the value words of this hash (short messages in registers, the OODS values straight from the batch)
+        uint32_t v8[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nvals = 1;
+        switch (phase) {
+        case kRoot0: case kRoot1: case kRoot2: case kFriRoot: {  // channel_mix_u256 (channel.simf:154-161)
+            const uint32_t o = phase == kFriRoot ? lay.h_fri_roots + 8 * fri_l
+                                                 : lay.h_roots + (phase == kRoot0 ? 0 : phase == kRoot1 ? 8 : 16);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {  // j = a, b, c, d ; index = 4 * coord + j
-            QM31 c0 = HQ(lay.h_oods_cp + 4 * (0 + j)), c1 = HQ(lay.h_oods_cp + 4 * (4 + j));
-            QM31 c2 = HQ(lay.h_oods_cp + 4 * (8 + j)), c3 = HQ(lay.h_oods_cp + 4 * (12 + j));
-            QM31 r = qm31_add(c0, qm31_mul(c1, QM31{0, 1, 0, 0}));
-            r = qm31_add(r, qm31_mul(c2, QM31{0, 0, 1, 0}));
-            r = qm31_add(r, qm31_mul(c3, QM31{0, 0, 0, 1}));
-            part[j] = r;
+            for (int i = 0; i < 8; i++) v8[i] = H(o + i);
+            nvals = 8;
+            break;
         }
-        QM31 sampled = qm31_add(part[0], qm31_mul(part[1], P.y));
-        sampled = qm31_add(sampled, qm31_mul(part[2], P.x));
-        sampled = qm31_add(sampled, qm31_mul(part[3], qm31_mul(P.x, P.y)));
-        if (!qm31_eq(cp_eval, sampled)) FAIL(stwo_code(2, 0, 0, 3));
-
-        if (!ch.draw_qm31(deep_alpha)) FAIL(stwo_code(1, 0, 0, draw_ord));
-        draw_ord++;
-    }
-
-    // ---- stage III: fri_commit (fri/commit.simf:70-85)
-    for (uint32_t l = 0; l <= lay.K; l++) {
-        uint32_t r[8];
-        for (int i = 0; i < 8; i++) r[i] = H(lay.h_fri_roots + 8 * l + i);
-        ch.mix(r);
-        QM31 fa;
-        if (!ch.draw_qm31(fa)) FAIL(stwo_code(1, 0, 0, draw_ord));
-        draw_ord++;
-        CQ(lay.c_fold + 4 * l, fa);
-    }
-    {
-        uint32_t m[4] = {H(lay.h_last), H(lay.h_last + 1), H(lay.h_last + 2), H(lay.h_last + 3)};
-        ch.template mix_values<4>(m);  // channel_mix_line_poly, fri/commit.simf:48-57
-    }
-
-    // ---- stage IV: check_proof_of_work (pow.simf:22-36)
-    {
-        uint32_t m[2] = {H(lay.h_nonce), H(lay.h_nonce + 1)};
-        ch.template mix_values<2>(m);  // channel_mix_u64
-        if (!(Hasher<HF>::pow_value(ch.dig.v) < lay.pow_target)) FAIL(stwo_code(4, 0, 0, 0));
-    }
-
-    // ---- stage V (first half): fri_generate_queries (fri/queries.simf:29-43)
-    {
-        const uint32_t mask = shl32(lay.L, 1) - 1;
-        for (uint32_t base = 0; base < lay.Q; base += 8) {
-            uint32_t w[8];
-            ch.draw_words(w);
+        case kOods: nvals = 4 * (lay.N + kCp); break;  // channel_mix_oods_evals (deep/oods.simf:23-39): trace and cp values are adjacent
+        case kLast:                                    // channel_mix_line_poly, fri/commit.simf:48-57
+#pragma unroll
+            for (int i = 0; i < 4; i++) v8[i] = H(lay.h_last + i);
+            nvals = 4;
+            break;
+        case kNonce: v8[0] = H(lay.h_nonce); v8[1] = H(lay.h_nonce + 1); nvals = 2; break;  // channel_mix_u64
+        default: v8[0] = ctr; break;                   // channel_draw_words (channel.simf:36-65): digest || be4(counter)
+        }
+        const bool from_batch = phase == kOods;
+        const uint32_t total = 8 + nvals, nblk = Hasher<HF>::n_blocks(total);
+        Dig st;
+        Hasher<HF>::iv(st.v);
+        for (uint32_t blk = 0; blk < nblk; blk++) {
+            W16 w;
+            Hasher<HF>::fill(w, blk, nblk, total, dig, [&](int j, uint32_t i) { return from_batch ? H(lay.h_oods_trace + i) : v8[j & 7]; });
+            Hasher<HF>::compress(st, w, blk, nblk, total);  // <- the kernel's only compression
+        }
+        // ---- what the digest is for
+        const bool is_draw = phase == kDrawCp || phase == kDrawT || phase == kDrawDeep || phase == kFriDraw;
+        if (is_draw || phase == kQueries) ctr = ctr + 1;
+        else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) dig[i] = st.v[i];
+            ctr = 0;
+        }
+        QM31 drawn = qm31_zero();
+        if (is_draw) {
+            // channel_draw_qm31 (channel.simf:115-140): retry while any of the first four words >= 2^32 - 2; the
+            // for_while counter is a u8, so at most 256 attempts
+            const uint32_t w0 = Hasher<HF>::native(st.v[0]), w1 = Hasher<HF>::native(st.v[1]);
+            const uint32_t w2 = Hasher<HF>::native(st.v[2]), w3 = Hasher<HF>::native(st.v[3]);
+            const bool ok = w0 < 4294967294u && w1 < 4294967294u && w2 < 4294967294u && w3 < 4294967294u;
+            if (!ok && ++tries < 256) continue;
+            if (ok) drawn = {m31_red(w0), m31_red(w1), m31_red(w2), m31_red(w3)};
+            else  // sub = the ordinal of the draw: cp_alpha, t, deep_alpha, then one per FRI layer
+                FAIL(stwo_code(1, 0, 0, phase == kDrawCp ? 0 : phase == kDrawT ? 1 : phase == kDrawDeep ? 2 : 3 + fri_l));
+            tries = 0;
+        }
+        switch (phase) {
+        // ---- stage I: evals_commit (evals/commit.simf:20-35)
+        case kRoot0: phase = kRoot1; break;
+        case kRoot1: phase = kDrawCp; break;
+        case kDrawCp: park(kParkCpAlpha, drawn); phase = kRoot2; break;
+        case kRoot2: phase = kDrawT; break;
+        // ---- stage II: oods (deep/oods.simf:44-64)
+        case kDrawT: {  // channel_draw_qm31_point (channel.simf:143-151)
+            const QM31 t = drawn;
+            QM31 inv;
+            QM31 t_sq = qm31_mul(t, t);
+            if (!qm31_inv(qm31_add(qm31_one(), t_sq), inv)) FAIL(stwo_code(2, 0, 0, 1));
+            park(kParkPx, qm31_mul(qm31_sub(qm31_one(), t_sq), inv));
+            park(kParkPy, qm31_mul(qm31_add(t, t), inv));
+            phase = kOods;
+            break;
+        }
+        case kOods: {
+            // eval_composition_poly (constraints/wide_fibonacci.simf:24-62).  A column value reaches
+            // the squares through multiplications only, so it is reduced first and squared once
+            // (the reference squares it as `b` and again as `a`); it reaches the subtraction raw.
+            const QM31 cp_alpha = parked(kParkCpAlpha);
+            const QM31Point P{parked(kParkPx), parked(kParkPy)};
+            QM31 acc = qm31_zero(), sq_a = qm31_zero(), sq_b = qm31_zero();
+            uint32_t skip = 0;
+            for (uint32_t k = 0; k < lay.N; k++) {
+                const QM31 c = HQ(lay.h_oods_trace + 4 * k);
+                if (skip == 2) {
+                    const QM31 constraint = qm31_sub(c, qm31_add(sq_b, sq_a));
+                    acc = qm31_add(qm31_mul_c(acc, cp_alpha), constraint);
+                } else {
+                    skip++;
+                }
+                sq_a = sq_b;
+                sq_b = qm31_sqr_c(qm31_red(c));
+            }
+            // vanishing_poly_eval (evals/composition_poly.simf:27-35,66-71): u8 loop counter
+            QM31 van = P.x;
+            {
+                const uint32_t n_iter = (lay.TL - 1) & 0xff;
+                for (uint32_t counter = 0; counter < 256; counter++) {
+                    if (counter == n_iter) break;
+                    van = qm31_dbl_x(van);
+                }
+            }
+            QM31 van_inv;
+            if (!qm31_inv(van, van_inv)) FAIL(stwo_code(2, 0, 0, 2));
+            QM31 cp_eval = qm31_mul(acc, van_inv);
+            // composition_poly_eval_from_decomposed (evals/composition_poly.simf:38-59)
+            // (one part at a time, the loop kept rolled: sixteen QM31 values in flight at once cost 130 VGPRs)
+            QM31 sampled = qm31_zero();
+#pragma unroll 1
+            for (int j = 0; j < 4; j++) {  // j = a, b, c, d ; index = 4 * coord + j
+                QM31 c0 = HQ(lay.h_oods_cp + 4 * (0 + j)), c1 = HQ(lay.h_oods_cp + 4 * (4 + j));
+                QM31 c2 = HQ(lay.h_oods_cp + 4 * (8 + j)), c3 = HQ(lay.h_oods_cp + 4 * (12 + j));
+                QM31 r = qm31_add(c0, qm31_mul(c1, QM31{0, 1, 0, 0}));
+                r = qm31_add(r, qm31_mul(c2, QM31{0, 0, 1, 0}));
+                r = qm31_add(r, qm31_mul(c3, QM31{0, 0, 0, 1}));
+                // sampled = part[0] + part[1] P.y + part[2] P.x + part[3] (P.x P.y), summed in that order
+                if (j == 0) sampled = r;
+                else sampled = qm31_add(sampled, qm31_mul(r, j == 1 ? P.y : j == 2 ? P.x : qm31_mul(P.x, P.y)));
+            }
+            if (!qm31_eq(cp_eval, sampled)) FAIL(stwo_code(2, 0, 0, 3));
+            phase = kDrawDeep;
+            break;
+        }
+        case kDrawDeep: park(kParkDeepAlpha, drawn); phase = kFriRoot; break;
+        // ---- stage III: fri_commit (fri/commit.simf:70-85)
+        case kFriRoot: phase = kFriDraw; break;
+        case kFriDraw:
+            CQ(lay.c_fold + 4 * fri_l, drawn);
+            fri_l++;
+            phase = fri_l <= lay.K ? kFriRoot : kLast;
+            break;
+        case kLast: phase = kNonce; break;
+        // ---- stage IV: check_proof_of_work (pow.simf:22-36)
+        case kNonce:
+            if (!(Hasher<HF>::pow_value(dig) < lay.pow_target)) FAIL(stwo_code(4, 0, 0, 0));
+            phase = kQueries;
+            fri_l = 0;
+            break;
+        // ---- stage V (first half): fri_generate_queries (fri/queries.simf:29-43)
+        default:  // kQueries
 #pragma unroll
             for (int j = 0; j < 8; j++)
-                if (base + j < lay.Q) CW(lay.c_queries + base + j, w[j] & mask);
+                if (fri_l + j < lay.Q) CW(lay.c_queries + fri_l + j, Hasher<HF>::native(st.v[j]) & qmask);
+            fri_l += 8;
+            if (fri_l >= lay.Q) phase = kEnd;
+            break;
         }
     }
 
@@ -180,6 +221,8 @@ __device__ __forceinline__ void stwo_transcript_body(const StwoLayout &lay, cons
     // [0, P] except the raw `value`, which the reference doubles with wrapping adds (kept) and
     // otherwise only multiplies (reduced first), so the sums are the reference's words.
     {
+        const QM31 deep_alpha = parked(kParkDeepAlpha);
+        const QM31Point P{parked(kParkPx), parked(kParkPy)};
         QM31Point P2 = qm31_point_add(P, P);
         CQ(lay.c_p, P.x);  CQ(lay.c_p + 4, P.y);
         CQ(lay.c_p2, P2.x); CQ(lay.c_p2 + 4, P2.y);
@@ -226,7 +269,7 @@ __device__ __forceinline__ void stwo_transcript_body(const StwoLayout &lay, cons
     if (fail != 0xffffffffu) atomicMin(&status[p], fail);
 }
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 stwo_transcript_kernel_sha(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,
                            uint32_t *__restrict__ status)
 {
