@@ -52,6 +52,7 @@ extern "C" {
 #define SS_ERR_HIP (-2)       /* a HIP call failed; see ss_last_error() */
 #define SS_ERR_NO_DEVICE (-3) /* no usable gfx950 device */
 #define SS_ERR_WORKSPACE (-4) /* workspace too small */
+#define SS_ERR_NOMEM (-5)     /* the host ran out of memory inside the call (nothing is left half done: the call failed as a whole) */
 
 int ss_version(void);
 const char *ss_last_error(void); /* thread-local text of the last error */
@@ -144,6 +145,7 @@ typedef struct ss_stwo_cfg {
  *   root, 2 cp path, 3 cp root) | 6 DEEP denominator abort (sub = batch) | 7 FRI layer (sub 0
  *   path, 1 root, 2 fold inverse) | 8 log_size_ex != 0 [LITERAL] | 9 last layer (sub 0
  *   folded_query != 0 [LITERAL], 1 value mismatch fri/layers.simf:76)                       */
+/* Pure functions of their arguments (no environment, no process state): sizes computed in one process hold in another. */
 size_t ss_stwo_record_words(const ss_stwo_cfg *cfg);
 size_t ss_stwo_batch_words(const ss_stwo_cfg *cfg, size_t n);
 size_t ss_stwo_workspace_bytes(const ss_stwo_cfg *cfg, size_t n);

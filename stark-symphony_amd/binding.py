@@ -12,7 +12,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libss_verify.so")
 
-SS_OK, SS_ERR_ARG, SS_ERR_HIP, SS_ERR_NO_DEVICE, SS_ERR_WORKSPACE = 0, -1, -2, -3, -4
+SS_OK, SS_ERR_ARG, SS_ERR_HIP, SS_ERR_NO_DEVICE, SS_ERR_WORKSPACE, SS_ERR_NOMEM = 0, -1, -2, -3, -4, -5
 MODE_LITERAL, MODE_FIXTURE = 0, 1
 
 

@@ -714,7 +714,12 @@ extern "C" int ss_stwo_parse(const ss_stwo_cfg *c, const char *text, size_t len,
 {
     if (!cfg_ok(c)) return set_err(SS_ERR_ARG, "unsupported stwo config");
     if (!text || !record_out || fmt < SS_TEXT_AUTO || fmt > SS_TEXT_WIT) return set_err(SS_ERR_ARG, "bad argument");
-    const ParseResult r = stwo_parse_text(*c, text, len, fmt, record_out);
+    ParseResult r;
+    try {
+        r = stwo_parse_text(*c, text, len, fmt, record_out);
+    } catch (const std::exception &e) {
+        return set_err(SS_ERR_NOMEM, "host reader: %s", e.what());
+    }
     if (r != kParsed) memset(record_out, 0, ss_stwo_record_words(c) * 4);
     return r == kParsed ? 0 : r == kConfigMismatch ? (int)SS_STATUS_CONFIG_MISMATCH : (int)SS_STATUS_MALFORMED;
 }
@@ -722,7 +727,12 @@ extern "C" int ss_stwo_parse(const ss_stwo_cfg *c, const char *text, size_t len,
 extern "C" int ss_s101_parse(const char *text, size_t len, int fmt, ss_s101_shape *shape, uint32_t *record_out)
 {
     if (!text || !shape || fmt < SS_TEXT_AUTO || fmt > SS_TEXT_WIT) return set_err(SS_ERR_ARG, "bad argument");
-    S101Parsed *p = s101_parse_text(text, len, fmt);
+    S101Parsed *p;
+    try {
+        p = s101_parse_text(text, len, fmt);
+    } catch (const std::exception &e) {
+        return set_err(SS_ERR_NOMEM, "host reader: %s", e.what());
+    }
     if (!p) return (int)SS_STATUS_MALFORMED;
     uint32_t nl, pm;
     s101_parsed_shape(p, &nl, &pm);

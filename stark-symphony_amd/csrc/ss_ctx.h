@@ -90,6 +90,7 @@ struct TextPath {
     GrowBuf win_dev[kTextBufs];        // per-window scratch of the GPU reader (ss_textdev.h)
     GrowBuf shrec_dev[kTextBufs], hint_dev[kTextBufs];  // shared-path texts: capacity-form shared records, per-text hints
     GrowBuf fix_pin[kTextBufs];        // records re-made by the host reader, on their way up
+    GrowBuf fix_dev[kTextBufs];        // ... as they arrive: one block, scattered into rec_dev by a kernel
     GrowBuf batch_dev, ws_dev, status_dev;
     hipStream_t up = nullptr, cx = nullptr, vx = nullptr;  // upload, GPU reader, re-tile + verify
     hipEvent_t uploaded[kTextBufs] = {};  // H2D of buffer b complete

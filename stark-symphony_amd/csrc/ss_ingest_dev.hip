@@ -58,6 +58,7 @@ void text_path_destroy(TextPath &tp)
     for (int i = 0; i < kTextBufs; i++) {
         release(tp.text_pin[i]); release(tp.text_dev[i]); release(tp.rec_dev[i]); release(tp.out_dev[i]);
         release(tp.out_pin[i]); release(tp.fix_pin[i]); release(tp.win_dev[i]); release(tp.shrec_dev[i]); release(tp.hint_dev[i]);
+        release(tp.fix_dev[i]);
         if (tp.uploaded[i]) (void)hipEventDestroy(tp.uploaded[i]);
         if (tp.parsed[i]) (void)hipEventDestroy(tp.parsed[i]);
         if (tp.fixed[i]) (void)hipEventDestroy(tp.fixed[i]);
@@ -391,23 +392,34 @@ static int ingest_pipeline(ss_ctx *ctx, const Family &F, size_t n, const char *c
         if (!todo.empty()) {
             const double tp0 = now_s();
             fallbacks += todo.size();
-            HIP_TRY(hipEventSynchronize(tp.fixed[b]));  // fix_pin[b]'s previous uploads are through
-            if ((rc = grow(tp.fix_pin[b], todo.size() * W * 4, true))) return rc;
+            HIP_TRY(hipEventSynchronize(tp.fixed[b]));  // fix_pin[b]'s previous upload is through
+            // one block: the re-made records back to back, then the slot each one belongs to
+            const size_t fix_bytes = todo.size() * W * 4 + todo.size() * 4;
+            if ((rc = grow(tp.fix_pin[b], fix_bytes, true))) return rc;
+            if ((rc = grow(tp.fix_dev[b], fix_bytes, false))) return rc;
             uint32_t *fix = (uint32_t *)tp.fix_pin[b].p;
             const uint8_t *stage = (const uint8_t *)tp.text_pin[b].p;
             const uint64_t *offs = (const uint64_t *)(stage + meta_off(ch));
-            parallel_for(todo.size(), [&](size_t j) {
-                const size_t i = todo[j], g = ch.lo + i;
-                uint32_t *dst = fix + j * W;
-                int r = (int)SS_STATUS_MALFORMED;
-                if (!unreadable[g]) r = F.host_read(g, (const char *)stage + offs[i], tlen[g], dst);
-                if (r != 0) memset(dst, 0, W * 4);
-                outcome[g] = (uint8_t)r;
-            }, threads);
-            uint32_t *rec = (uint32_t *)tp.rec_dev[b].p;
-            for (size_t j = 0; j < todo.size(); j++)
-                HIP_TRY(hipMemcpyAsync(rec + (size_t)todo[j] * W, fix + j * W, W * 4, hipMemcpyHostToDevice, tp.vx));
+            try {  // (an exception in a worker -- the host reader allocates its parse tree -- is rethrown here by the pool)
+                parallel_for(todo.size(), [&](size_t j) {
+                    const size_t i = todo[j], g = ch.lo + i;
+                    uint32_t *dst = fix + j * W;
+                    int r = (int)SS_STATUS_MALFORMED;
+                    if (!unreadable[g]) r = F.host_read(g, (const char *)stage + offs[i], tlen[g], dst);
+                    if (r != 0) memset(dst, 0, W * 4);
+                    outcome[g] = (uint8_t)r;
+                }, threads);
+            } catch (const std::exception &e) {
+                return set_err(SS_ERR_NOMEM, "host reader: %s", e.what());
+            }
+            // ONE upload and a scatter kernel, however the host-read texts are spread over the chunk (a copy per text
+            // made a batch of mostly non-canonical texts pay a launch per proof on the verify stream: ADVICE r3)
+            memcpy(fix + todo.size() * W, todo.data(), todo.size() * 4);
+            HIP_TRY(hipMemcpyAsync(tp.fix_dev[b].p, fix, fix_bytes, hipMemcpyHostToDevice, tp.vx));
             HIP_TRY(hipEventRecord(tp.fixed[b], tp.vx));
+            const uint32_t *fd = (const uint32_t *)tp.fix_dev[b].p;
+            launch_text_scatter(todo.size(), W, fd, fd + todo.size() * W, (uint32_t *)tp.rec_dev[b].p, tp.vx);
+            HIP_TRY(hipGetLastError());
             parse_s += now_s() - tp0;
         }
         for (size_t i = 0; i < ch.cnt; i++) text_total += tlen[ch.lo + i];

@@ -16,22 +16,14 @@ bool ss::cfg_ok(const ss_stwo_cfg *c)
     return c && c->hash <= SS_HASH_BLAKE2S && c->flags <= (SS_FLAG_NO_DEDUP | SS_FLAG_TOP_CHECKS) &&
            stwo_cfg_ok(c->n_cols, c->trace_log, c->lde_log, c->n_queries, c->n_layers, c->mode);
 }
+// The layout of a batch and of its workspace is a function of (cfg, n) ONLY -- no process state: a caller may size
+// buffers in one process and verify in another (the round-3 A/B environment knobs are gone: the byte
+// compares' place is cfg.flags & SS_FLAG_TOP_CHECKS, the group size is the compile-time kTopMinGroups).
 StwoLayout ss::lay_of(const ss_stwo_cfg *c, size_t n)
 {
-    static const uint32_t min_groups = [] {  // tuning knob (tools/r03/gpu_o.sh); the default is kTopMinGroups
-        const char *e = getenv("SS_TOP_MIN_GROUPS");
-        const int v = e ? atoi(e) : 0;
-        return v > 0 ? (uint32_t)v : kTopMinGroups;
-    }();
-    // SS_MERKLE_CHECKS=0 = SS_FLAG_TOP_CHECKS for every call of the process: the byte compares of the pair
-    // memoisation stay in the top kernel (the path of query counts that do not divide 64), for A/B runs
-    static const bool merkle_checks = [] {
-        const char *e = getenv("SS_MERKLE_CHECKS");
-        return !(e && e[0] == '0');
-    }();
     return stwo_layout(c->n_cols, c->trace_log, c->lde_log, c->n_queries, c->n_layers, c->mode,
-                       c->pow_target, n, !(c->flags & SS_FLAG_NO_DEDUP), c->hash == SS_HASH_BLAKE2S, min_groups,
-                       merkle_checks && !(c->flags & SS_FLAG_TOP_CHECKS));
+                       c->pow_target, n, !(c->flags & SS_FLAG_NO_DEDUP), c->hash == SS_HASH_BLAKE2S, kTopMinGroups,
+                       !(c->flags & SS_FLAG_TOP_CHECKS));
 }
 
 extern "C" size_t ss_stwo_record_words(const ss_stwo_cfg *c)

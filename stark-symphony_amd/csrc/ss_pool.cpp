@@ -2,6 +2,7 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <exception>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -20,15 +21,21 @@ class Pool {
     size_t n_ = 0, helpers_wanted_ = 0, helpers_in_ = 0, helpers_out_ = 0;
     std::atomic<size_t> next_{0};
     uint64_t gen_ = 0;
-    bool stop_ = false;
     pid_t owner_ = getpid();  // a fork()ed child inherits this object but none of its threads
+    std::exception_ptr error_;  // the first exception an item threw (under m_); rethrown on the calling thread
 
     void drain()
     {
         for (;;) {
             const size_t i = next_.fetch_add(1, std::memory_order_relaxed);
             if (i >= n_) return;
-            (*f_)(i);
+            try {
+                (*f_)(i);
+            } catch (...) {  // e.g. bad_alloc in the host reader: fail the call, not the process
+                std::lock_guard<std::mutex> lk(m_);
+                if (!error_) error_ = std::current_exception();
+                next_.store(n_, std::memory_order_relaxed);  // the remaining items are not started
+            }
         }
     }
     void worker()
@@ -36,8 +43,7 @@ class Pool {
         uint64_t seen = 0;
         std::unique_lock<std::mutex> lk(m_);
         for (;;) {
-            work_.wait(lk, [&] { return stop_ || (gen_ != seen && helpers_in_ < helpers_wanted_); });
-            if (stop_) return;
+            work_.wait(lk, [&] { return gen_ != seen && helpers_in_ < helpers_wanted_; });
             seen = gen_;
             helpers_in_++;
             lk.unlock();
@@ -53,13 +59,9 @@ public:
         const unsigned n = effective_cpus();
         for (unsigned i = 1; i < n; i++) workers_.emplace_back([this] { worker(); });  // the caller is the n-th
     }
-    ~Pool()
-    {
-        if (getpid() != owner_) { for (auto &t : workers_) t.detach(); return; }  // (the child of a fork: nothing to join)
-        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
-        work_.notify_all();
-        for (auto &t : workers_) t.join();
-    }
+    // No destructor runs: the pool is allocated once and never freed (parallel_for), so neither a normal exit nor the
+    // exit of a fork()ed child -- which inherits the std::thread handles but none of the threads -- touches them.
+    ~Pool() = delete;
     void run(size_t n, const std::function<void(size_t)> &f, size_t max_threads)
     {
         const size_t helpers = std::min(workers_.size(), std::min(n, max_threads) - 1);
@@ -68,6 +70,7 @@ public:
         {
             std::lock_guard<std::mutex> lk(m_);
             f_ = &f; n_ = n;
+            error_ = nullptr;
             next_.store(0, std::memory_order_relaxed);
             helpers_wanted_ = helpers; helpers_in_ = helpers_out_ = 0;
             gen_++;
@@ -78,6 +81,12 @@ public:
         // every helper that was asked for must have come and gone before the job's fields may change again
         done_.wait(lk, [&] { return helpers_out_ == helpers_wanted_; });
         f_ = nullptr;
+        if (error_) {
+            std::exception_ptr e = error_;
+            error_ = nullptr;
+            lk.unlock();
+            std::rethrow_exception(e);
+        }
     }
 };
 
@@ -85,9 +94,9 @@ public:
 
 void parallel_for(size_t n, const std::function<void(size_t)> &f, size_t max_threads)
 {
-    static Pool pool;  // constructed on first use; its threads end with the process
+    static Pool *const pool = new Pool();  // constructed on first use, never destroyed: its threads end with the process
     if (max_threads == 0) max_threads = 1;
-    pool.run(n, f, max_threads);
+    pool->run(n, f, max_threads);
 }
 
 }  // namespace ss

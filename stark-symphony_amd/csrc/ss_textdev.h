@@ -44,5 +44,7 @@ struct TextParseArgs {
 constexpr size_t kTextSlack = 4096;  // bytes readable behind the last text of a chunk (whole 1 KiB windows + the next)
 
 void launch_text_parse(const TextParseArgs &a, hipStream_t s);
+// records re-made by the host reader: src holds n of them back to back, record j goes to slot idx[j] of dst
+void launch_text_scatter(size_t n, size_t record_words, const uint32_t *src, const uint32_t *idx, uint32_t *dst, hipStream_t s);
 
 }  // namespace ss

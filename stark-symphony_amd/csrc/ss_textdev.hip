@@ -503,6 +503,19 @@ __global__ void __launch_bounds__(64) text_place_kernel(TextParseArgs a)
     if (mism) a.outcome[t] = 1;
 }
 
+__global__ void __launch_bounds__(256) text_scatter_kernel(uint32_t record_words, const uint32_t *__restrict__ src,
+                                                           const uint32_t *__restrict__ idx, uint32_t *__restrict__ dst)
+{
+    const uint32_t *from = src + (size_t)blockIdx.x * record_words;
+    uint32_t *to = dst + (size_t)idx[blockIdx.x] * record_words;
+    for (uint32_t i = threadIdx.x; i < record_words; i += 256) to[i] = from[i];
+}
+
+void launch_text_scatter(size_t n, size_t record_words, const uint32_t *src, const uint32_t *idx, uint32_t *dst, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(text_scatter_kernel, dim3((unsigned)n), dim3(256), 0, s, (uint32_t)record_words, src, idx, dst);
+}
+
 void launch_text_parse(const TextParseArgs &a, hipStream_t s)
 {
     if (!a.n) return;

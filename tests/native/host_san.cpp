@@ -15,8 +15,15 @@
 #include <string>
 #include <vector>
 
+#include <stdexcept>
+
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include "ss_ingest.h"
 #include "ss_pack.h"
+#include "ss_pool.h"
+#include "ss_shared.h"
 #include "ss_text.h"
 
 int ss::set_err(int code, const char *, ...) { return code; }  // (the library's lives in ss_api.hip)
@@ -151,6 +158,107 @@ int main(int argc, char **argv)
         if (!a.ok || !b.ok || d.ok) { fprintf(stderr, "template of a supported config missing (or made for an odd pow_target)\n"); return 1; }
         checks++;
     }
-    printf("host_san: %zu checks, %zu mutants taken by the scalar rule\n", checks, taken);
+    // ---- shared records (csrc/ss_sharedrec.cpp): share / unshare through exact-size buffers, random shapes and
+    // positions (uniform, clustered, equal), structure mutants into the host expansion; the shared text writer, its
+    // template and the scalar rule of the GPU reader for that format
+    size_t shared_taken = 0;
+    for (const auto &sh : shapes) {
+        const ss_stwo_cfg c = make_cfg(sh[0], sh[1], sh[2], sh[3], sh[4], 0, 0);
+        const size_t Wc = ss_stwo_record_words(&c), cap = ss_stwo_shared_max_words(&c), fixed = ss_stwo_shared_fixed_words(&c);
+        const uint32_t N = c.n_cols, L = c.lde_log, Q = c.n_queries, K = c.n_layers;
+        for (int rep = 0; rep < 6; rep++) {
+            std::vector<uint32_t> qs(Q);
+            const uint32_t base_pos = rnd() & ((1u << L) - 1);
+            for (auto &q : qs) q = rep % 3 == 0 ? (rnd() & ((1u << L) - 1)) : rep % 3 == 1 ? (base_pos ^ (rnd() & 7 & ((1u << L) - 1))) : base_pos;
+            // a record whose paths agree wherever these positions make them meet: node bytes are a function of (tree, level, position)
+            uint32_t *rec = new uint32_t[Wc];
+            for (size_t i = 0; i < Wc; i++) rec[i] = rnd() | 1u;
+            const uint32_t head = 24 + 4 * N + 64 + 8 * (K + 1) + 6, qstride = N + 16 + 16 * L;
+            uint32_t fo = head + Q * qstride;
+            for (uint32_t t = 0; t < K + 3; t++) {
+                const uint32_t len = t < 2 ? L : L + 1 - t, shift = t < 2 ? 0 : t - 1;
+                for (uint32_t q = 0; q < Q; q++)
+                    for (uint32_t lvl = 0; lvl < len; lvl++) {
+                        uint32_t *dst = t < 2 ? rec + head + q * qstride + N + 16 + t * 8 * L + 8 * lvl : rec + fo + q * (4 + 8 * len) + 4 + 8 * lvl;
+                        const uint32_t pos = ((qs[q] >> shift) >> lvl) ^ 1;
+                        for (uint32_t w = 0; w < 8; w++) dst[w] = (pos * 2654435761u) ^ (t * 40503u + lvl * 97u + w) ^ 0x9e3779b9u;
+                    }
+                if (t >= 2) fo += Q * (4 + 8 * len);
+            }
+            for (uint32_t t = 0; t < K + 3; t++)
+                for (uint32_t q = 0; q < Q; q++) rec[fo + t * Q + q] = t < 2 ? L : L + 1 - t;
+            size_t words = 0;
+            std::vector<uint32_t> big(cap);
+            if (ss_stwo_share_record(&c, rec, qs.data(), big.data(), cap, &words) != 0 || words < fixed || words > cap) { fprintf(stderr, "share failed\n"); return 1; }
+            uint32_t *shr = new uint32_t[words];  // exact size
+            memcpy(shr, big.data(), words * 4);
+            uint32_t *back = new uint32_t[Wc];
+            if (ss_stwo_unshare_record(&c, shr, words, back) != 0 || memcmp(back, rec, Wc * 4) != 0) { fprintf(stderr, "unshare is not the inverse of share\n"); return 1; }
+            if (words > 1 && ss_stwo_share_record(&c, rec, qs.data(), big.data(), words - 1, &words) >= 0) { fprintf(stderr, "short capacity accepted\n"); return 1; }
+            for (int m = 0; m < 40; m++) {  // structure mutants: any size, hints, counts
+                size_t mw = words;
+                std::vector<uint32_t> mut(shr, shr + words);
+                switch (rnd() % 5) {
+                case 0: mw = rnd() % (words + 1); break;
+                case 1: mut[fixed - (K + 3) - Q + rnd() % Q] = rnd(); break;
+                case 2: mut[fixed - (K + 3) + rnd() % (K + 3)] += 1 + rnd() % 3; break;
+                case 3: mut[rnd() % words] ^= 1u << (rnd() % 32); break;
+                default: mut.resize(words + 1 + rnd() % 9, 7); mw = mut.size(); break;
+                }
+                uint32_t *exact = new uint32_t[mw ? mw : 1];
+                memcpy(exact, mut.data(), mw * 4);
+                (void)ss_stwo_unshare_record(&c, exact, mw, back);
+                delete[] exact;
+                checks++;
+            }
+            // the text of this shared record, its template, the scalar rule
+            std::string text;
+            ss::TextTemplateHost t3;
+            ss::stwo_build_template(c, SS_TEXT_JSON_SHARED, t3);
+            if (!t3.ok || !ss::stwo_write_json_shared(c, shr, words, rep & 1 ? ss::kStylePython : ss::kStyleCompact, text)) { fprintf(stderr, "no shared text\n"); return 1; }
+            if (!ss::shared_text_scan_reference(c, t3, text.data(), text.size(), back) || memcmp(back, rec, Wc * 4) != 0) { fprintf(stderr, "shared text does not read back\n"); return 1; }
+            for (int i = 0; i < mutants / 20; i++) {
+                const std::string mt = mutate(text);
+                char *exact = new char[mt.size() ? mt.size() : 1];
+                memcpy(exact, mt.data(), mt.size());
+                shared_taken += ss::shared_text_scan_reference(c, t3, exact, mt.size(), back);
+                delete[] exact;
+                checks++;
+            }
+            delete[] back;
+            delete[] shr;
+            delete[] rec;
+        }
+    }
+
+    // ---- the worker pool (csrc/ss_pool.cpp): an exception in an item fails the call on the CALLING thread and leaves the
+    // pool usable; a fork()ed child (no worker threads of its own) runs items inline and exits without touching the pool
+    {
+        bool caught = false;
+        try {
+            ss::parallel_for(1000, [](size_t i) { if (i == 517) throw std::runtime_error("item 517"); }, 8);
+        } catch (const std::runtime_error &e) {
+            caught = strcmp(e.what(), "item 517") == 0;
+        }
+        std::vector<int> seen(2000, 0);
+        ss::parallel_for(seen.size(), [&](size_t i) { seen[i] = 1; }, 8);
+        size_t done = 0;
+        for (int v : seen) done += v;
+        if (!caught || done != seen.size()) { fprintf(stderr, "pool: exception not delivered or pool unusable afterwards\n"); return 1; }
+        const pid_t child = fork();
+        if (child == 0) {
+            std::vector<int> c2(100, 0);
+            ss::parallel_for(c2.size(), [&](size_t i) { c2[i] = 1; }, 8);
+            size_t d2 = 0;
+            for (int v : c2) d2 += v;
+            // (_exit: LeakSanitizer would report the vanished worker threads' allocations as leaks of the child; the pool
+            // itself has no destructor that could run at exit -- it is allocated once and never freed)
+            _exit(d2 == c2.size() ? 0 : 3);
+        }
+        int st = 0;
+        if (waitpid(child, &st, 0) != child || !WIFEXITED(st) || WEXITSTATUS(st) != 0) { fprintf(stderr, "pool: forked child failed (%d)\n", st); return 1; }
+        checks += 3;
+    }
+    printf("host_san: %zu checks, %zu mutants taken by the scalar rule, %zu shared-text mutants\n", checks, taken, shared_taken);
     return 0;
 }
