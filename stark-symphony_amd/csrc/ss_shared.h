@@ -10,7 +10,7 @@
 // every expanded path in full, so a wrong hint can only make a proof fail.
 //
 // Closed form of the first-use order (what the kernel and the host functions compute; the walk itself is
-// restated in oracle/ss_oracle_shared.c and formats.shared_path_order and compared in the tests):
+// restated independently by the test checker and by formats.shared_path_order, and compared in the tests):
 //   d(q, q')   = bit length of pos[q] ^ pos[q']  = the lowest level (from the leaf of the LDE-sized tree) at
 //                which the two queries sit at the same position;
 //   s(q)       = min over q' < q of d(q, q')  (32 for q = 0): below level s(q) no earlier query has been where q is;
