@@ -127,6 +127,32 @@ def main():
                 i = int(np.nonzero(got != want)[0][0])
                 print("   first mismatch at %d: gpu %#x oracle %#x" % (i, got[i], want[i]))
             bad += mism
+        # the same mutants as SHARED records (every distinct sibling once, expanded on the GPU: round 4) wherever a mutant
+        # still has a shared form, + structure mutants of the honest shared record (hints, counts, sizes, bits anywhere)
+        if base.cfg.n_queries > 1:
+            qs = formats.stwo_queries(base)
+            keep, shared = [], []
+            for i, m in enumerate(muts):
+                try:
+                    shared.append(verifier.stwo_shared_record(m, qs))
+                    keep.append(i)
+                except ValueError:
+                    pass
+            want_all = O.stwo_verify_batch(muts, verifier.MODE_FIXTURE)
+            got = ver.verify_stwo_shared_records(base.cfg, shared, verifier.MODE_FIXTURE)
+            mism = int((got != want_all[keep]).sum())
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from test_shared_records import shared_mutants
+            sm = shared_mutants(base.cfg, shared[0], rng, min(N, 400))
+            exp = []
+            for m in sm:
+                orc, orec = O.shared_expand(base.cfg, m)
+                exp.append(2 if orc else int(O.stwo_verify_batch([records.stwo_from_record(base.cfg, orec)], verifier.MODE_FIXTURE)[0]))
+            got2 = ver.verify_stwo_shared_records(base.cfg, sm, verifier.MODE_FIXTURE)
+            mism += int((got2 != np.array(exp, dtype=np.uint32)).sum())
+            print("stwo %-16s shared records: %d of the mutants have a shared form, %d structure mutants (%d refused), mismatches %d"
+                  % (name, len(keep), len(sm), sum(1 for e in exp if e == 2), mism), flush=True)
+            bad += mism
     print("TOTAL mismatches:", bad)
     sys.exit(1 if bad else 0)
 

@@ -14,11 +14,11 @@ import sys
 
 
 def short(name: str) -> str:
-    m = re.search(r"(stwo_\w+|s101_\w+|p_\w+)", name)
+    m = re.search(r"(stwo_\w+|s101_\w+|text_\w+|p_\w+)", name)
     return m.group(1) if m else name.split("(")[0][-40:]
 
 
-def summarise(dirs, newest_only=False):
+def summarise(dirs, newest_only=False, keep=None):
     """newest_only: of several runs merged into one directory, read only the latest file"""
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     dur = collections.defaultdict(list)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where one process-per-proof run spends its time (the reference's `make run` convention): HIP start-up, context,
-first and second call of the text entry point.  python tools/r03/latency_probe.py"""
+first and second call of the text entry point.  python tools/probes/latency_probe.py"""
 import ctypes as C
 import os
 import sys

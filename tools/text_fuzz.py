@@ -29,7 +29,10 @@ from test_text_fastpath import _number_mutant, canonical, write_text, s101_canon
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
 SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 20261007
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-JSON, WIT = binding.TEXT_JSON, binding.TEXT_WIT
+JSON, WIT, SHARED = binding.TEXT_JSON, binding.TEXT_WIT, binding.TEXT_JSON_SHARED
+
+
+HOST_FMT = {JSON: JSON, WIT: WIT, SHARED: JSON}  # the host reader knows the shared form by its "queries" member
 
 
 def cases():
@@ -45,16 +48,27 @@ def main():
     bad = 0
     for name, p in cases():
         rec = verifier.stwo_record(p)
-        for fmt, kind in ((JSON, "json"), (WIT, "wit")):
-            base = write_text(p.cfg, rec, fmt, rnd.randrange(2))
+        for fmt, kind in ((JSON, "json"), (WIT, "wit"), (SHARED, "json-shared")):
+            if fmt == SHARED:  # every distinct Merkle sibling once + "queries": read and expanded on the GPU (round 4)
+                obj = ss.stwo_to_json(p, shared=True)
+                base = (json.dumps(obj) if rnd.randrange(2) else json.dumps(obj, separators=(",", ":"))).encode()
+            else:
+                base = write_text(p.cfg, rec, fmt, rnd.randrange(2))
             n = N if len(base) < 300000 else max(200, N // 8)
             texts = []
             for i in range(n):
                 t = _text_mutant(rnd, base) if i % 3 == 0 else _number_mutant(rnd, base)
                 if i % 5 == 0:
                     t = _number_mutant(rnd, t)
-                if i % 7 == 0 and fmt == JSON:
+                if i % 7 == 0 and fmt != WIT:
                     t = b" " * rnd.randrange(1, 1100) + t
+                if fmt == SHARED and i % 9 == 0:  # another position in the hint (the lists then rarely fit it)
+                    try:
+                        o = json.loads(base)
+                        o["queries"][rnd.randrange(p.cfg.n_queries)] = rnd.randrange(1 << p.cfg.lde_log)
+                        t = json.dumps(o, separators=(",", ":")).encode()
+                    except ValueError:
+                        pass
                 texts.append(t)
             recs, outcome = ver.read_stwo_texts(p.cfg, texts, fmt)
             taken = changed = 0
@@ -66,7 +80,7 @@ def main():
                     continue
                 if want:
                     taken += 1
-                    got, hrec = verifier.parse_stwo_text(p.cfg, t, fmt=fmt)
+                    got, hrec = verifier.parse_stwo_text(p.cfg, t, fmt=HOST_FMT[fmt])
                     if got != 0 or not np.array_equal(recs[i], srec) or not np.array_equal(hrec, srec):
                         bad += 1
                         print("RECORD", name, kind, i, got, t[:100])
@@ -76,7 +90,7 @@ def main():
             status, stats = ver.verify_stwo_texts(p.cfg, sample, fmt=fmt)
             ok_recs, ok_idx = [], []
             for i, t in enumerate(sample):
-                got, hrec = verifier.parse_stwo_text(p.cfg, t, fmt=fmt)
+                got, hrec = verifier.parse_stwo_text(p.cfg, t, fmt=HOST_FMT[fmt])
                 if got == 0:
                     ok_recs.append(hrec); ok_idx.append(i)
                 elif status[i] != got:
