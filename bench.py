@@ -91,13 +91,12 @@ def load_workload(name: str):
     raise SystemExit("unknown workload %r" % name)
 
 
-MERKLE_STAGE_SOURCES = ("ss_stwo.hip", "ss_stwo_checks.h", "ss_sha256.h", "ss_hash.h", "ss_layout.h", "ss_fields.h", "ss_channel.h",
-                        "ss_stark101.hip")
+MERKLE_STAGE_SOURCES = ("ss_stwo.hip", "ss_stwo_checks.h", "ss_sha256.h", "ss_hash.h", "ss_layout.h", "ss_fields.h", "ss_channel.h")
 
 
 def kernel_sources_digest() -> str:
-    """sha256 over the sources that define the verifier kernels: what ties a committed counter profile to the code
-    that is running (the GPU box has no .git to ask for a commit)."""
+    """sha256 over the sources that define the stwo verifier kernels (the counter profiles are of the stwo metric
+    config): what ties a committed counter profile to the code that is running (the GPU box has no .git to ask for a commit)."""
     import hashlib
     h = hashlib.sha256()
     for name in MERKLE_STAGE_SOURCES:
