@@ -64,6 +64,10 @@ int ss_p_hash_qm31(ss_ctx *ctx, uint32_t hash, size_t n, const uint32_t *vals, u
 /* Merkle tree over n = 2^k leaf hashes: levels[0 .. 2n-1) = leaves (n), then n/2 parents, ...,
  * root last; node = H(left || right).  `levels` already holds the leaves in [0, n).          */
 int ss_p_merkle(ss_ctx *ctx, uint32_t hash, size_t n_leaves, uint32_t *levels, void *stream);
+/* out[i] = H(leaf[i] || leaf[i]), n hashes: the first node level of a tree whose leaves come in equal pairs (the 16
+ * composition columns are polynomials in x alone, so the two points (x, +-y) of a storage pair have the same row and
+ * the same leaf hash): the 2n duplicated leaves need not exist in memory.                                          */
+int ss_p_merkle_dup(ss_ctx *ctx, uint32_t hash, size_t n, const uint32_t *leaf, uint32_t *out, void *stream);
 
 /* Composition polynomial on the canonic coset of log size n+1 (hx_c = its pair x coordinates):
  * F = (sum_k alpha^(N-1-k) (c_k - c_{k-1}^2 - c_{k-2}^2)) / pi^(n-1)(x), out[coord][i].     */

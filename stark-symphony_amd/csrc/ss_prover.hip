@@ -305,6 +305,24 @@ __global__ void p_merkle_level_kernel(size_t n_parents, const uint32_t *__restri
     o[1] = make_uint4(Hasher<HF>::native(d[4]), Hasher<HF>::native(d[5]), Hasher<HF>::native(d[6]), Hasher<HF>::native(d[7]));
 }
 
+// parent[i] = H(leaf[i] || leaf[i]): a tree whose leaves come in equal pairs
+template <int HF>
+__global__ void p_merkle_dup_kernel(size_t n, const uint32_t *__restrict__ leaf, uint32_t *__restrict__ parents)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4 *c = reinterpret_cast<const uint4 *>(leaf + i * 8);
+    const uint4 a0 = c[0], a1 = c[1];
+    const uint32_t l[8] = {Hasher<HF>::native(a0.x), Hasher<HF>::native(a0.y), Hasher<HF>::native(a0.z),
+                           Hasher<HF>::native(a0.w), Hasher<HF>::native(a1.x), Hasher<HF>::native(a1.y),
+                           Hasher<HF>::native(a1.z), Hasher<HF>::native(a1.w)};
+    uint32_t d[8];
+    Hasher<HF>::template pair<true>(l, l, d);
+    uint4 *o = reinterpret_cast<uint4 *>(parents + i * 8);
+    o[0] = make_uint4(Hasher<HF>::native(d[0]), Hasher<HF>::native(d[1]), Hasher<HF>::native(d[2]), Hasher<HF>::native(d[3]));
+    o[1] = make_uint4(Hasher<HF>::native(d[4]), Hasher<HF>::native(d[5]), Hasher<HF>::native(d[6]), Hasher<HF>::native(d[7]));
+}
+
 // ----------------------------------------------------------------------------- composition
 __global__ void p_composition_kernel(uint32_t n_log, uint32_t n_cols, const uint32_t *__restrict__ ev,
                                      const uint32_t *__restrict__ hx, QM31 alpha, uint32_t *__restrict__ out)
@@ -682,6 +700,18 @@ extern "C" int ss_p_merkle(ss_ctx *ctx, uint32_t hash, size_t n_leaves, uint32_t
                                parents, children, out);
         off += n;
     }
+    P_TRY(hipGetLastError());
+    return SS_OK;
+}
+
+extern "C" int ss_p_merkle_dup(ss_ctx *ctx, uint32_t hash, size_t n, const uint32_t *leaf, uint32_t *out, void *stream)
+{
+    SS_DEVICE_GUARD(ctx);
+    if (!leaf || !out || !n || hash > 1) return ss_internal_set_err(SS_ERR_ARG, "ss_p_merkle_dup: bad argument");
+    if (hash)
+        hipLaunchKernelGGL(p_merkle_dup_kernel<1>, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, n, leaf, out);
+    else
+        hipLaunchKernelGGL(p_merkle_dup_kernel<0>, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, n, leaf, out);
     P_TRY(hipGetLastError());
     return SS_OK;
 }

@@ -129,6 +129,7 @@ class GpuProver:
         sig("ss_p_hash_rows", C.c_uint32, sz, C.c_uint32, u32p, sz, u32p)
         sig("ss_p_hash_qm31", C.c_uint32, sz, u32p, u32p)
         sig("ss_p_merkle", C.c_uint32, sz, u32p)
+        sig("ss_p_merkle_dup", C.c_uint32, sz, u32p, u32p)
         sig("ss_p_composition", C.c_uint32, C.c_uint32, u32p, u32p, u32p, u32p)
         sig("ss_p_eval_at_point", C.c_uint32, u32p, u32p, u32p, u32p)
         sig("ss_p_eval_at_point_batch", C.c_uint32, C.c_uint32, u32p, sz, u32p, u32p, u32p)
@@ -307,12 +308,14 @@ class GpuProver:
         cp_lde = self.extend(cp_coefs, L, x_only=True)  # [16, 2^(L-1)]: position i -> column value at i >> 1
         half_L = size_L >> 1
 
-        def cp_leaves(lv):
-            pair_leaf = self._empty(half_L, 8)
-            self._call("ss_p_hash_rows", hsel, half_L, 16, cp_lde.data_ptr(), half_L, pair_leaf.data_ptr())
-            lv[:size_L].view(half_L, 2, 8).copy_(pair_leaf[:, None, :].expand(half_L, 2, 8))
-        cp_tree = self.merkle(hsel, cp_leaves, size_L)
-        cp_root = self._root(cp_tree, size_L)
+        # The two leaves of a storage pair are equal, so the 2^L leaf hashes are 2^(L-1) distinct ones and the first node
+        # level is H(leaf || leaf): `cp_tree` holds the tree from that level up (its "leaves" are the level-1 nodes), the
+        # duplicated leaf level exists nowhere (round 3 wrote it out: 0.8 GB of copies per proof).
+        pair_leaf = self._empty(half_L, 8)
+        self._call("ss_p_hash_rows", hsel, half_L, 16, cp_lde.data_ptr(), half_L, pair_leaf.data_ptr())
+        cp_tree = self.merkle(hsel, lambda lv: self._call(
+            "ss_p_merkle_dup", hsel, half_L, pair_leaf.data_ptr(), lv.data_ptr()), half_L)
+        cp_root = self._root(cp_tree, half_L)
         mark("composition commit")
         ch.mix(cp_root)
 
@@ -436,7 +439,9 @@ class GpuProver:
         lde_t, cp_lde_t = lde.T, cp_lde.T  # views: row = LDE position
         k_tq, k_cq = g.rows(lde_t, queries), g.rows(cp_lde_t, [q >> 1 for q in queries])  # [Q, N], [Q, 16]
         k_thw = g.rows(trace_tree, self._path_rows(size_L, queries))
-        k_chw = g.rows(cp_tree, self._path_rows(size_L, queries))
+        # composition tree: the sibling of leaf q is the other leaf of its pair (the same hash); above it, the tree over the pairs
+        k_chw0 = g.rows(pair_leaf, [q >> 1 for q in queries])
+        k_chw = g.rows(cp_tree, self._path_rows(half_L, [q >> 1 for q in queries]))
         k_layers = []
         cur_q = list(queries)
         for l in range(K + 1):
@@ -457,7 +462,8 @@ class GpuProver:
             np.stack([np.frombuffer(r, dtype=np.uint8) for r in (const_root, trace_root, cp_root)]),
             np.array(oods_trace, dtype=np.uint32).reshape(N, 4), np.array(oods_cp, dtype=np.uint32).reshape(16, 4),
             got[k_tq].reshape(Q, N).copy(), got[k_cq].reshape(Q, 16).copy(),
-            list(hashes(got[k_thw], Q, L)), list(hashes(got[k_chw], Q, L)),
+            list(hashes(got[k_thw], Q, L)),
+            list(hashes(np.concatenate([got[k_chw0].reshape(Q, 1, 8), got[k_chw].reshape(Q, L - 1, 8)], axis=1), Q, L)),
             np.stack([np.frombuffer(r, dtype=np.uint8) for r in roots]), np.array(last, dtype=np.uint32),
             np.stack([got[ks].reshape(Q, 4) for ks, _ in k_layers]),
             [list(hashes(got[kh], Q, L - 1 - l)) for l, (_, kh) in enumerate(k_layers)], nonce)

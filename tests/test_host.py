@@ -32,7 +32,7 @@ def test_library_exports_every_prover_symbol():
     lib = binding.lib()
     hdr = open(os.path.join(ROOT, "include", "ss_prover.h")).read()
     declared = set(re.findall(r"\b(ss_p[a-z0-9_]+)\s*\(", hdr))
-    assert len(declared) == 19
+    assert len(declared) == 20
     for name in declared:
         assert hasattr(lib, name), name
 
