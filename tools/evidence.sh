@@ -31,6 +31,7 @@ if want sha; then
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/sha_bench.hip -o build/sha_bench 2>/dev/null && build/sha_bench 512 > $O/sha_bench.txt 2>&1
 fi
 if want host; then
+  rm -f $O/host_path.txt
   for n in 2048 16384; do
     python tools/host_path_bench.py $n >> $O/host_path.txt 2>&1
     python tools/host_path_bench.py $n distinct >> $O/host_path.txt 2>&1
@@ -91,7 +92,7 @@ for f in sorted(glob.glob(O + '/e2e_*.json')):
     print(os.path.basename(f), {k: (round(v['proofs_per_s_best']), round(v['text_GB_per_s_best'], 1), v.get('host_parsed'),
                                     round(v.get('files_proofs_per_s_best') or 0)) for k, v in d.items() if isinstance(v, dict)})
 PY
-[ -f $O/host_path.txt ] && grep -v amdgpu.ids $O/host_path.txt | tail -4
+[ -f $O/host_path.txt ] && grep -v amdgpu.ids $O/host_path.txt | tail -8
 [ -f $O/prover_bench.txt ] && grep prove_many $O/prover_bench.txt
 [ -f $O/fuzz_parity.txt ] && tail -1 $O/fuzz_parity.txt
 [ -f $O/text_fuzz.txt ] && tail -1 $O/text_fuzz.txt
