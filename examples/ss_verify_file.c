@@ -7,6 +7,8 @@
  *
  *   ss_verify_file stwo <n_cols> <trace_log> <lde_log> <n_queries> <n_layers> <pow_bits> <hash 0|1> \
  *                  <mode 0|1> records.bin
+ *   ss_verify_file stwo-shared <the same nine numbers> shared.bin      (ABI 2.2: SHARED records back to back -- every
+ *                  distinct Merkle sibling once; a record says how long it is: fixed words + 8 * sum of its counts)
  *   ss_verify_file stark101 <max_layers> <max_path> records.bin
  *
  * records.bin = the records back to back, little-endian u32 words (include/ss_verify.h; written by
@@ -39,7 +41,8 @@ static uint32_t *read_words(const char *path, size_t *n_words)
 int main(int argc, char **argv)
 {
     if (argc < 2) { fprintf(stderr, "usage: see the header of examples/ss_verify_file.c\n"); return 2; }
-    const int stwo = strcmp(argv[1], "stwo") == 0;
+    const int shared = strcmp(argv[1], "stwo-shared") == 0;
+    const int stwo = shared || strcmp(argv[1], "stwo") == 0;
     if ((stwo && argc != 11) || (!stwo && (strcmp(argv[1], "stark101") != 0 || argc != 5))) {
         fprintf(stderr, "usage: see the header of examples/ss_verify_file.c\n");
         return 2;
@@ -72,17 +75,41 @@ int main(int argc, char **argv)
     size_t n_words = 0;
     uint32_t *words = read_words(path, &n_words);
     if (!words) return 2;
-    if (n_words % rec_words) { fprintf(stderr, "%s: %zu words is not a multiple of the %zu-word record\n", path, n_words, rec_words); return 2; }
-    const size_t n = n_words / rec_words;
-    const uint32_t **recs = (const uint32_t **)malloc(n * sizeof *recs);
-    uint32_t *status = (uint32_t *)malloc(n * sizeof *status);
-    for (size_t i = 0; i < n; i++) recs[i] = words + i * rec_words;
+    size_t n = 0;
+    const uint32_t **recs;
+    size_t *lens = NULL;
+    if (shared) {
+        /* split the file: a shared record is ss_stwo_shared_fixed_words words -- the last 3 + n_layers of them its
+         * counts -- followed by 8 words per counted node.  Whether the counts are the ones its positions imply is
+         * the library's business (SS_STATUS_MALFORMED), not this program's. */
+        const size_t fixed = ss_stwo_shared_fixed_words(&cfg), trees = 3 + cfg.n_layers, max_words = ss_stwo_shared_max_words(&cfg);
+        recs = (const uint32_t **)malloc((n_words / fixed + 1) * sizeof *recs);
+        lens = (size_t *)malloc((n_words / fixed + 1) * sizeof *lens);
+        for (size_t o = 0; o < n_words;) {
+            size_t len = fixed;
+            if (o + fixed > n_words) len = n_words - o;  /* a truncated tail: handed over as it is */
+            else {
+                for (size_t t = 0; t < trees; t++) len += 8 * (size_t)words[o + fixed - trees + t];
+                if (len > max_words || o + len > n_words) len = n_words - o;
+            }
+            recs[n] = words + o;
+            lens[n++] = len;
+            o += len;
+        }
+    } else {
+        if (n_words % rec_words) { fprintf(stderr, "%s: %zu words is not a multiple of the %zu-word record\n", path, n_words, rec_words); return 2; }
+        n = n_words / rec_words;
+        recs = (const uint32_t **)malloc(n * sizeof *recs);
+        for (size_t i = 0; i < n; i++) recs[i] = words + i * rec_words;
+    }
+    uint32_t *status = (uint32_t *)malloc((n ? n : 1) * sizeof *status);
 
     ss_ctx *ctx = NULL;
     int rc = ss_ctx_create(0, &ctx);
     if (rc == SS_OK)
-        rc = stwo ? ss_stwo_verify_records(ctx, &cfg, n, recs, status)
-                  : ss_s101_verify_records(ctx, &shape, n, recs, status);
+        rc = shared ? ss_stwo_verify_shared_records(ctx, &cfg, n, recs, lens, status)
+             : stwo ? ss_stwo_verify_records(ctx, &cfg, n, recs, status)
+                    : ss_s101_verify_records(ctx, &shape, n, recs, status);
     if (rc != SS_OK) {  /* no CPU fallback: a missing GPU is an error, never a verdict */
         fprintf(stderr, "libss_verify: %s (code %d)\n", ss_last_error(), rc);
         return 2;
@@ -93,6 +120,6 @@ int main(int argc, char **argv)
         else printf("proof %zu: ACCEPT\n", i);
     }
     ss_ctx_destroy(ctx);
-    free(status); free(recs); free(words);
+    free(status); free(recs); free(lens); free(words);
     return rejected ? 1 : 0;
 }

@@ -435,6 +435,24 @@ def test_c_abi_consumer_program(ver, tmp_path, s101_proof, stwo_prod):
     ok = tmp_path / "one.bin"
     verifier.stwo_record(stwo_prod).astype("<u4").tofile(ok)
     assert subprocess.run(args[:-1] + [str(ok)], capture_output=True).returncode == 0
+    # the same from SHARED records (ABI 2.2): the proofs that have a shared form, back to back in one file
+    qs = formats.stwo_queries(stwo_prod)
+    sh, sh_want = [], []
+    for p, w in zip(proofs, want.tolist()):
+        try:
+            sh.append(verifier.stwo_shared_record(p, qs))
+            sh_want.append(w)
+        except ValueError:
+            pass
+    assert len(sh) >= 3 and sh_want[0] == 0
+    spath = tmp_path / "shared.bin"
+    np.concatenate(sh).astype("<u4").tofile(spath)
+    r = subprocess.run([exe, "stwo-shared"] + args[2:-1] + [str(spath)], capture_output=True, text=True)
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == len(sh), r.stderr
+    for i, w in enumerate(sh_want):
+        assert lines[i] == ("proof %d: ACCEPT" % i if w == 0 else "proof %d: REJECT (first failing assert 0x%08x)" % (i, w))
+    assert r.returncode == (1 if any(sh_want) else 0)
     ml, pm = verifier.s101_shape_of([s101_proof])
     p101 = tmp_path / "s101.bin"
     verifier.s101_record(s101_proof, ml, pm).astype("<u4").tofile(p101)
