@@ -6,7 +6,10 @@
 For every random configuration (columns, trace size, blow-up, queries incl. non powers of two up to 64,
 PoW bits, hash family) the GPU prover makes a proof; the valid proof and seeded mutants of it
 (tools/fuzz_parity.mutate_stwo) must get the oracle's status word from the GPU verifier in both
-modes, with the pair memoisation on and off."""
+modes, with the pair memoisation on and off.  Since round 4 the same batch also goes through the SHARED forms (every
+distinct Merkle sibling once): as shared records through ss_stwo_verify_shared_records and, the honest proof, as
+shared-path proof.json through the GPU reader -- the status words of the per-query form."""
+import json
 import os
 import sys
 
@@ -17,7 +20,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 import fuzz_parity as fz  # noqa: E402
-from stark_symphony_amd import prover, verifier  # noqa: E402
+import stark_symphony_amd as ss  # noqa: E402
+from stark_symphony_amd import formats, prover, verifier  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 shapes = int(sys.argv[1]) if len(sys.argv) > 1 else 100
@@ -49,6 +53,26 @@ for i in range(shapes):
                 j = int(np.nonzero(got != want)[0][0])
                 print("MISMATCH", kw, "mode", mode, name, "at", j, hex(got[j]), hex(want[j]), flush=True)
                 bad += m
+    # the shared forms of the same batch (query counts that do not divide 64, one query, many columns ...)
+    qs = formats.stwo_queries(proof)
+    keep, shared = [], []
+    for j, p in enumerate(batch):
+        try:
+            shared.append(verifier.stwo_shared_record(p, qs))
+            keep.append(j)
+        except ValueError:
+            pass
+    want = O.stwo_verify_batch(batch, verifier.MODE_FIXTURE)
+    got = ver.verify_stwo_shared_records(proof.cfg, shared, verifier.MODE_FIXTURE)
+    m = int((got != want[keep]).sum())
+    text = json.dumps(ss.stwo_to_json(proof, shared=True, queries=qs), separators=(",", ":")).encode()
+    st, stats = ver.verify_stwo_texts(proof.cfg, [text, text + b"\n"])
+    if st.tolist() != [0, 0] or stats["host_parsed"] != 0:
+        print("SHARED TEXT", kw, st.tolist(), stats["host_parsed"], flush=True)
+        m += 1
+    if m:
+        print("MISMATCH (shared forms)", kw, m, flush=True)
+        bad += m
     if mode == verifier.MODE_LITERAL and i % 10 == 9:
         print("%d shapes done, last %s" % (i + 1, kw), flush=True)
 print("shapes %d, total mismatches %d" % (shapes, bad))
