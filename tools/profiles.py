@@ -140,7 +140,7 @@ for name, src, head in (("sha_calibration.txt", "sha_bench.txt", "$ build/sha_be
                         ("prover_bench.txt", "prover_bench.txt", "$ python tools/prover_bench.py 20 3 sha256 1,4,4,3 48; python tools/prover101_bench.py   (at %s)" % commit),
                         ("fuzz_parity.txt", "fuzz_parity.txt", "$ python tools/fuzz_parity.py 20000 20261004   (at %s; GPU status words against the oracle, per-query and shared records)" % commit),
                         ("text_fuzz.txt", "text_fuzz.txt", "$ python tools/text_fuzz.py 4000 20261004   (at %s; GPU reader against the scalar rule and the host reader, json / wit / json-shared)" % commit),
-                        ("shape_sweep.txt", "shape_sweep.txt", "$ python tools/shape_sweep.py 100 4   (at %s)" % commit)):
+                        ("shape_sweep.txt", "shape_sweep.txt", "$ python tools/shape_sweep.py <shapes> <seed>   (at %s; the last line says how many)" % commit)):
     path = os.path.join(G, src)
     if os.path.exists(path):
         body = [l for l in open(path).read().splitlines() if "amdgpu.ids" not in l]
