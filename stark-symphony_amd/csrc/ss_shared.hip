@@ -233,7 +233,8 @@ extern "C" int ss_stwo_verify_shared_records(ss_ctx *ctx, const ss_stwo_cfg *c, 
         while (lo < n) {
             first.push_back(lo);
             size_t w = 0, hi = lo;
-            while (hi < n && (hi == lo || w + sent(hi) <= step_words)) w += sent(hi++);
+            // (and at most 256 MiB of expanded records per chunk, however short -- e.g. malformed -- the inputs are)
+            while (hi < n && (hi == lo || (w + sent(hi) <= step_words && (hi - lo + 1) * W * 4 <= ((size_t)256 << 20)))) w += sent(hi++);
             lo = hi;
             step_words = std::min(budget, step_words * 2);
         }

@@ -260,3 +260,18 @@ def test_full_size_shared_texts_end_to_end(ver):
     batch = [texts[i % 4] for i in range(400)]
     status, stats = ver.verify_stwo_texts(p.cfg, batch)
     assert status.tolist() == [want[i % 4] for i in range(400)] and stats["host_parsed"] == 0 and want[0] == 0
+
+
+def test_many_short_records_do_not_size_the_scratch(ver):
+    """20 000 records of a few words each against the 2^20 config: every one is SS_STATUS_MALFORMED, and the call's
+    device scratch follows the 256 MiB of expanded records a chunk may hold, not 20 000 x 170 KB."""
+    import os
+    from conftest import GOLDEN
+    cfg = records.load_stwo_npz(os.path.join(GOLDEN, "stwo_trace20.npz"))[0].cfg
+    rng = np.random.default_rng(SEED + 55)
+    batch = [rng.integers(0, 1 << 32, size=int(rng.integers(0, 40)), dtype=np.uint64).astype(np.uint32) for _ in range(20000)]
+    import torch
+    before = torch.cuda.mem_get_info(0)[0]
+    got = ver.verify_stwo_shared_records(cfg, batch, verifier.MODE_FIXTURE)
+    assert (got == verifier.B.STATUS_MALFORMED).all()
+    assert before - torch.cuda.mem_get_info(0)[0] < (3 << 30)
