@@ -58,6 +58,11 @@ B2S_CALIBRATED_PEAK = 38.9e9  # Blake2s-256 compressions/s, same tool (one compr
 GEN_ONLY: dict = {}
 
 
+def hash_label(h: str) -> str:
+    """The reference has no Blake2s: every line measured with it says that its parity is unpinned."""
+    return "blake2s (PARITY UNPINNED: not a hash of the reference; RFC 7693 + prover / oracle / GPU agreement only)" if h == "blake2s" else h
+
+
 def load_workload(name: str):
     """-> (workload name, family, list of distinct proofs, note)"""
     import stark_symphony_amd as ss
@@ -77,11 +82,11 @@ def load_workload(name: str):
         proofs = records.load_stwo_npz(os.path.join(GOLDEN, fn))
         c = proofs[0].cfg
         return name, "stwo", proofs, "wide-Fibonacci 2^%d x %d, LDE 2^%d, Q=%d, K=%d, %s" % (
-            c.trace_log, c.n_cols, c.lde_log, c.n_queries, c.n_layers, c.hash)
+            c.trace_log, c.n_cols, c.lde_log, c.n_queries, c.n_layers, hash_label(c.hash))
     if name in GEN_ONLY:
         c = formats.StwoConfig(**GEN_ONLY[name])
         return name, "stwo", [], "wide-Fibonacci 2^%d x %d, LDE 2^%d, Q=%d, K=%d, %s" % (
-            c.trace_log, c.n_cols, c.lde_log, c.n_queries, c.n_layers, c.hash)
+            c.trace_log, c.n_cols, c.lde_log, c.n_queries, c.n_layers, hash_label(c.hash))
     if name == "stwo_fixture":
         p = ss.stwo_from_json(json.load(open(os.path.join(GOLDEN, "stwo_proof.json"))))
         return name, "stwo", [p], "reference proof.json (trace 2^9, LDE 2^13, Q=16, K=8) replicated"
@@ -711,6 +716,7 @@ def main() -> None:
                        "hash_compressions_per_proof": compr_per_proof,
                        "hash_compressions_executed_per_proof": executed,
                        "pair_memoisation": family == "stwo" and not args.no_dedup, "hash": hash_name,
+                       "parity": "unpinned (Blake2s is not in the reference)" if hash_name == "blake2s" else "pinned (reference KATs + proofs)",
                        "mode": "fixture_correct", "inflight_streams": nslot,
                        "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
                        "submission": "%d independent streams, whole passes" % args.streams if streams else
