@@ -502,3 +502,32 @@ def test_worker_pool_survives_a_fork(stwo_prod):
             os._exit(2)
     _, st = os.waitpid(pid, 0)
     assert os.WIFEXITED(st) and os.WEXITSTATUS(st) == 0
+
+
+def test_bench_uses_counter_profiles_only_for_the_sources_they_were_taken_on(tmp_path, monkeypatch):
+    """bench.pmc_profile: `roofline.traffic` and `alu_roofline.issue_frac` come from a committed
+    counter profile only while the digest of the kernel sources recorded in it is the digest of the sources in the
+    tree; a profile of other sources yields null figures and says why."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    digest = bench.kernel_sources_digest()
+    assert len(digest) == 64 and digest == bench.kernel_sources_digest()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    row = {"workload": "stwo_2p20", "commit": "abc1234", "kernel_sources_sha256": digest,
+           "hbm_bytes_per_proof": 300000.0, "valu_instructions_per_proof": 170000.0}
+    (prof / "r99_hbm_traffic.json").write_text(json.dumps(row))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_sources_digest", lambda: digest)
+    t, i, src = bench.pmc_profile("stwo_2p20", 1000)
+    assert t == 3e8 and i == 1.7e8 and "r99_hbm_traffic.json" in src
+    row["kernel_sources_sha256"] = "0" * 64
+    (prof / "r99_hbm_traffic.json").write_text(json.dumps(row))
+    t, i, src = bench.pmc_profile("stwo_2p20", 1000)
+    assert t is None and i is None and "other kernel sources" in src
+    assert bench.pmc_profile("no_such_workload", 1)[0] is None
+    # the committed profile: either of the sources in this tree (figures used) or of others (figures null, reason given)
+    monkeypatch.undo()
+    t, i, src = bench.pmc_profile("stwo_2p20", 65536)
+    assert (t and i and "the ones in this tree" in src) or (t is None and i is None and "other kernel sources" in src), src
