@@ -243,6 +243,150 @@ p_fft_pass_kernel(uint32_t m, uint32_t lo, uint32_t nb, uint32_t cpb_log, uint32
     for (uint32_t e = tid; e < elems; e += 256) col[gaddr(e)] = tile[laddr(e)];
 }
 
+// The strided pass again, with the layers in REGISTERS: a tile of 2^(A+4) rows x 32 lanes is a 2^A x 16 array of rows, and
+// its A + 4 layers split into a radix-2^A stage over the upper row bits (a thread holds the 2^A rows k * 16 + r_lo of one
+// lane: their twiddles depend on k only) and a radix-16 stage over the lower four (the 16 rows r_hi * 16 + k: twiddles
+// from r_hi and k), with ONE exchange through LDS in between.  Against p_fft_pass_kernel<false> -- a tile staged in LDS,
+// two layers per LDS round trip, every butterfly's operands addressed anew -- an element costs one LDS write and one read
+// instead of ten LDS accesses, its global load and store go straight from and to registers, and the index arithmetic is
+// per 16 rows instead of per 4.  Same butterflies on canonical values, so the same words come out.
+//   forward: stage A (layers A+3 .. 4), exchange, stage B (layers 3 .. 0);  inverse: B (0 .. 3), exchange, A (4 .. A+3), scale.
+//   LDE top pass (src): rows at or above `live` are zero and the top z layers copy (v0 + 0 w = v0 - 0 w = v0).
+template <int A>
+__global__ void __launch_bounds__(256)
+p_fft_pass16_kernel(uint32_t m, uint32_t lo, uint32_t *__restrict__ data, const uint32_t *__restrict__ tw, int inverse,
+                    uint32_t scale, const uint32_t *__restrict__ src, uint32_t z)
+{
+    constexpr uint32_t NB = A + 4, ROWS = 1u << NB, RA = 1u << A;
+    __shared__ uint32_t tile[ROWS * kFftTp];
+    __shared__ uint32_t twl[ROWS];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t chunks = (1u << lo) / kFftT;
+    const uint32_t hi = blockIdx.x / chunks;
+    uint32_t *col = data + ((size_t)blockIdx.y << m);
+    const size_t base = ((size_t)hi << (lo + NB)) + (size_t)(blockIdx.x % chunks) * kFftT;
+    for (uint32_t ip = 0; ip < NB; ip++) {  // layer ip of the tile at twl[ROWS - (ROWS >> ip) ..]
+        const size_t goff = ((size_t)1 << m) - ((size_t)1 << (m - lo - ip));
+        const uint32_t cnt = ROWS >> (ip + 1);
+        for (uint32_t q = tid; q < cnt; q += 256) twl[ROWS - (ROWS >> ip) + q] = tw[goff + ((size_t)hi << (NB - 1 - ip)) + q];
+    }
+    __syncthreads();
+    auto TW = [&](uint32_t ip, uint32_t hl) { return twl[ROWS - (ROWS >> ip) + hl]; };
+    const uint32_t first_copy = NB - z;  // layers at or above this one pair a row with a zero row (LDE top pass only)
+    auto fwd = [&](uint32_t &v0, uint32_t &v1, uint32_t ip, uint32_t hl) {
+        if (ip >= first_copy) { v1 = v0; return; }
+        const uint32_t x = m31_mul_c(v1, TW(ip, hl));
+        v1 = m31_sub_c(v0, x);
+        v0 = m31_add_c(v0, x);
+    };
+    auto inv = [&](uint32_t &v0, uint32_t &v1, uint32_t ip, uint32_t hl) {
+        const uint32_t sum = m31_add_c(v0, v1);
+        v1 = m31_mul_c(m31_sub_c(v0, v1), TW(ip, hl));
+        v0 = sum;
+    };
+    const uint32_t c = tid & 31, rx = tid >> 5;
+    const uint32_t *scol = src ? src + ((size_t)blockIdx.y << (m - z)) : nullptr;
+    const uint32_t live = ROWS >> z;
+    const bool last = inverse && lo + NB == m && scale != 1;
+    if (!inverse) {
+        // ---- stage A: rows k * 16 + r_lo
+#pragma unroll
+        for (uint32_t j = 0; j < 2; j++) {
+            const uint32_t r_lo = rx + 8 * j;
+            uint32_t v[RA];
+#pragma unroll
+            for (uint32_t k = 0; k < RA; k++) {
+                const uint32_t row = k * 16 + r_lo;
+                const size_t g = base + ((size_t)row << lo) + c;
+                v[k] = scol ? (row < live ? scol[g] : 0u) : col[g];
+            }
+#pragma unroll
+            for (int s = A - 1; s >= 0; s--) {
+#pragma unroll
+                for (uint32_t k = 0; k < RA; k++)
+                    if (!(k & (1u << s))) fwd(v[k], v[k + (1u << s)], 4 + s, k >> (s + 1));
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < RA; k++) tile[(k * 16 + r_lo) * kFftTp + c] = v[k];
+        }
+        __syncthreads();
+        // ---- stage B: rows r_hi * 16 + k
+#pragma unroll
+        for (uint32_t j = 0; j < (RA * 32 + 255) / 256; j++) {
+            const uint32_t item = tid + 256 * j;
+            if (item < RA * 32) {
+                const uint32_t r_hi = item >> 5;
+                uint32_t u[16];
+#pragma unroll
+                for (uint32_t k = 0; k < 16; k++) u[k] = tile[(r_hi * 16 + k) * kFftTp + c];
+#pragma unroll
+                for (int s = 3; s >= 0; s--) {
+#pragma unroll
+                    for (uint32_t k = 0; k < 16; k++)
+                        if (!(k & (1u << s))) fwd(u[k], u[k + (1u << s)], s, (r_hi << (3 - s)) + (k >> (s + 1)));
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < 16; k++) col[base + ((size_t)(r_hi * 16 + k) << lo) + c] = u[k];
+            }
+        }
+    } else {
+#pragma unroll
+        for (uint32_t j = 0; j < (RA * 32 + 255) / 256; j++) {
+            const uint32_t item = tid + 256 * j;
+            if (item < RA * 32) {
+                const uint32_t r_hi = item >> 5;
+                uint32_t u[16];
+#pragma unroll
+                for (uint32_t k = 0; k < 16; k++) u[k] = col[base + ((size_t)(r_hi * 16 + k) << lo) + c];
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+#pragma unroll
+                    for (uint32_t k = 0; k < 16; k++)
+                        if (!(k & (1u << s))) inv(u[k], u[k + (1u << s)], s, (r_hi << (3 - s)) + (k >> (s + 1)));
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < 16; k++) tile[(r_hi * 16 + k) * kFftTp + c] = u[k];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t j = 0; j < 2; j++) {
+            const uint32_t r_lo = rx + 8 * j;
+            uint32_t v[RA];
+#pragma unroll
+            for (uint32_t k = 0; k < RA; k++) v[k] = tile[(k * 16 + r_lo) * kFftTp + c];
+#pragma unroll
+            for (int s = 0; s < A; s++) {
+#pragma unroll
+                for (uint32_t k = 0; k < RA; k++)
+                    if (!(k & (1u << s))) inv(v[k], v[k + (1u << s)], 4 + s, k >> (s + 1));
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < RA; k++) {
+                const uint32_t out = last ? m31_mul_c(v[k], scale) : v[k];
+                col[base + ((size_t)(k * 16 + r_lo) << lo) + c] = out;
+            }
+        }
+    }
+}
+
+// a strided pass of nb layers: the register kernel for 5..8 layers, the LDS kernel otherwise (and with -DSS_FFT_LDS, for A/B runs)
+static void launch_strided_pass(uint32_t m, uint32_t lo, uint32_t nb, uint32_t ncols, uint32_t *data, const uint32_t *tw, int inverse,
+                                uint32_t scale, const uint32_t *src, uint32_t z, hipStream_t stream)
+{
+    const dim3 grid((1u << (m - nb)) / kFftT, ncols);
+#ifndef SS_FFT_LDS
+    switch (nb) {
+    case 5: hipLaunchKernelGGL(p_fft_pass16_kernel<1>, grid, dim3(256), 0, stream, m, lo, data, tw, inverse, scale, src, z); return;
+    case 6: hipLaunchKernelGGL(p_fft_pass16_kernel<2>, grid, dim3(256), 0, stream, m, lo, data, tw, inverse, scale, src, z); return;
+    case 7: hipLaunchKernelGGL(p_fft_pass16_kernel<3>, grid, dim3(256), 0, stream, m, lo, data, tw, inverse, scale, src, z); return;
+    case 8: hipLaunchKernelGGL(p_fft_pass16_kernel<4>, grid, dim3(256), 0, stream, m, lo, data, tw, inverse, scale, src, z); return;
+    default: break;
+    }
+#endif
+    hipLaunchKernelGGL(p_fft_pass_kernel<false>, grid, dim3(256), 0, stream, m, lo, nb, 0u, data, tw, inverse, scale, src, z);
+}
+
 // --------------------------------------------------------------------------------- hashing
 // WC = the row width when it is one of the two the stwo prover hashes 2^24 times (4 trace columns, 16 composition
 // columns): the padding words and, for 16, the whole second block's message schedule are then compile-time constants
@@ -595,8 +739,7 @@ extern "C" int ss_p_fft(ss_ctx *ctx, uint32_t m, uint32_t ncols, uint32_t *data,
                                    dim3(256), 0, (hipStream_t)stream, m, lo[i], nb[i], cpb_log, data, tw, inverse,
                                    scale, nullptr, 0u);
             else
-                hipLaunchKernelGGL(p_fft_pass_kernel<false>, dim3((1u << (m - nb[i])) / kFftT, ncols), dim3(256), 0,
-                                   (hipStream_t)stream, m, lo[i], nb[i], 0u, data, tw, inverse, scale, nullptr, 0u);
+                launch_strided_pass(m, lo[i], nb[i], ncols, data, tw, inverse, scale, nullptr, 0u, (hipStream_t)stream);
         }
         P_TRY(hipGetLastError());
         return SS_OK;
@@ -642,9 +785,8 @@ extern "C" int ss_p_lde(ss_ctx *ctx, uint32_t k, uint32_t m, uint32_t ncols, con
             hipLaunchKernelGGL(p_fft_pass_kernel<true>, dim3((1u << (m - nb[i])) >> (5 - cpb_log), ncols >> cpb_log),
                                dim3(256), 0, (hipStream_t)stream, m, lo[i], nb[i], cpb_log, out, tw, 0, 1u, nullptr, 0u);
         else
-            hipLaunchKernelGGL(p_fft_pass_kernel<false>, dim3((1u << (m - nb[i])) / kFftT, ncols), dim3(256), 0,
-                               (hipStream_t)stream, m, lo[i], nb[i], 0u, out, tw, 0, 1u, i == np - 1 ? coefs : nullptr,
-                               i == np - 1 ? z : 0u);
+            launch_strided_pass(m, lo[i], nb[i], ncols, out, tw, 0, 1u, i == np - 1 ? coefs : nullptr, i == np - 1 ? z : 0u,
+                                (hipStream_t)stream);
     }
     P_TRY(hipGetLastError());
     return SS_OK;
