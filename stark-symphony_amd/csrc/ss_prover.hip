@@ -370,6 +370,121 @@ p_fft_pass16_kernel(uint32_t m, uint32_t lo, uint32_t *__restrict__ data, const 
     }
 }
 
+// The contiguous pass (the lowest A + 4 layers: lo = 0) with the layers in registers.  Here a lane is a (column, group of
+// 2^(A+4) contiguous words) and every butterfly has its own twiddle, so the tile is still loaded and stored through LDS --
+// rows are what is contiguous in memory -- but between those two coalesced sweeps the layers run as in
+// p_fft_pass16_kernel: radix-2^A over the upper row bits, one exchange, radix-16 over the lower four, twiddles straight
+// from the table (15 loads per 16 rows and stage, shared by the CPB columns of the block through L1).
+template <int A>
+__global__ void __launch_bounds__(256)
+p_fft_pass16c_kernel(uint32_t m, uint32_t cpb_log, uint32_t *__restrict__ data, const uint32_t *__restrict__ tw, int inverse,
+                     uint32_t scale)
+{
+    constexpr uint32_t NB = A + 4, ROWS = 1u << NB, RA = 1u << A, ELEMS = ROWS * kFftT;
+    __shared__ uint32_t tile[ROWS * kFftTp];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t glog = 5 - cpb_log, gmask = (1u << glog) - 1;  // lane = column * G + group
+    const uint32_t hi = blockIdx.x << glog;
+    uint32_t *col = data + ((size_t)(blockIdx.y << cpb_log) << m);
+    auto gaddr = [&](uint32_t e) -> size_t {  // e = lane * ROWS + row
+        const uint32_t l = e >> NB;
+        return ((size_t)(l >> glog) << m) + ((size_t)(hi + (l & gmask)) << NB) + (e & (ROWS - 1));
+    };
+    for (uint32_t e = tid; e < ELEMS; e += 256) tile[(e & (ROWS - 1)) * kFftTp + (e >> NB)] = col[gaddr(e)];
+    __syncthreads();
+    const uint32_t c = tid & 31, rx = tid >> 5;
+    const uint32_t g = hi + (c & gmask);
+    auto TW = [&](uint32_t ip, uint32_t hl) {  // layer ip of the whole transform (lo = 0), butterfly group hl of this lane's group
+        return tw[(((size_t)1 << m) - ((size_t)1 << (m - ip))) + ((size_t)g << (NB - 1 - ip)) + hl];
+    };
+    auto fwd = [&](uint32_t &v0, uint32_t &v1, uint32_t w) {
+        const uint32_t x = m31_mul_c(v1, w);
+        v1 = m31_sub_c(v0, x);
+        v0 = m31_add_c(v0, x);
+    };
+    auto inv = [&](uint32_t &v0, uint32_t &v1, uint32_t w) {
+        const uint32_t sum = m31_add_c(v0, v1);
+        v1 = m31_mul_c(m31_sub_c(v0, v1), w);
+        v0 = sum;
+    };
+    const bool last = inverse && NB == m && scale != 1;
+    auto stage_a = [&]() {
+#pragma unroll
+        for (uint32_t j = 0; j < 2; j++) {
+            const uint32_t r_lo = rx + 8 * j;
+            uint32_t v[RA];
+#pragma unroll
+            for (uint32_t k = 0; k < RA; k++) v[k] = tile[(k * 16 + r_lo) * kFftTp + c];
+            if (!inverse) {
+#pragma unroll
+                for (int s = A - 1; s >= 0; s--) {
+#pragma unroll
+                    for (uint32_t k = 0; k < RA; k++)
+                        if (!(k & (1u << s))) fwd(v[k], v[k + (1u << s)], TW(4 + s, k >> (s + 1)));
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < A; s++) {
+#pragma unroll
+                    for (uint32_t k = 0; k < RA; k++)
+                        if (!(k & (1u << s))) inv(v[k], v[k + (1u << s)], TW(4 + s, k >> (s + 1)));
+                }
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < RA; k++) tile[(k * 16 + r_lo) * kFftTp + c] = last ? m31_mul_c(v[k], scale) : v[k];
+        }
+    };
+    auto stage_b = [&]() {
+#pragma unroll
+        for (uint32_t j = 0; j < (RA * 32 + 255) / 256; j++) {
+            const uint32_t item = tid + 256 * j;
+            if (item < RA * 32) {
+                const uint32_t r_hi = item >> 5;
+                uint32_t u[16];
+#pragma unroll
+                for (uint32_t k = 0; k < 16; k++) u[k] = tile[(r_hi * 16 + k) * kFftTp + c];
+                if (!inverse) {
+#pragma unroll
+                    for (int s = 3; s >= 0; s--) {
+#pragma unroll
+                        for (uint32_t k = 0; k < 16; k++)
+                            if (!(k & (1u << s))) fwd(u[k], u[k + (1u << s)], TW(s, (r_hi << (3 - s)) + (k >> (s + 1))));
+                    }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; s++) {
+#pragma unroll
+                        for (uint32_t k = 0; k < 16; k++)
+                            if (!(k & (1u << s))) inv(u[k], u[k + (1u << s)], TW(s, (r_hi << (3 - s)) + (k >> (s + 1))));
+                    }
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < 16; k++) tile[(r_hi * 16 + k) * kFftTp + c] = u[k];
+            }
+        }
+    };
+    if (!inverse) { stage_a(); __syncthreads(); stage_b(); }
+    else { stage_b(); __syncthreads(); stage_a(); }
+    __syncthreads();
+    for (uint32_t e = tid; e < ELEMS; e += 256) col[gaddr(e)] = tile[(e & (ROWS - 1)) * kFftTp + (e >> NB)];
+}
+
+static void launch_contig_pass(uint32_t m, uint32_t nb, uint32_t cpb_log, uint32_t ncols, uint32_t *data, const uint32_t *tw, int inverse,
+                               uint32_t scale, hipStream_t stream)
+{
+    const dim3 grid((1u << (m - nb)) >> (5 - cpb_log), ncols >> cpb_log);
+#ifndef SS_FFT_LDS
+    switch (nb) {
+    case 5: hipLaunchKernelGGL(p_fft_pass16c_kernel<1>, grid, dim3(256), 0, stream, m, cpb_log, data, tw, inverse, scale); return;
+    case 6: hipLaunchKernelGGL(p_fft_pass16c_kernel<2>, grid, dim3(256), 0, stream, m, cpb_log, data, tw, inverse, scale); return;
+    case 7: hipLaunchKernelGGL(p_fft_pass16c_kernel<3>, grid, dim3(256), 0, stream, m, cpb_log, data, tw, inverse, scale); return;
+    case 8: hipLaunchKernelGGL(p_fft_pass16c_kernel<4>, grid, dim3(256), 0, stream, m, cpb_log, data, tw, inverse, scale); return;
+    default: break;
+    }
+#endif
+    hipLaunchKernelGGL(p_fft_pass_kernel<true>, grid, dim3(256), 0, stream, m, 0u, nb, cpb_log, data, tw, inverse, scale, nullptr, 0u);
+}
+
 // a strided pass of nb layers: the register kernel for 5..8 layers, the LDS kernel otherwise (and with -DSS_FFT_LDS, for A/B runs)
 static void launch_strided_pass(uint32_t m, uint32_t lo, uint32_t nb, uint32_t ncols, uint32_t *data, const uint32_t *tw, int inverse,
                                 uint32_t scale, const uint32_t *src, uint32_t z, hipStream_t stream)
@@ -735,9 +850,7 @@ extern "C" int ss_p_fft(ss_ctx *ctx, uint32_t m, uint32_t ncols, uint32_t *data,
         for (uint32_t s = 0; s < k; s++) {
             const uint32_t i = inverse ? s : k - 1 - s;
             if (i == 0)
-                hipLaunchKernelGGL(p_fft_pass_kernel<true>, dim3((1u << (m - nb[i])) >> (5 - cpb_log), ncols >> cpb_log),
-                                   dim3(256), 0, (hipStream_t)stream, m, lo[i], nb[i], cpb_log, data, tw, inverse,
-                                   scale, nullptr, 0u);
+                launch_contig_pass(m, nb[i], cpb_log, ncols, data, tw, inverse, scale, (hipStream_t)stream);
             else
                 launch_strided_pass(m, lo[i], nb[i], ncols, data, tw, inverse, scale, nullptr, 0u, (hipStream_t)stream);
         }
@@ -782,8 +895,7 @@ extern "C" int ss_p_lde(ss_ctx *ctx, uint32_t k, uint32_t m, uint32_t ncols, con
     for (uint32_t s = 0; s < np; s++) {
         const uint32_t i = np - 1 - s;
         if (i == 0)
-            hipLaunchKernelGGL(p_fft_pass_kernel<true>, dim3((1u << (m - nb[i])) >> (5 - cpb_log), ncols >> cpb_log),
-                               dim3(256), 0, (hipStream_t)stream, m, lo[i], nb[i], cpb_log, out, tw, 0, 1u, nullptr, 0u);
+            launch_contig_pass(m, nb[i], cpb_log, ncols, out, tw, 0, 1u, (hipStream_t)stream);
         else
             launch_strided_pass(m, lo[i], nb[i], ncols, out, tw, 0, 1u, i == np - 1 ? coefs : nullptr, i == np - 1 ? z : 0u,
                                 (hipStream_t)stream);
