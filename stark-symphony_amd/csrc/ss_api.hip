@@ -619,12 +619,9 @@ extern "C" int ss_stwo_verify_records(ss_ctx *ctx, const ss_stwo_cfg *c, size_t 
     SS_DEVICE_GUARD(ctx);
     const size_t W = ss_stwo_record_words(c);
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(n, (64u << 20) / (W * 4)));
-    // Chunks small at BOTH ends of the call: nothing overlaps the staging of the first one, nor the re-tiling and
-    // verification of the last one (the same ramp as the text pipeline: a sixteenth of a chunk + half the distance to the
-    // nearer end)
+    // (the first chunks are small and double: nothing overlaps the staging of the first one)
     std::vector<size_t> counts;
-    for (size_t lo = 0; lo < n;) {
-        const size_t step = std::min(chunk, std::max<size_t>(1, chunk / 16) + std::min(lo, n - lo) / 2);
+    for (size_t lo = 0, step = std::max<size_t>(1, chunk / 16); lo < n; step = std::min(chunk, step * 2)) {
         counts.push_back(std::min(step, n - lo));
         lo += counts.back();
     }

@@ -225,22 +225,18 @@ extern "C" int ss_stwo_verify_shared_records(ss_ctx *ctx, const ss_stwo_cfg *c, 
     // fixed words travel (the kernel then sees a size that cannot match and refuses it).
     const size_t fixed = ss_stwo_shared_fixed_words(c);
     auto sent = [&](size_t i) { return words[i] > max_words ? std::min(words[i], fixed) : words[i]; };
-    // chunks of <= 64 MiB, small at both ends of the call (nothing overlaps the staging of the first one, nor the expansion
-    // and verification of the last one): a sixteenth of a chunk + half the distance, in words, to the nearer end
+    // chunks of <= 64 MiB; the first ones small and doubling (nothing overlaps the staging of the first)
     const size_t budget = (64u << 20) / 4;
     std::vector<size_t> first;  // first record of every chunk, then n
     {
-        size_t total_words = 0, done_words = 0;
-        for (size_t i = 0; i < n; i++) total_words += sent(i);
-        size_t lo = 0;
+        size_t lo = 0, step_words = std::max<size_t>(budget / 16, max_words);
         while (lo < n) {
             first.push_back(lo);
-            const size_t step_words = std::max(max_words, std::min(budget, budget / 16 + std::min(done_words, total_words - done_words) / 2));
             size_t w = 0, hi = lo;
             // (and at most 256 MiB of expanded records per chunk, however short -- e.g. malformed -- the inputs are)
             while (hi < n && (hi == lo || (w + sent(hi) <= step_words && (hi - lo + 1) * W * 4 <= ((size_t)256 << 20)))) w += sent(hi++);
             lo = hi;
-            done_words += w;
+            step_words = std::min(budget, step_words * 2);
         }
         first.push_back(n);
     }
