@@ -3,7 +3,8 @@ once + the query positions, instead of one full path per query (the reference no
 stwo-verifier/src/fri/queries.simf:41; its adapter splits per-query witnesses, scripts/generate_wit.py:36-40).
 No reference bytes exist for such a format, so parity is defined through expansion: a shared text must read, in
 formats.py and in the native reader alike, as exactly the per-query proof it was made from -- after which the
-verifier (and the oracle) see nothing new.  CPU only; the GPU leg is in tests/test_gpu_text.py."""
+verifier (and the oracle) see nothing new.  The second half of the file holds the scalar statement of the GPU reader's rule for
+these texts against the host reader.  CPU only; the GPU legs are in tests/test_gpu_text.py and tests/test_gpu_shared.py."""
 import json
 import os
 import random
