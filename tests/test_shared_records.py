@@ -174,3 +174,31 @@ def test_malformed_shared_records_host_equals_oracle():
             assert rc == orc and np.array_equal(rec, orec)
             bad += rc != 0
         assert 40 < bad < 150
+
+
+def test_closed_form_property_based():
+    """Hypothesis over positions and shapes: the library's counts are the walk's, a random record that agrees wherever
+    its positions meet survives share -> unshare, and expanding with the ORACLE's walk gives the same record."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=120, deadline=None)
+    @given(st.integers(2, 20), st.data())
+    def prop(L, data):
+        K = data.draw(st.integers(0, L - 2))
+        Q = data.draw(st.sampled_from([1, 2, 3, 6, 16, 17, 48, 64]))
+        # positions with many shared prefixes: a few random bases XOR small offsets
+        bases = data.draw(st.lists(st.integers(0, (1 << L) - 1), min_size=1, max_size=3))
+        qs = np.array([(bases[data.draw(st.integers(0, len(bases) - 1))] ^ data.draw(st.integers(0, min((1 << L) - 1, 31)))) for _ in range(Q)],
+                      dtype=np.uint32)
+        cfg = ss.StwoConfig(3, max(1, L - 1), L, Q, K, 5)
+        counts = verifier.stwo_shared_counts(cfg, qs)
+        for t in range(K + 3):
+            assert O.shared_walk(L, t, qs)[1] == int(counts[t])
+        rng = np.random.default_rng(int(qs.sum()) + L + K + Q)
+        p = _random_record(rng, cfg, qs)
+        rec = verifier.stwo_record(p)
+        sh = verifier.stwo_shared_record(p, qs)
+        rc, back = verifier.stwo_unshare_record(cfg, sh)
+        orc, oback = O.shared_expand(cfg, sh)
+        assert rc == 0 and orc == 0 and np.array_equal(back, rec) and np.array_equal(oback, rec)
+    prop()
