@@ -326,12 +326,14 @@ def end_to_end(ver, proofs, n: int, rank: int = 0, world: int = 1, dist=None):
     shared = [verifier.stwo_shared_record(p) for p in distinct]
     for kind, src, call in (("records", recs, ver.verify_stwo_records), ("shared_records", shared, ver.verify_stwo_shared_records)):
         batch = [src[(lo + i) % len(distinct)].copy() for i in range(n_local)]
+        if kind == "records":  # one 2-d array, a record per row (every record still has its own memory)
+            batch = np.stack(batch)
         try:
             call(cfg, batch)
         except Exception as e:  # noqa: BLE001
             errors.append("rank %d warm-up: %r" % (rank, e))
         dt, _ = timed(lambda: (call(cfg, batch), {}))
-        nbytes = sum(int(b.nbytes) for b in batch)
+        nbytes = int(batch.nbytes) if isinstance(batch, np.ndarray) else sum(int(b.nbytes) for b in batch)
         slowest, links = across_ranks(dt, nbytes)
         row = {"proofs_per_s": n / slowest, "total_s": None if slowest == float("inf") else slowest,
                "link_GB_per_s": nbytes * (n / max(n_local, 1)) / slowest / 1e9,
