@@ -328,12 +328,16 @@ def end_to_end(ver, proofs, n: int, rank: int = 0, world: int = 1, dist=None):
         batch = [src[(lo + i) % len(distinct)].copy() for i in range(n_local)]
         if kind == "records":  # one 2-d array, a record per row (every record still has its own memory)
             batch = np.stack(batch)
+        else:                  # the variable-length shared records back to back + their offsets
+            offs = np.zeros(len(batch) + 1, dtype=np.uint64)
+            offs[1:] = np.cumsum([b.size for b in batch])
+            batch = (np.concatenate(batch), offs)
         try:
             call(cfg, batch)
         except Exception as e:  # noqa: BLE001
             errors.append("rank %d warm-up: %r" % (rank, e))
         dt, _ = timed(lambda: (call(cfg, batch), {}))
-        nbytes = int(batch.nbytes) if isinstance(batch, np.ndarray) else sum(int(b.nbytes) for b in batch)
+        nbytes = int(batch.nbytes) if isinstance(batch, np.ndarray) else int(batch[0].nbytes)
         slowest, links = across_ranks(dt, nbytes)
         row = {"proofs_per_s": n / slowest, "total_s": None if slowest == float("inf") else slowest,
                "link_GB_per_s": nbytes * (n / max(n_local, 1)) / slowest / 1e9,

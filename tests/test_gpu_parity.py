@@ -293,6 +293,9 @@ def test_host_buffer_entry_point(ver, stwo_prod):
         idx = [i % 7 for i in range(n)]
         got = ver.verify_stwo_records(stwo_prod.cfg, [recs[i] for i in idx])
         assert got.tolist() == [int(want_d[i]) for i in idx]
+        # the same batch as ONE 2-d array (a record per row: no per-record work in the Python wrapper)
+        got2 = ver.verify_stwo_records(stwo_prod.cfg, np.stack([recs[i] for i in idx]))
+        assert got2.tolist() == got.tolist()
 
 
 def test_stwo_mixed_shapes_in_one_call(ver, stwo_small, stwo_prod):

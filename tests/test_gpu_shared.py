@@ -82,6 +82,9 @@ def test_shared_records_verify_as_the_per_query_records(ver, mode):
         got_rec = ver.verify_stwo_records(cfg, [verifier.stwo_record(p) for p in proofs], mode)
         got_sh = ver.verify_stwo_shared_records(cfg, shared, mode)
         assert np.array_equal(got_rec, want) and np.array_equal(got_sh, want), cfg
+        offs = np.zeros(len(shared) + 1, dtype=np.uint64)   # the same records back to back + offsets: no per-record Python work
+        offs[1:] = np.cumsum([s.size for s in shared])
+        assert np.array_equal(ver.verify_stwo_shared_records(cfg, (np.concatenate(shared), offs), mode), want), cfg
         assert (want == 0).sum() >= (1 if mode == verifier.MODE_FIXTURE else 0)
         # structure mutants (hints, counts, sizes, bits anywhere -- a flipped node is seen by every query that shares
         # it): whatever still expands is verified as the record it expands to; the rest is malformed
