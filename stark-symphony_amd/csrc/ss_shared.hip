@@ -42,6 +42,11 @@ struct SharedArgs {
     uint32_t hint_stride;
 };
 
+#ifndef SS_GATHER
+#define SS_GATHER 4
+#endif
+constexpr uint32_t kGather = SS_GATHER;  // siblings a lane keeps in flight in the copy phase
+
 __global__ void __launch_bounds__(256) stwo_shared_expand_kernel(SharedArgs a)
 {
     __shared__ uint8_t s_d[kMaxQueries][kMaxQueries];    // d(q, e) for e < q
@@ -138,10 +143,33 @@ __global__ void __launch_bounds__(256) stwo_shared_expand_kernel(SharedArgs a)
         uint32_t dst0, per_q;
         if (t < 2) { dst0 = m.head + N + kCp + t * 8 * L; per_q = a.qstride; }
         else { const uint32_t l = t - 2; dst0 = a.fbase + a.foff[l] + 4; per_q = 4 + 8 * len; }
-        for (uint32_t i = grp; i < Q * len; i += 32) {
-            const uint32_t q = i / len, lvl = i - q * len;
-            const uint32_t src = (uint32_t)s_base[t][s_lead[q][shift + lvl]] + lvl;
-            rec[dst0 + q * per_q + 8 * lvl + sub] = nodes[8 * (uint64_t)src + sub];
+        // (8-byte accesses, four lanes per node, wherever both sides are 8-byte aligned -- every layout with an even
+        // number of columns and queries: all BASELINE configs; word accesses, eight lanes per node, otherwise)
+        const bool wide = ((((uintptr_t)nodes) | ((uintptr_t)(rec + dst0))) & 7) == 0 && (per_q & 1) == 0;
+        if (wide) {
+            // kGather nodes per lane in flight: a lone load -> store chain per iteration is bound by memory latency
+            const uint32_t sub2 = tid & 3, total = Q * len;
+            for (uint32_t i0 = tid >> 2; i0 < total; i0 += 64 * kGather) {
+                uint2 v[kGather];
+                uint32_t dst[kGather];
+#pragma unroll
+                for (uint32_t u = 0; u < kGather; u++) {
+                    const uint32_t i = i0 + 64 * u;
+                    const uint32_t ii = i < total ? i : i0;  // (the tail repeats its first node: same bytes to the same place)
+                    const uint32_t q = ii / len, lvl = ii - q * len;
+                    const uint32_t src = (uint32_t)s_base[t][s_lead[q][shift + lvl]] + lvl;
+                    dst[u] = dst0 + q * per_q + 8 * lvl;
+                    v[u] = reinterpret_cast<const uint2 *>(nodes + 8 * (uint64_t)src)[sub2];
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < kGather; u++) reinterpret_cast<uint2 *>(rec + dst[u])[sub2] = v[u];
+            }
+        } else {
+            for (uint32_t i = grp; i < Q * len; i += 32) {
+                const uint32_t q = i / len, lvl = i - q * len;
+                const uint32_t src = (uint32_t)s_base[t][s_lead[q][shift + lvl]] + lvl;
+                rec[dst0 + q * per_q + 8 * lvl + sub] = nodes[8 * (uint64_t)src + sub];
+            }
         }
     }
     if (tid == 0) a.outcome[p] = 0;
