@@ -55,19 +55,22 @@ def verify_sharded(proofs: Sequence, verify_local: Callable[[Sequence], np.ndarr
     import torch
     import torch.distributed as dist
     rank, world = _world(group)
+    # a process group that exists is used whatever its size: a one-rank "nccl" group sends the same two calls through
+    # RCCL as eight ranks do (the single-GPU test box's only way to run them)
+    grouped = dist.is_available() and dist.is_initialized()
     lo, hi = shard_range(len(proofs), rank, world)
     local = np.asarray(verify_local(proofs[lo:hi]) if hi > lo else np.zeros(0, np.uint32),
                        dtype=np.uint32)
     if device is None:
-        backend = dist.get_backend(group) if world > 1 else "gloo"
+        backend = dist.get_backend(group) if grouped else "gloo"
         device = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
     counts = torch.tensor([int((local == 0).sum()), int(local.size)], dtype=torch.int64, device=device)
-    if world > 1:
+    if grouped:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
     accepted, total = int(counts[0].item()), int(counts[1].item())
     if not gather_status:
         return local, accepted, total
-    if world == 1:
+    if not grouped:
         return local, accepted, total, local.copy()
     # ranks may own slices that differ by one proof: pad to the longest
     longest = (len(proofs) + world - 1) // world

@@ -131,9 +131,37 @@ assert all_st.tolist() == want.tolist()
 lo, hi = distributed.shard_range(37, rank, dist.get_world_size())
 assert local_st.tolist() == want[lo:hi].tolist()
 dist.barrier()
+backend_, world_ = dist.get_backend(), dist.get_world_size()
 dist.destroy_process_group()
-print("rank %d ok: %d of %d accepted" % (rank, acc, tot))
+print("rank %d ok: %d of %d accepted, backend %s, world %d" % (rank, acc, tot, backend_, world_))
 """
+
+
+def _torchrun(worker, nproc, env, timeout=900):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(worker)],
+                          capture_output=True, text=True, timeout=timeout, env=env)
+
+
+def test_rccl_one_rank_runs_the_exchange(tmp_path):
+    """The nccl backend (RCCL) with ONE rank on the one GPU of the test box: distributed.verify_sharded sends its
+    accept-count all-reduce and its status all-gather through RCCL (a process group that exists is used whatever its
+    size) on a mixed batch, against the oracle.  Not a scaling result -- it shows that RCCL initialises on this image
+    and accepts the calls, devices and dtypes the N > 1 path makes; two ranks need two devices (next test)."""
+    worker = tmp_path / "rccl_worker.py"
+    worker.write_text(_RCCL_WORKER.format(root=ROOT))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env["NCCL_DEBUG"] = "VERSION"
+    r = _torchrun(worker, 1, env)
+    assert r.returncode == 0 and r.stdout.count("ok:") == 1, (r.stdout[-2000:], r.stderr[-3000:])
+    assert "backend nccl" in r.stdout
+    version = [l for l in (r.stdout + r.stderr).splitlines() if "version" in l.lower() and "ccl" in l.lower()]
+    assert version, (r.stdout[-2000:], r.stderr[-2000:])  # NCCL_DEBUG=VERSION: the library that ran says which it is
+    print("\n".join(version[:3]), r.stdout.strip().splitlines()[-1])
 
 
 @pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs: the first RCCL evidence comes from a multi-GPU box")
@@ -143,14 +171,9 @@ def test_rccl_two_ranks_verify_sharded_and_bench(tmp_path):
     modes.  Skipped on the single-GPU test box."""
     worker = tmp_path / "rccl_worker.py"
     worker.write_text(_RCCL_WORKER.format(root=ROOT))
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(worker)],
-                       capture_output=True, text=True, timeout=900, env=env)
+    r = _torchrun(worker, 2, env)
     assert r.returncode == 0 and r.stdout.count("ok:") == 2, (r.stdout[-2000:], r.stderr[-3000:])
     for extra in (["--proofs-per-gpu", "2048"], ["--batch", "4096"]):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "stwo_fixture",
