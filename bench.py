@@ -260,7 +260,7 @@ def end_to_end(ver, proofs, n: int, rank: int = 0, world: int = 1, dist=None):
         is recorded, not raised: the other ranks are waiting in the next collective."""
         best = None
         for _ in range(3):
-            if world > 1:
+            if dist is not None:
                 dist.barrier()
             t0 = time.perf_counter()
             try:
@@ -279,7 +279,7 @@ def end_to_end(ver, proofs, n: int, rank: int = 0, world: int = 1, dist=None):
 
     def across_ranks(dt: float, link_bytes: int):
         """-> (slowest rank's time, per-rank GB/s on the host link)"""
-        if world == 1:
+        if dist is None:
             return dt, [link_bytes / dt / 1e9]
         import torch
         mine = torch.tensor([dt if dt != float("inf") else -1.0, float(link_bytes)], dtype=torch.float64, device=ver.device)
@@ -461,11 +461,15 @@ def main() -> None:
 
     if args.proofs_per_gpu:
         args.scaling = "weak"
-    if args.workload == "stark101" and args.graph in ("auto", "streams"):
-        # The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and
-        # streams that share a queue serialize: 16 overlapping passes need their own queues.  Must be
-        # in the environment before the runtime initialises (measured: 44.7 M -> 60.6 M proofs/s).
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+    # The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that
+    # share a queue serialize.  Must be in the environment before the runtime initialises.  stark101: 16 overlapping
+    # passes need their own queues (measured: 44.7 M -> 60.6 M proofs/s).  stwo: the pipeline's head streams must not
+    # share a queue with its tail streams, and its two tail streams not with each other, or the overlap they exist for
+    # is lost -- which queue a stream gets depends on how many streams the process made before it, so the accept
+    # reduce's communication stream alone moved one GPU's 8 192-proof share from 2.32 to 2.55-2.60 ms per step at 4 AND
+    # at 16 queues (rocprofv3 Queue_Id: both tail streams on one queue); with 24 every stream has its own: 2.38 ms
+    # (profiles/r04_accept_reduce.txt).
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` typed as is: this process becomes the launcher.  It has not
         # imported torch or touched HIP, so starting children is safe; it never verifies anything.
@@ -485,7 +489,13 @@ def main() -> None:
     dev_index = 0 if os.environ.get("SS_BENCH_SHARE_GPU") else local
     backend = os.environ.get("SS_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(dev_index)
-    if world > 1:
+    # Test hook: SS_BENCH_GROUP_OF_ONE=1 makes a single rank form its process group too, so that every collective of
+    # this file (accept reduce on its stream, barriers, max-over-ranks, the e2e gathers) goes through RCCL on a one-GPU
+    # box.  Never set by the driver.
+    grouped = world > 1 or os.environ.get("SS_BENCH_GROUP_OF_ONE") == "1"
+    if grouped:
+        for k_, v_ in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_PORT", "29531")):
+            os.environ.setdefault(k_, v_)
         # the ranks of one host share its granted cores: each library instance gets its share for staging / host reading
         os.environ.setdefault("SS_HOST_THREADS", str(max(2, granted_cores() // world)))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -574,12 +584,12 @@ def main() -> None:
     acc = accs[0]
 
     def reduce_accepts(k: int) -> None:
-        if world > 1:  # the path's only exchange: accept-count reduce over xGMI
+        if grouped:  # the path's only exchange: accept-count reduce over xGMI
             accs[k].copy_(slots[k].accept_dev)
             dist.all_reduce(accs[k], op=dist.ReduceOp.SUM)
 
     def step(i: int, p=None) -> None:
-        (p or pipe).submit(reduce_accepts if world > 1 else None)
+        (p or pipe).submit(reduce_accepts if grouped else None)
 
     for i in range(args.warmup):
         step(i)
@@ -587,7 +597,7 @@ def main() -> None:
     if args.warmup:
         assert batch.accepted() == n_local, "benchmark proofs must all be ACCEPT (%d of %d)" % (
             batch.accepted(), n_local)
-    small = family == "stark101" and world == 1
+    small = family == "stark101" and not grouped
     streams = args.graph == "streams" or (args.graph == "auto" and small)
     graphed = args.graph == "on"
     if streams:
@@ -647,14 +657,14 @@ def main() -> None:
         else:
             for i in range(2 * nslot):
                 step(i, timed_pipe)
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(i, timed_pipe)
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
         elapsed = time.perf_counter() - t0
         if overlapped:  # Merkle launches overlapped at their edges: their durations come from a pass where they do not
@@ -665,7 +675,7 @@ def main() -> None:
             torch.cuda.synchronize()
         timing = ver.collect_timing()
         ver.set_timing(False)
-    if world > 1:
+    if grouped:
         t = torch.tensor([elapsed], dtype=torch.float64, device=ver.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -675,7 +685,7 @@ def main() -> None:
     assert total_accept == job_proofs, "accept-reduce mismatch (%d of %d)" % (total_accept, job_proofs)
 
     # text / records in host memory -> verdicts, every rank its share at the same time (never `value`)
-    e2e = end_to_end(ver, proofs, args.e2e, rank, world, dist if world > 1 else None) if family == "stwo" and args.e2e > 0 else None
+    e2e = end_to_end(ver, proofs, args.e2e, rank, world, dist if grouped else None) if family == "stwo" and args.e2e > 0 else None
     if rank == 0:
         total = job_proofs * args.steps
         value = total / elapsed
@@ -764,7 +774,7 @@ def main() -> None:
             out["cpu_baseline"] = cpu_baseline(family, proofs, args.cpu_seconds)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

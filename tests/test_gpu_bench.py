@@ -164,6 +164,27 @@ def test_rccl_one_rank_runs_the_exchange(tmp_path):
     print("\n".join(version[:3]), r.stdout.strip().splitlines()[-1])
 
 
+def test_bench_collectives_through_rccl_with_one_rank():
+    """bench.py with its process group formed by ONE rank over the nccl backend (SS_BENCH_GROUP_OF_ONE): the accept
+    reduce submitted on the pipeline's stream every step, the barriers around the timed region, the max-over-ranks and
+    the e2e gathers all go through RCCL on the one GPU of the test box -- the call sequence of the driver's N > 1 runs,
+    which no two-device box has executed yet.  Not a scaling result."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        env["MASTER_PORT"] = str(s.getsockname()[1])
+    env.update(SS_BENCH_GROUP_OF_ONE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for extra in (["--batch", "4096"], ["--proofs-per-gpu", "2048", "--scaling", "weak"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "stwo_fixture", "--steps", "8",
+                            "--warmup", "2", "--no-cpu-baseline", "--e2e", "256"] + extra,
+                           capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        d = _last_json(r.stdout)
+        assert d["n_gpus"] == 1 and d["steps"] == 8
+        assert abs(d["value"] - d["config"]["proofs_per_step"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+        assert "errors" not in d["e2e"] and d["e2e"]["records"]["proofs_per_s"] > 0
+
+
 @pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs: the first RCCL evidence comes from a multi-GPU box")
 def test_rccl_two_ranks_verify_sharded_and_bench(tmp_path):
     """Two ranks on two devices over the nccl backend (RCCL over xGMI): distributed.verify_sharded with
