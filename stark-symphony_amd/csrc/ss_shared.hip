@@ -8,8 +8,9 @@
 //
 // HBM-bound word shuffling, no MFMA.  One 256-thread block per proof: wave 0 turns the Q hinted positions
 // into the plan (pairwise bit lengths by shuffles, per-tree prefix sums), all four waves then copy -- a
-// sibling is eight consecutive lanes reading 32 contiguous bytes of the node list and writing 32 contiguous
-// bytes of the record, so both sides are full 32-byte sectors.
+// sibling is four consecutive lanes (eight where a side is not 8-byte aligned) reading 32 contiguous bytes of
+// the node list and writing 32 contiguous bytes of the record, so both sides are full 32-byte sectors; a lane
+// keeps kGather siblings in flight (3.2 TB/s with the chip full, profiles/r04_shared_expand_probe.txt).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -135,7 +136,7 @@ __global__ void __launch_bounds__(256) stwo_shared_expand_kernel(SharedArgs a)
     }
     for (uint32_t i = tid; i < (K + 3) * Q; i += 256) rec[a.tbase + i] = shared_tree_len(L, i / Q);
     __syncthreads();
-    // ---- the siblings: 8 lanes per node
+    // ---- the siblings
     const uint32_t sub = tid & 7, grp = tid >> 3;
     for (uint32_t t = 0; t < K + 3; t++) {
         const uint32_t len = shared_tree_len(L, t), shift = shared_tree_shift(t);
