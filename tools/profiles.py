@@ -19,6 +19,12 @@ import pmc_summary  # noqa: E402
 import bench  # noqa: E402
 
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
+ONLY = set(sys.argv[2:])  # `profiles.py r04 bench`: only the bench lines (sections: bench stats pmc e2e text); default: everything
+
+
+def want(section):
+    return not ONLY or section in ONLY
+
 G = os.path.join(ROOT, "gpurun_out", TAG)
 P = os.path.join(ROOT, "profiles")
 commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip()
@@ -46,12 +52,13 @@ def last_json(path):
     return json.loads([l for l in open(path) if l.startswith("{")][-1])
 
 
-if os.path.exists(os.path.join(G, "bench_default.json")):
+if want("bench") and os.path.exists(os.path.join(G, "bench_default.json")):
     json.dump(last_json(os.path.join(G, "bench_default.json")), open(os.path.join(P, TAG + "_default_bench.json"), "w"))
-copy(one("stats/*/*_kernel_stats.csv"), "default_kernel_stats.csv")
-copy(one("stats_e2e/*/*_kernel_stats.csv"), "e2e_kernel_stats.csv")
-copy(one("stats_prover/*/*_kernel_stats.csv"), "prover_kernel_stats.csv")
-have_pmc = all(one(d + "/*/*_counter_collection.csv") for d in ("pmc_valu", "pmc_wait", "pmc_fetch", "pmc_write"))
+if want("stats"):
+    copy(one("stats/*/*_kernel_stats.csv"), "default_kernel_stats.csv")
+    copy(one("stats_e2e/*/*_kernel_stats.csv"), "e2e_kernel_stats.csv")
+    copy(one("stats_prover/*/*_kernel_stats.csv"), "prover_kernel_stats.csv")
+have_pmc = want("pmc") and all(one(d + "/*/*_counter_collection.csv") for d in ("pmc_valu", "pmc_wait", "pmc_fetch", "pmc_write"))
 if have_pmc:
     for src, dst in (("pmc_valu", "pmc_valu.csv"), ("pmc_wait", "pmc_wait.csv"), ("pmc_fetch", "pmc_FETCH_SIZE.csv"), ("pmc_write", "pmc_WRITE_SIZE.csv")):
         copy(one(src + "/*/*_counter_collection.csv"), dst)
@@ -97,7 +104,7 @@ if have_pmc:
     print("merkle stage: %.2f GB per launch = %.3f x algorithmic; %.2f G VALU instructions" % (tot / 1e9, tot / alg, insts / 1e9))
 
 # the GPU text reader: HBM bytes per text byte
-if one("pmc_fetch_e2e/*/*_counter_collection.csv") and one("pmc_write_e2e/*/*_counter_collection.csv"):
+if want("pmc") and one("pmc_fetch_e2e/*/*_counter_collection.csv") and one("pmc_write_e2e/*/*_counter_collection.csv"):
     e = pmc_summary.summarise([os.path.dirname(one(dd + "/*/*_counter_collection.csv")) for dd in ("pmc_fetch_e2e", "pmc_write_e2e")],
                               newest_only=True, keep=("text_", "stwo_shared", "stwo_pack"))
     text = {}
@@ -110,7 +117,7 @@ if one("pmc_fetch_e2e/*/*_counter_collection.csv") and one("pmc_write_e2e/*/*_co
                "commit": commit, "kernels": text}, open(os.path.join(P, TAG + "_pmc_text_reader.json"), "w"), indent=1)
 
 lines = {}
-for f in sorted(glob.glob(os.path.join(G, "bench_*.json"))):
+for f in sorted(glob.glob(os.path.join(G, "bench_*.json"))) if want("bench") else []:
     try:
         line = last_json(f)
     except (ValueError, IndexError):
@@ -123,7 +130,7 @@ if lines:
                        "split over 8 (--proofs-per-gpu 8192; _ts1 = one Merkle stream, default = two)",
                "lines": lines}, open(os.path.join(P, TAG + "_bench_configs.json"), "w"), indent=1)
 e2e = {}
-for f in sorted(glob.glob(os.path.join(G, "e2e_*.json"))):
+for f in sorted(glob.glob(os.path.join(G, "e2e_*.json"))) if want("e2e") else []:
     try:
         e2e[os.path.basename(f)[:-5]] = json.load(open(f))
     except ValueError:
@@ -142,7 +149,7 @@ for name, src, head in (("sha_calibration.txt", "sha_bench.txt", "$ build/sha_be
                         ("text_fuzz.txt", "text_fuzz.txt", "$ python tools/text_fuzz.py 4000 20261004   (at %s; GPU reader against the scalar rule and the host reader, json / wit / json-shared)" % commit),
                         ("shape_sweep.txt", "shape_sweep.txt", "$ python tools/shape_sweep.py <shapes> <seed>   (at %s; the last line says how many)" % commit)):
     path = os.path.join(G, src)
-    if os.path.exists(path):
+    if want("text") and os.path.exists(path):
         body = [l for l in open(path).read().splitlines() if "amdgpu.ids" not in l]
         open(os.path.join(P, "%s_%s" % (TAG, name)), "w").write("\n".join([head] + body) + "\n")
 print("profiles written at", commit, "kernel sources", digest[:12])
