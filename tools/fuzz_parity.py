@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Differential fuzzing of the GPU verifiers against the CPU oracle (run on the GPU box).
 
-    python tools/fuzz_parity.py [mutations_per_case] [seed]
+    python tools/fuzz_parity.py [mutations_per_case] [seed] [shared-record structure mutants per case]
 
 For every proof family / configuration it mutates valid proofs (single bit flips, words
 replaced by 0 / P / P+v / 2^32-1, whole siblings swapped or zeroed, values copied between
@@ -25,6 +25,7 @@ import stwo_prover  # noqa: E402
 _cli = __name__ == "__main__"
 N = int(sys.argv[1]) if _cli and len(sys.argv) > 1 else 2000
 SEED = int(sys.argv[2]) if _cli and len(sys.argv) > 2 else 20251003
+N_STRUCT = int(sys.argv[3]) if _cli and len(sys.argv) > 3 else min(N, 400)  # structure mutants of a shared record (one oracle walk each)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 P31 = 2147483647
 P101 = 3221225473
@@ -143,7 +144,7 @@ def main():
             mism = int((got != want_all[keep]).sum())
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from test_shared_records import shared_mutants
-            sm = shared_mutants(base.cfg, shared[0], rng, min(N, 400))
+            sm = shared_mutants(base.cfg, shared[0], rng, N_STRUCT)
             exp = []
             for m in sm:
                 orc, orec = O.shared_expand(base.cfg, m)
