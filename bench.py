@@ -588,11 +588,26 @@ def main() -> None:
             accs[k].copy_(slots[k].accept_dev)
             dist.all_reduce(accs[k], op=dist.ReduceOp.SUM)
 
+    # Where the reduce of a pass is enqueued.  "reuse" (default): on the slot's head stream when the slot comes round
+    # again -- one pipeline depth later, flushed before the clock stops -- so the exchange needs no stream and no events
+    # of its own; "stream": at once, on the pipeline's communication stream (Pipeline.submit).
+    lazy = os.environ.get("SS_BENCH_REDUCE", "reuse") != "stream"
+
     def step(i: int, p=None) -> None:
-        (p or pipe).submit(reduce_accepts if grouped else None)
+        if not grouped:
+            (p or pipe).submit()
+        elif lazy:
+            (p or pipe).submit(on_reuse=reduce_accepts)
+        else:
+            (p or pipe).submit(reduce_accepts)
+
+    def flush(p=None) -> None:
+        if grouped and lazy:
+            (p or pipe).flush(reduce_accepts)
 
     for i in range(args.warmup):
         step(i)
+    flush()
     torch.cuda.synchronize()
     if args.warmup:
         assert batch.accepted() == n_local, "benchmark proofs must all be ACCEPT (%d of %d)" % (
@@ -621,6 +636,7 @@ def main() -> None:
         ver.collect_timing()
         for i in range(min(args.steps, 20)):
             step(i)
+        flush()
         torch.cuda.synchronize()
         timing = ver.collect_timing()
         ver.set_timing(False)
@@ -646,6 +662,7 @@ def main() -> None:
         ver.collect_timing()
         for i in range(min(args.steps, 20)):
             step(i)
+        flush()
         torch.cuda.synchronize()
         timing = ver.collect_timing()
         ver.set_timing(False)
@@ -657,12 +674,14 @@ def main() -> None:
         else:
             for i in range(2 * nslot):
                 step(i, timed_pipe)
+            flush(timed_pipe)
         if grouped:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(i, timed_pipe)
+        flush(timed_pipe)  # (the reduces of the last passes: inside the timed region)
         torch.cuda.synchronize()
         if grouped:
             dist.barrier()
@@ -672,6 +691,7 @@ def main() -> None:
             ver.collect_timing()
             for i in range(min(args.steps, 20)):
                 step(i)
+            flush()
             torch.cuda.synchronize()
         timing = ver.collect_timing()
         ver.set_timing(False)
@@ -740,7 +760,11 @@ def main() -> None:
                                      "eager, HEAD/TAIL pipelined" + (", Merkle halves alternating over %d streams (kernel "
                                                                      "durations from a separate non-overlapping pass)"
                                                                      % args.tail_streams if args.tail_streams > 1 else ""),
-                       "parallelism": "proofs sharded over %d GPU(s)" % world},
+                       "parallelism": "proofs sharded over %d GPU(s)" % world,
+                       "accept_reduce": None if not grouped else
+                       ("all-reduce(SUM) of every step's accept count over %s, " % backend) +
+                       ("enqueued on the slot's head stream when the slot is used again (one pipeline depth later), the last ones "
+                        "flushed inside the timed region" if lazy else "at once on the pipeline's communication stream")},
             "hbm_gb_s": value * bytes_per_proof / 1e9,
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

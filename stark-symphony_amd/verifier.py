@@ -46,16 +46,23 @@ class Pipeline:
         self.tail_done = [None for _ in self.slots]
         self.i = 0
 
-    def submit(self, after_tail=None) -> int:
-        """Enqueue one pass; returns the slot it used.  `after_tail(slot)` is called with the
-        communication stream current, ordered after the pass (e.g. to all-reduce its accept
-        count); the slot is not reused before it has completed."""
+    def submit(self, after_tail=None, on_reuse=None) -> int:
+        """Enqueue one pass; returns the slot it used.
+        `after_tail(slot)` is called with the communication stream current, ordered after the pass (e.g. to all-reduce
+        its accept count at once); the slot is not reused before that has completed.
+        `on_reuse(slot)` is called with the slot's HEAD stream current when the slot comes round again, after its
+        previous pass has completed and before the new one touches it (and by `flush` for the passes still pending at
+        the end): the same exchange, one pipeline depth later, without a stream of its own -- every stream more shifts
+        the hardware queue the others land on (bench.py, GPU_MAX_HW_QUEUES), and the head stream has the slack."""
         torch = _torch()
         k = self.i % len(self.slots)
         self.i += 1
         slot, hs = self.slots[k], self.head_streams[k]
         if self.tail_done[k] is not None:  # the slot's workspace is free again
             hs.wait_event(self.tail_done[k])
+            if on_reuse is not None:
+                with torch.cuda.stream(hs):
+                    on_reuse(k)
         slot.run(hs, PHASE_HEAD)
         # a fresh event per pass: re-recording one event inside a stream capture crashes
         # hipStreamEndCapture on ROCm 7.0 (tools/probes/graph_capture_probe.py)
@@ -76,6 +83,16 @@ class Pipeline:
             ev.record(self.comm_stream)
         self.tail_done[k] = ev
         return k
+
+    def flush(self, on_reuse) -> None:
+        """on_reuse for every slot whose last pass has not had it yet (call once after the last submit)."""
+        torch = _torch()
+        for k, hs in enumerate(self.head_streams):
+            if self.tail_done[k] is not None:
+                hs.wait_event(self.tail_done[k])
+                with torch.cuda.stream(hs):
+                    on_reuse(k)
+                self.tail_done[k] = None
 
     def synchronize(self) -> None:
         for s in self.head_streams:

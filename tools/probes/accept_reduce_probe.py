@@ -57,7 +57,22 @@ def main() -> None:
             dist.all_reduce(accs[k], op=dist.ReduceOp.SUM)
         return cb
 
-    variants = [("no reduce", none, False), ("copy + all-reduce on a communication stream", every_step, False)]
+    def nothing(pipe):      # the communication stream's two event waits only
+        return lambda k: None
+
+    def copy_only(pipe):
+        def cb(k):
+            accs[k].copy_(slots[k].accept_dev)
+        return cb
+
+    def reduce_in_place(pipe):
+        def cb(k):
+            dist.all_reduce(slots[k].accept_dev, op=dist.ReduceOp.SUM)
+        return cb
+
+    variants = [("no reduce", none, False), ("communication stream, no work on it", nothing, False),
+                ("copy of the counter", copy_only, False), ("all-reduce of the counter in place", reduce_in_place, False),
+                ("copy + all-reduce on a communication stream", every_step, False)]
     print("GPU_MAX_HW_QUEUES=%s, %d proofs per step, %d steps, five interleaved repetitions" % (
         os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"), n, steps))
     for ts in ((2,) if n < 65536 else (1,)):
