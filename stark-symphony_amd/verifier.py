@@ -31,13 +31,16 @@ class Pipeline:
     few per cent when a launch is only a few milliseconds (one GPU's 8 192-proof share of a batch);
     per-kernel durations measured under that overlap are inflated."""
 
-    def __init__(self, slots: Sequence["_DeviceBatch"], tail_streams: int = 1):
+    def __init__(self, slots: Sequence["_DeviceBatch"], tail_streams: int = 1, head_streams: int = 0):
         torch = _torch()
         self.slots = list(slots)
         dev = self.slots[0].ver.device
-        # one head stream per slot: HEAD halves are latency bound (a few waves per CU), so
-        # several of them also overlap each other; TAIL halves share one stream.
-        self.head_streams = [torch.cuda.Stream(device=dev) for _ in self.slots]
+        # one head stream per slot (head_streams = 0): HEAD halves are latency bound (a few waves per CU), so
+        # several of them also overlap each other; TAIL halves share one stream.  head_streams = 1 measures the same
+        # at 8 192 and 65 536 proofs per pass (profiles/r04_accept_reduce.txt) and leaves a process that keeps the
+        # runtime's 4 hardware queues with a stream per queue.
+        made = [torch.cuda.Stream(device=dev) for _ in range(head_streams or len(self.slots))]
+        self.head_streams = [made[i % len(made)] for i in range(len(self.slots))]
         # (a high-priority tail stream was tried: no measurable effect on MI355X)
         self.tail_streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, tail_streams))]
         self.tail_stream = self.tail_streams[0]
