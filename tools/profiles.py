@@ -19,7 +19,7 @@ import pmc_summary  # noqa: E402
 import bench  # noqa: E402
 
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
-ONLY = set(sys.argv[2:])  # `profiles.py r04 bench`: only the bench lines (sections: bench stats pmc e2e text); default: everything
+ONLY = set(sys.argv[2:])  # `profiles.py r04 bench host`: only those (bench stats pmc e2e sha host prover fuzz textfuzz sweep); default: everything
 
 
 def want(section):
@@ -140,16 +140,16 @@ if e2e:
                        "proof.json, read and expanded on the GPU) (e2e_4096: 4096 texts of the 2^20 shape, with --files; _nc1: 1 % of the texts with "
                        "reversed member order = host reader; _512: a small batch; _2p16: the 2^16 / Q=32 shape; _pysep: proof.json with json.dumps' "
                        "default separators)", "commit": commit, "runs": e2e}, open(os.path.join(P, TAG + "_e2e.json"), "w"), indent=1)
-for name, src, head in (("sha_calibration.txt", "sha_bench.txt", "$ build/sha_bench 512      (tools/sha_bench.hip at %s; MI355X)" % commit),
-                        ("host_path.txt", "host_path.txt", "$ python tools/host_path_bench.py 2048 [distinct]; ... 16384 [distinct]   (ss_stwo_verify_records and "
+for sect, name, src, head in (("sha", "sha_calibration.txt", "sha_bench.txt", "$ build/sha_bench 512      (tools/sha_bench.hip at %s; MI355X)" % commit),
+                        ("host", "host_path.txt", "host_path.txt", "$ python tools/host_path_bench.py 2048 [distinct]; ... 16384 [distinct]   (ss_stwo_verify_records and "
                                                            "ss_stwo_verify_shared_records, 2^20 shape, at %s; the first call of a run allocates the scratch; "
                                                            "`distinct`: every record its own host buffer)" % commit),
-                        ("prover_bench.txt", "prover_bench.txt", "$ python tools/prover_bench.py 20 3 sha256 1,4,4,3 48; python tools/prover101_bench.py   (at %s)" % commit),
-                        ("fuzz_parity.txt", "fuzz_parity.txt", "$ python tools/fuzz_parity.py 20000 20261004   (at %s; GPU status words against the oracle, per-query and shared records)" % commit),
-                        ("text_fuzz.txt", "text_fuzz.txt", "$ python tools/text_fuzz.py 4000 20261004   (at %s; GPU reader against the scalar rule and the host reader, json / wit / json-shared)" % commit),
-                        ("shape_sweep.txt", "shape_sweep.txt", "$ python tools/shape_sweep.py <shapes> <seed>   (at %s; the last line says how many)" % commit)):
+                        ("prover", "prover_bench.txt", "prover_bench.txt", "$ python tools/prover_bench.py 20 3 sha256 1,4,4,3 48; python tools/prover101_bench.py   (at %s)" % commit),
+                        ("fuzz", "fuzz_parity.txt", "fuzz_parity.txt", "$ python tools/fuzz_parity.py 20000 20261004   (at %s; GPU status words against the oracle, per-query and shared records)" % commit),
+                        ("textfuzz", "text_fuzz.txt", "text_fuzz.txt", "$ python tools/text_fuzz.py 4000 20261004   (at %s; GPU reader against the scalar rule and the host reader, json / wit / json-shared)" % commit),
+                        ("sweep", "shape_sweep.txt", "shape_sweep.txt", "$ python tools/shape_sweep.py <shapes> <seed>   (at %s; the last line says how many)" % commit)):
     path = os.path.join(G, src)
-    if want("text") and os.path.exists(path):
+    if want(sect) and os.path.exists(path):
         body = [l for l in open(path).read().splitlines() if "amdgpu.ids" not in l]
         open(os.path.join(P, "%s_%s" % (TAG, name)), "w").write("\n".join([head] + body) + "\n")
 print("profiles written at", commit, "kernel sources", digest[:12])
