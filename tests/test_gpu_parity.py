@@ -270,6 +270,39 @@ def test_pipeline_matches_single_stream(ver, stwo_prod):
         assert slot.accepted() == int((ref == 0).sum())
 
 
+def test_pipeline_callbacks_see_every_pass_once(ver, stwo_prod):
+    """Pipeline.submit(after_tail=...) / (on_reuse=...) + flush: the hook a caller hangs its accept reduce on runs exactly
+    once per pass, ordered after that pass and before the slot's next one (bench.py's use: all_reduce of the count); with
+    two tail streams and a single head stream (head_streams=1) the verdicts are the same."""
+    import torch
+    rng = np.random.default_rng(SEED + 15)
+    distinct = [stwo_prod] + [formats.stwo_corrupt(stwo_prod, rng)[0] for _ in range(5)]
+    batch = [distinct[i % 6] for i in range(192)]
+    ref = ver.verify_stwo(batch, cfg=stwo_prod.cfg)
+    want = int((ref == 0).sum())
+    a = ver.stwo_batch(batch)
+    for kw in ({}, {"tail_streams": 2}, {"tail_streams": 2, "head_streams": 1}):
+        slots = [a, a.sibling(), a.sibling()]
+        for how in ("after_tail", "on_reuse"):
+            pipe = verifier.Pipeline(slots, **kw)
+            total = torch.zeros(1, dtype=torch.int64, device=ver.device)
+            calls = []
+
+            def hook(k):
+                calls.append(k)
+                total.add_(slots[k].accept_dev.to(torch.int64))  # on the stream the pipeline made current: ordered after pass k
+
+            for _ in range(7):
+                pipe.submit(**{how: hook})
+            if how == "on_reuse":
+                assert calls == [0, 1, 2, 0]  # passes 0..3 when their slots came round; 4, 5, 6 are still pending
+                pipe.flush(hook)
+            pipe.synchronize()
+            assert sorted(calls) == [0, 0, 0, 1, 1, 2, 2] and int(total.item()) == 7 * want, (kw, how, calls)
+            for slot in slots:
+                assert slot.status().tolist() == ref.tolist()
+
+
 @pytest.mark.parametrize("which,n", [("small", 3), ("prod", 70), ("wide", 5)])
 def test_device_pack_equals_host_pack(ver, stwo_small, stwo_prod, which, n):
     """ss_stwo_pack_dev (GPU re-tiling of raw records) writes the same words as ss_stwo_pack."""
