@@ -3,6 +3,9 @@ One rank forms a "nccl" group (RCCL) and runs the bench pipeline without the red
 (every step, a copy of the counter and an all-reduce on the pipeline's communication stream), five interleaved repetitions
 each, every one with freshly made streams.  Run it under different GPU_MAX_HW_QUEUES: the streams of a process share the
 runtime's hardware queues, and a head stream that shares a queue with a tail stream loses its overlap.
+Caveat: torch hands out streams from a pool of 32 per device, so after a few repetitions "freshly made" streams are old
+ones on whatever queue they had -- read the FIRST repetition of each variant as the clean one, the spread as what a
+process that makes many streams can run into; the bench-level table of profiles/r04_accept_reduce.txt is the reference.
 Run on a GPU box:  GPU_MAX_HW_QUEUES=16 python tools/probes/accept_reduce_probe.py [n] [steps]"""
 import os
 import sys
