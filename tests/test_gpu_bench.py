@@ -183,6 +183,7 @@ def test_bench_collectives_through_rccl_with_one_rank():
         assert d["n_gpus"] == 1 and d["steps"] == 8
         assert abs(d["value"] - d["config"]["proofs_per_step"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
         assert "errors" not in d["e2e"] and d["e2e"]["records"]["proofs_per_s"] > 0
+        assert d["config"]["accept_reduce"].startswith("all-reduce(SUM) of every step's accept count over nccl")
 
 
 @pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs: the first RCCL evidence comes from a multi-GPU box")
