@@ -56,7 +56,8 @@ class Pipeline:
         `on_reuse(slot)` is called with the slot's HEAD stream current when the slot comes round again, after its
         previous pass has completed and before the new one touches it (and by `flush` for the passes still pending at
         the end): the same exchange, one pipeline depth later, without a stream of its own -- every stream more shifts
-        the hardware queue the others land on (bench.py, GPU_MAX_HW_QUEUES), and the head stream has the slack."""
+        the hardware queue the others land on (bench.py, GPU_MAX_HW_QUEUES), and the head stream has the slack.  Hooks of
+        different slots run on different head streams, possibly at the same time: keep their state per slot."""
         torch = _torch()
         k = self.i % len(self.slots)
         self.i += 1

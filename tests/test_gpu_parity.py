@@ -285,12 +285,13 @@ def test_pipeline_callbacks_see_every_pass_once(ver, stwo_prod):
         slots = [a, a.sibling(), a.sibling()]
         for how in ("after_tail", "on_reuse"):
             pipe = verifier.Pipeline(slots, **kw)
-            total = torch.zeros(1, dtype=torch.int64, device=ver.device)
+            # one accumulator per slot: on_reuse hooks of different slots run on different head streams, at the same time
+            totals = torch.zeros(len(slots), dtype=torch.int64, device=ver.device)
             calls = []
 
             def hook(k):
                 calls.append(k)
-                total.add_(slots[k].accept_dev.to(torch.int64))  # on the stream the pipeline made current: ordered after pass k
+                totals[k:k + 1].add_(slots[k].accept_dev.to(torch.int64))  # on the stream the pipeline made current: ordered after pass k
 
             for _ in range(7):
                 pipe.submit(**{how: hook})
@@ -298,7 +299,7 @@ def test_pipeline_callbacks_see_every_pass_once(ver, stwo_prod):
                 assert calls == [0, 1, 2, 0]  # passes 0..3 when their slots came round; 4, 5, 6 are still pending
                 pipe.flush(hook)
             pipe.synchronize()
-            assert sorted(calls) == [0, 0, 0, 1, 1, 2, 2] and int(total.item()) == 7 * want, (kw, how, calls)
+            assert sorted(calls) == [0, 0, 0, 1, 1, 2, 2] and totals.tolist() == [3 * want, 2 * want, 2 * want], (kw, how, calls, totals.tolist())
             for slot in slots:
                 assert slot.status().tolist() == ref.tolist()
 
