@@ -42,9 +42,12 @@
 extern "C" {
 #endif
 
-#define SS_VERSION 0x00020002 /* 2.0: stwo records carry their Merkle path lengths; shape_status is gone.
+#define SS_VERSION 0x00020003 /* 2.0: stwo records carry their Merkle path lengths; shape_status is gone.
                                  2.1: GPU text reader behind the text entry points, ss_stwo_write_text, thread rules
-                                 2.2: shared records (every distinct Merkle sibling once), expanded on the GPU */
+                                 2.2: shared records (every distinct Merkle sibling once), expanded on the GPU
+                                 2.3: minimal records (one sorted, deduplicated decommitment per tree), verified without
+                                      expansion; ss_selftest replays the reference's known-answer tests; stark101
+                                      intermediates; caller-pinned host buffers */
 
 /* return codes (all < 0 are errors; verdicts live in the status array) */
 #define SS_OK 0
@@ -181,6 +184,35 @@ int ss_stwo_share_record(const ss_stwo_cfg *cfg, const uint32_t *record, const u
  * SS_STATUS_MALFORMED (record_out zeroed).  Pure.                                                                */
 int ss_stwo_unshare_record(const ss_stwo_cfg *cfg, const uint32_t *shared, size_t words, uint32_t *record_out);
 
+/* Minimal record: one decommitment per TREE instead of one path per query -- what upstream stwo's prover sends
+ * (MerkleDecommitment / FriLayerProof of starkware-libs/stwo, a dependency that is not in the reference's repository)
+ * before the reference's adapter cuts it per query (scripts/generate_wit.py:36-42; fri/queries.simf:41 "we do not sort and
+ * remove duplicates"; merkle.simf:22-44 folds one path).  With Nodes(a) = the distinct positions `query >> a`, ascending,
+ * and Lone(a) = those whose sibling `x ^ 1` is not among them (a = 0 .. lde_log - 1 counts from the leaves):
+ *   head                       roots[3][8] oods_trace[n_cols][4] oods_cp[16][4] fri_roots[1+n_layers][8] last_layer[4] nonce_hi _lo
+ *   n_vals[2]  n_fw[1+n_layers]  n_hw[3+n_layers]         the lengths of the lists below (data, like a path's length)
+ *   trace_vals[n_vals[0]][n_cols]  cp_vals[n_vals[1]][16]  once per node of Nodes(0)
+ *   fri_wit[l][n_fw[l]][4]                                 layer l: the fold partners of Lone(l), i.e. the members of the
+ *                                                          layer's pairs that are not queried themselves
+ *   hash_wit[t][n_hw[t]][8]                                tree t (0 trace, 1 cp, 2+l FRI layer l): the siblings of Lone(a)
+ *                                                          for a = first .. lde_log-1 (first = 0, 0, l+1), level by level
+ * Every other sibling / partner is a value the verifier computes from another query's chain, and the library takes it
+ * from there: no expansion pass, no hint -- the queries are the verifier's own.  Verdicts: a minimal record M verifies
+ * exactly as R(M), the per-query record in which each omitted value is the computed one; a tree whose lists do not have
+ * the lengths the queries imply fails like a path of the wrong length (sub 0 of stage 5 / 7, query 0).  A record whose
+ * size is not what its counts give, or whose counts exceed n_queries (x the tree's depth), is SS_STATUS_MALFORMED.
+ * No bytes of this form exist in the reference: PARITY UNPINNED; the published algorithm is restated in
+ * oracle/ss_oracle.c and held against the per-query path through R(M).  Only proofs whose paths all have the config's
+ * lengths and whose queries agree wherever they present the same thing have a minimal form.                       */
+size_t ss_stwo_minimal_fixed_words(const ss_stwo_cfg *cfg);
+size_t ss_stwo_minimal_max_words(const ss_stwo_cfg *cfg);
+/* list lengths for these positions: counts[0..1] = n_vals, [2 .. 2+n_layers] = n_fw, [3+n_layers .. 5+2 n_layers] = n_hw.  Pure. */
+int ss_stwo_minimal_counts(const ss_stwo_cfg *cfg, const uint32_t *queries, uint32_t *counts);
+/* per-query record + the positions its prover drew -> minimal record (a selection: nothing is hashed or checked beyond
+ * "queries that present the same thing present the same words").  Returns 0, or 1 = no minimal form.  Pure.        */
+int ss_stwo_minimise_record(const ss_stwo_cfg *cfg, const uint32_t *record, const uint32_t *queries, uint32_t *minimal_out,
+                            size_t cap_words, size_t *words_out);
+
 /* ======================================================================= execution
  * One context per process and GPU (one process per GPU is the intended deployment).
  * Threads.  A context may be shared by threads.  Entry points that use the context's own scratch
@@ -250,6 +282,19 @@ int ss_s101_verify_records(ss_ctx *ctx, const ss_s101_shape *shape, size_t n,
                            const uint32_t *const *records, uint32_t *status_host);
 int ss_stwo_verify_records(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n,
                            const uint32_t *const *records, uint32_t *status_host);
+
+/* Minimal records on the device: min_dev holds n minimal records, record i at word offset offs_dev[i] with offs_dev[i+1]
+ * - offs_dev[i] words; batch_dev (ss_stwo_minimal_batch_words words) and the workspace (ss_stwo_minimal_workspace_bytes)
+ * are scratch the call fills.  SS_PHASE_HEAD = read the records, transcript, plan + gather, query kernel; SS_PHASE_TAIL =
+ * merkle / top / finalize, as for ss_stwo_verify_phase_dev.  Asynchronous, no allocation, graph-capturable.        */
+size_t ss_stwo_minimal_batch_words(const ss_stwo_cfg *cfg, size_t n);
+size_t ss_stwo_minimal_workspace_bytes(const ss_stwo_cfg *cfg, size_t n);
+int ss_stwo_verify_minimal_dev(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const uint32_t *min_dev,
+                               const uint64_t *offs_dev, uint32_t *batch_dev, void *workspace_dev, size_t workspace_bytes,
+                               uint32_t *status_dev, uint32_t *accept_count_dev, int phases, void *stream);
+/* The same from host memory (minimal[i] has words[i] words): the fewest bytes on the host link of all input forms. */
+int ss_stwo_verify_minimal_records(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const uint32_t *const *minimal,
+                                   const size_t *words, uint32_t *status_host);
 
 /* The same from shared records (shared[i] has words[i] words): fewer bytes on the host link, expanded behind it. */
 int ss_stwo_verify_shared_records(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const uint32_t *const *shared,

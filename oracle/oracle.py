@@ -191,6 +191,8 @@ def lib() -> C.CDLL:
         u32p, i)
     sig("so_num_procs", i)
     sig("so_stwo_fri_tail", u32, i, u32, u32, u32, u32, QM31, QM31)
+    sig("so_stwo_verify_minimal", u32, C.POINTER(StwoCfg), u32p, C.c_size_t, i)
+    sig("so_stwo_minimal_expand", u32, C.POINTER(StwoCfg), u32p, C.c_size_t, i, u32p)
     sig("so_shared_walk", u32, u32, u32, u32, u32p, u32p)
     sig("so_shared_expand", i, u32, u32, u32, u32, u32p, C.c_size_t, u32p)
     _lib = L
@@ -391,6 +393,31 @@ def shared_expand(cfg, shared: np.ndarray):
     u32p = C.POINTER(C.c_uint32)
     rc = lib().so_shared_expand(N, L, Q, K, sh.ctypes.data_as(u32p), sh.size, rec.ctypes.data_as(u32p))
     return int(rc), rec
+
+
+def _cfg_struct(cfg) -> StwoCfg:
+    return StwoCfg(cfg.n_cols, cfg.trace_log, cfg.lde_log, cfg.n_queries, cfg.n_layers, cfg.pow_target,
+                   1 if getattr(cfg, "hash", "sha256") == "blake2s" else 0)
+
+
+def stwo_verify_minimal(cfg, rec: np.ndarray, mode: int = MODE_FIXTURE) -> int:
+    """Status of a MINIMAL record (include/ss_verify.h) by the layer-by-layer walk of upstream stwo's MerkleVerifier /
+    SparseEvaluation as restated in ss_oracle.c (parity unpinned: the reference has no such format)."""
+    r = np.ascontiguousarray(rec, dtype=np.uint32)
+    return int(lib().so_stwo_verify_minimal(C.byref(_cfg_struct(cfg)), r.ctypes.data_as(C.POINTER(C.c_uint32)), r.size, mode))
+
+
+def stwo_minimal_expand(cfg, rec: np.ndarray, mode: int = MODE_FIXTURE):
+    """-> (status, R(M)): the per-query record a minimal record corresponds to (every omitted sibling / fold-pair
+    evaluation replaced by the value the walk computes; a tree whose lists have the wrong length gets path_len 0)."""
+    N, L, Q, K = cfg.n_cols, cfg.lde_log, cfg.n_queries, cfg.n_layers
+    words = 24 + 4 * N + 64 + 8 * (K + 1) + 6 + Q * (N + 16 + 16 * L) + sum(Q * (4 + 8 * (L - 1 - l)) for l in range(K + 1)) \
+        + (K + 3) * Q
+    r = np.ascontiguousarray(rec, dtype=np.uint32)
+    out = np.zeros(words, dtype=np.uint32)
+    u32p = C.POINTER(C.c_uint32)
+    st = lib().so_stwo_minimal_expand(C.byref(_cfg_struct(cfg)), r.ctypes.data_as(u32p), r.size, mode, out.ctypes.data_as(u32p))
+    return int(st), out
 
 
 def num_procs() -> int:

@@ -256,6 +256,15 @@ uint32_t so_shared_walk(uint32_t lde_log, uint32_t tree, uint32_t n_queries, con
 int so_shared_expand(uint32_t n_cols, uint32_t lde_log, uint32_t n_queries, uint32_t n_layers, const uint32_t *shared,
                      size_t words, uint32_t *record);
 
+/* ----------------------------------------------------- minimal decommitment (ss_oracle.c, last section)
+ * Upstream stwo's one-decommitment-per-tree form (queries sorted and deduplicated, only the siblings / fold-pair
+ * evaluations the verifier cannot compute): PARITY UNPINNED, the reference holds no bytes of it (fri/queries.simf:41).
+ * `rec` is a minimal record (include/ss_verify.h).  so_stwo_verify_minimal restates the published layer-by-layer walk;
+ * so_stwo_minimal_expand also writes R(M), the per-query record in which every omitted value is the one the walk
+ * computes -- status(M) is defined as so_stwo_verify(R(M)).  2 = no minimal record of the config.             */
+uint32_t so_stwo_verify_minimal(const so_stwo_cfg *cfg, const uint32_t *rec, size_t words, int mode);
+uint32_t so_stwo_minimal_expand(const so_stwo_cfg *cfg, const uint32_t *rec, size_t words, int mode, uint32_t *record_out);
+
 #ifdef __cplusplus
 }
 #endif

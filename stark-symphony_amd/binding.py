@@ -65,6 +65,9 @@ EXPORTS = [
     "ss_s101_write_text", "ss_s101_text_is_canonical", "ss_s101_pack_dev", "ss_s101_read_texts",
     "ss_stwo_shared_fixed_words", "ss_stwo_shared_max_words", "ss_stwo_shared_counts", "ss_stwo_share_record",
     "ss_stwo_unshare_record", "ss_stwo_expand_shared_dev", "ss_stwo_verify_shared_records", "ss_stwo_write_shared_text",
+    "ss_stwo_minimal_fixed_words", "ss_stwo_minimal_max_words", "ss_stwo_minimal_counts", "ss_stwo_minimise_record",
+    "ss_stwo_minimal_batch_words", "ss_stwo_minimal_workspace_bytes", "ss_stwo_verify_minimal_dev",
+    "ss_stwo_verify_minimal_records",
 ]
 
 _lib = None
@@ -143,6 +146,14 @@ def lib() -> C.CDLL:
     sig("ss_stwo_expand_shared_dev", C.c_int, vp, cp, sz, vp, vp, vp, vp, vp)
     sig("ss_stwo_verify_shared_records", C.c_int, vp, cp, sz, pp, szp, vp)
     sig("ss_stwo_write_shared_text", sz, cp, vp, sz, C.c_int, vp, sz)
+    sig("ss_stwo_minimal_fixed_words", sz, cp)
+    sig("ss_stwo_minimal_max_words", sz, cp)
+    sig("ss_stwo_minimal_counts", C.c_int, cp, vp, vp)
+    sig("ss_stwo_minimise_record", C.c_int, cp, vp, vp, vp, sz, szp)
+    sig("ss_stwo_minimal_batch_words", sz, cp, sz)
+    sig("ss_stwo_minimal_workspace_bytes", sz, cp, sz)
+    sig("ss_stwo_verify_minimal_dev", C.c_int, vp, cp, sz, vp, vp, vp, vp, sz, vp, vp, C.c_int, vp)
+    sig("ss_stwo_verify_minimal_records", C.c_int, vp, cp, sz, pp, szp, vp)
     _lib = L
     return L
 

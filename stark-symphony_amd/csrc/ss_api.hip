@@ -231,6 +231,46 @@ extern "C" int ss_stwo_read_intermediates(ss_ctx *ctx, const ss_stwo_cfg *c, siz
     return SS_OK;
 }
 
+// TAIL half of a pass: merkle kernel, top (+ cold) kernel, finalize.  `y` is the batch's layout (per-query or minimal).
+static int stwo_tail(ss_ctx *ctx, const ss_stwo_cfg *c, const StwoLayout &y, const uint32_t *batch, uint32_t *ws,
+                     uint32_t *status, uint32_t *accept_count, hipStream_t s)
+{
+    Timer t(ctx, s);
+    const uint32_t tiles = (y.K + 3) * (y.nip >> 6);
+    // the top kernel's group counter, its count of flagged trees and -- when the merkle kernel makes the byte
+    // compares (y.mchk) -- the flags it raises, which lie directly behind
+    if (y.T) HIP_TRY(hipMemsetAsync(ws + y.ws_counter, 0, y.mchk ? (y.ws_plan - y.ws_counter) * 4 : 8, s));
+    t.begin();
+    const int hf = c->hash == SS_HASH_BLAKE2S;
+    if (y.minimal)
+        hipLaunchKernelGGL(hf ? stwo_merkle_min_kernel_b2s : stwo_merkle_min_kernel_sha, dim3((tiles + 3) / 4), dim3(256), 0, s, y,
+                           batch, ws, status);
+    else
+        hipLaunchKernelGGL(hf ? stwo_merkle_kernel_b2s : stwo_merkle_kernel_sha, dim3((tiles + 3) / 4), dim3(256), 0, s, y, batch,
+                           ws, status);
+    t.end("stwo_merkle");
+    if (y.T) {
+        t.begin();
+        const int ho = y.mchk != 0;
+        const uint32_t blocks = std::min<uint32_t>(y.top_blocks, (uint32_t)(ctx->top_blocks_per_cu[hf][ho] * std::min(ctx->cus, 256)));
+        void *args[] = {(void *)&y, (void *)&batch, (void *)&ws, (void *)&status};
+        // (behind minimal records the hash-only variant that takes computed siblings from their leaders: same footprint)
+        const void *fn = y.minimal ? (hf ? (const void *)stwo_top_min_kernel_b2s : (const void *)stwo_top_min_kernel_sha) : top_kernel(hf, ho);
+        HIP_TRY(hipLaunchKernel(fn, dim3(blocks), dim3(kTopChains), args, 0, s));
+        t.end("stwo_top");
+        // trees in which queries disagree about a node (none in an honest batch: the grid reads one word and leaves)
+        t.begin();
+        hipLaunchKernelGGL(hf ? stwo_top_cold_kernel_b2s : stwo_top_cold_kernel_sha, dim3(4 * ctx->cus), dim3(256), 0, s,
+                           y, batch, (const uint32_t *)ws, status);
+        t.end("stwo_top_cold");
+    }
+    t.begin();
+    hipLaunchKernelGGL(stwo_finalize_kernel, dim3((y.n + 255) / 256), dim3(256), 0, s, y.n, status,
+                       accept_count);
+    t.end("stwo_finalize");
+    return SS_OK;
+}
+
 extern "C" int ss_stwo_verify_phase_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n,
                                         const uint32_t *batch, void *workspace, size_t workspace_bytes,
                                         uint32_t *status, uint32_t *accept_count, int phases,
@@ -261,32 +301,39 @@ extern "C" int ss_stwo_verify_phase_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_
         t.end("stwo_query");
     }
     if (phases & SS_PHASE_TAIL) {
-        const uint32_t tiles = (y.K + 3) * (y.nip >> 6);
-        // the top kernel's group counter, its count of flagged trees and -- when the merkle kernel makes the byte
-        // compares (y.mchk) -- the flags it raises, which lie directly behind
-        if (y.T) HIP_TRY(hipMemsetAsync(ws + y.ws_counter, 0, y.mchk ? (y.ws_plan - y.ws_counter) * 4 : 8, s));
-        t.begin();
-        hipLaunchKernelGGL(c->hash == SS_HASH_BLAKE2S ? stwo_merkle_kernel_b2s : stwo_merkle_kernel_sha,
-                           dim3((tiles + 3) / 4), dim3(256), 0, s, y, batch, ws, status);
-        t.end("stwo_merkle");
-        if (y.T) {
-            t.begin();
-            const int hf = c->hash == SS_HASH_BLAKE2S;
-            const int ho = y.mchk != 0;
-            const uint32_t blocks = std::min<uint32_t>(y.top_blocks, (uint32_t)(ctx->top_blocks_per_cu[hf][ho] * std::min(ctx->cus, 256)));
-            void *args[] = {(void *)&y, (void *)&batch, (void *)&ws, (void *)&status};
-            HIP_TRY(hipLaunchKernel(top_kernel(hf, ho), dim3(blocks), dim3(kTopChains), args, 0, s));
-            t.end("stwo_top");
-            // trees in which queries disagree about a node (none in an honest batch: the grid reads one word and leaves)
-            t.begin();
-            hipLaunchKernelGGL(hf ? stwo_top_cold_kernel_b2s : stwo_top_cold_kernel_sha, dim3(4 * ctx->cus), dim3(256), 0, s,
-                               y, batch, (const uint32_t *)ws, status);
-            t.end("stwo_top_cold");
-        }
-        t.begin();
-        hipLaunchKernelGGL(stwo_finalize_kernel, dim3((y.n + 255) / 256), dim3(256), 0, s, y.n, status,
-                           accept_count);
-        t.end("stwo_finalize");
+        const int rc = stwo_tail(ctx, c, y, batch, ws, status, accept_count, s);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipGetLastError());
+    return SS_OK;
+}
+
+// Minimal records (csrc/ss_minimal.hip): the HEAD half reads the records, fills `batch_dev` and the workspace; the TAIL
+// half is the per-query path's, on the minimal layout.
+extern "C" int ss_stwo_verify_minimal_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const uint32_t *min_dev,
+                                          const uint64_t *offs_dev, uint32_t *batch_dev, void *workspace, size_t workspace_bytes,
+                                          uint32_t *status, uint32_t *accept_count, int phases, void *stream_)
+{
+    SS_DEVICE_GUARD(ctx);
+    if (!cfg_ok(c)) return set_err(SS_ERR_ARG, "unsupported stwo config");
+    if (!n || !min_dev || !offs_dev || !batch_dev || !workspace || !status) return set_err(SS_ERR_ARG, "null/empty argument");
+    if (n * (size_t)kMaxQueries > 0x7fffffffu) return set_err(SS_ERR_ARG, "batch too large");
+    if (!(phases & SS_PHASE_ALL)) return set_err(SS_ERR_ARG, "no phase selected");
+    const StwoLayout y = lay_of(c, n, true);
+    if (workspace_bytes < y.ws_total_words * 4)
+        return set_err(SS_ERR_WORKSPACE, "workspace %zu < %llu bytes", workspace_bytes,
+                       (unsigned long long)y.ws_total_words * 4);
+    hipStream_t s = (hipStream_t)stream_;
+    uint32_t *ws = (uint32_t *)workspace;
+    if (phases & SS_PHASE_HEAD) {
+        HIP_TRY(hipMemsetAsync(status, 0xff, n * 4, s));
+        if (accept_count) HIP_TRY(hipMemsetAsync(accept_count, 0, 4, s));
+        const int rc = stwo_minimal_head(ctx, c, y, min_dev, offs_dev, batch_dev, ws, status, s);
+        if (rc) return rc;
+    }
+    if (phases & SS_PHASE_TAIL) {
+        const int rc = stwo_tail(ctx, c, y, batch_dev, ws, status, accept_count, s);
+        if (rc) return rc;
     }
     HIP_TRY(hipGetLastError());
     return SS_OK;

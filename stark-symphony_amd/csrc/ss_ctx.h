@@ -136,6 +136,10 @@ int shared_expand_launch(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const uint
                          uint64_t capacity_stride, uint32_t *records_dev, uint32_t *outcome_dev, hipStream_t s,
                          const uint8_t *only_fmt = nullptr, const uint32_t *hint_pos = nullptr, uint32_t hint_stride = 0);  // ss_shared.hip
 
+// HEAD half in front of minimal records (ss_minimal.hip): head words, transcript, plan + gather into `batch`, query kernel
+int stwo_minimal_head(ss_ctx *ctx, const ss_stwo_cfg *c, const StwoLayout &y, const uint32_t *recs_dev, const uint64_t *offs_dev,
+                      uint32_t *batch, uint32_t *ws, uint32_t *status, hipStream_t s);
+
 int grow(GrowBuf &b, size_t bytes, bool pinned);  // (re)allocates when too small; contents are not kept
 void release(GrowBuf &b);
 

@@ -75,6 +75,13 @@ struct StwoLayout {
     uint32_t mchk;
     uint64_t ws_plan;     // plan[inst] = 4 words: byte dd-1 of words 0..1 = the query (of its proof) that leads this
                           // chain's position at depth dd, of words 2..3 = the one that leads the sibling position (0xff: none)
+    // Minimal records (ss_minimal.h): the batch is filled by stwo_min_expand_kernel from the verifier's OWN queries, the
+    // siblings / fold-pair evaluations the record omits are holes that the kernels fill from the chain that computes
+    // them.  Q is then the query count padded to a divisor of 64 (chains Qd .. Q-1 of a proof repeat query 0: whatever
+    // they fail, chain 0 fails with a smaller code), Qd the count the transcript draws.
+    uint32_t minimal, Qd;
+    uint64_t ws_sib;      // sib[inst][32 bytes]: byte a = the query of the proof whose node at absolute level a is this
+                          // chain's sibling (0xff: none, the sibling comes from the witness)
 };
 
 constexpr uint32_t kTopChains = 256;     // chains a top-kernel block plans at once (= its threads)
@@ -100,9 +107,17 @@ SS_HD inline bool stwo_cfg_ok(uint32_t N, uint32_t TL, uint32_t L, uint32_t Q, u
 SS_HD inline StwoLayout stwo_layout(uint32_t N, uint32_t TL, uint32_t L, uint32_t Q, uint32_t K,
                                     uint32_t mode, uint64_t pow_target, uint64_t n, bool dedup = true,
                                     bool light_hash = false, uint32_t min_groups = kTopMinGroups,
-                                    bool merkle_checks = true)
+                                    bool merkle_checks = true, bool minimal = false)
 {
     StwoLayout y{};
+    y.Qd = Q;
+    y.minimal = minimal;
+    if (minimal) {  // every proof gets a power-of-two number of chains (<= 64): its chains are lanes of one wavefront
+        uint32_t qp = 1;
+        while (qp < Q) qp <<= 1;
+        Q = qp;
+        merkle_checks = true;
+    }
     y.N = N; y.TL = TL; y.L = L; y.Q = Q; y.K = K; y.mode = mode; y.pow_target = pow_target;
     y.n = (uint32_t)n;
     y.np = (uint32_t)round_up64(n);
@@ -182,6 +197,7 @@ SS_HD inline StwoLayout stwo_layout(uint32_t N, uint32_t TL, uint32_t L, uint32_
     y.ws_flag = w;  w += y.T ? (uint64_t)(K + 3) * y.np : 0;  // (directly behind the counter: one memset clears both)
     y.mchk = y.T && merkle_checks && 64 % Q == 0;
     y.ws_plan = w;  w += y.mchk ? (uint64_t)y.nip * 4 : 0;
+    y.ws_sib = w;   w += minimal ? (uint64_t)y.nip * 8 : 0;
     y.ws_total_words = w;
     return y;
 }

@@ -19,11 +19,11 @@ bool ss::cfg_ok(const ss_stwo_cfg *c)
 // The layout of a batch and of its workspace is a function of (cfg, n) ONLY -- no process state: a caller may size
 // buffers in one process and verify in another (the round-3 A/B environment knobs are gone: the byte
 // compares' place is cfg.flags & SS_FLAG_TOP_CHECKS, the group size is the compile-time kTopMinGroups).
-StwoLayout ss::lay_of(const ss_stwo_cfg *c, size_t n)
+StwoLayout ss::lay_of(const ss_stwo_cfg *c, size_t n, bool minimal)
 {
     return stwo_layout(c->n_cols, c->trace_log, c->lde_log, c->n_queries, c->n_layers, c->mode,
                        c->pow_target, n, !(c->flags & SS_FLAG_NO_DEDUP), c->hash == SS_HASH_BLAKE2S, kTopMinGroups,
-                       !(c->flags & SS_FLAG_TOP_CHECKS));
+                       !(c->flags & SS_FLAG_TOP_CHECKS), minimal);
 }
 
 extern "C" size_t ss_stwo_record_words(const ss_stwo_cfg *c)

@@ -12,6 +12,6 @@ int set_err(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3))
 
 bool cfg_ok(const ss_stwo_cfg *c);
 bool shape_ok(const ss_s101_shape *sh);
-StwoLayout lay_of(const ss_stwo_cfg *c, size_t n);
+StwoLayout lay_of(const ss_stwo_cfg *c, size_t n, bool minimal = false);  // minimal: the layout behind minimal records (ss_minimal.h)
 
 }  // namespace ss

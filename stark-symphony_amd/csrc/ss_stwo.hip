@@ -202,10 +202,10 @@ __device__ __forceinline__ void stwo_transcript_body(const StwoLayout &lay, cons
         // ---- stage V (first half): fri_generate_queries (fri/queries.simf:29-43)
         default:  // kQueries
 #pragma unroll
-            for (int j = 0; j < 8; j++)
-                if (fri_l + j < lay.Q) CW(lay.c_queries + fri_l + j, Hasher<HF>::native(st.v[j]) & qmask);
+            for (int j = 0; j < 8; j++)  // (Qd = Q except behind minimal records, whose expansion kernel pads the list)
+                if (fri_l + j < lay.Qd) CW(lay.c_queries + fri_l + j, Hasher<HF>::native(st.v[j]) & qmask);
             fri_l += 8;
-            if (fri_l >= lay.Q) phase = kEnd;
+            if (fri_l >= lay.Qd) phase = kEnd;
             break;
         }
     }
@@ -432,9 +432,20 @@ stwo_query_kernel(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *
     uint32_t *leaf = ws + lay.ws_leaf;
     const uint32_t *wit = batch + lay.off_fri_wit;
     uint32_t cur = query;
+    // minimal records (ss_minimal.h): the other member of a fold pair is not in the proof when another query of the
+    // proof sits there -- it is that chain's value entering this layer, one lane away (a proof's chains are lanes of this
+    // wavefront: lay.Q divides 64, every lane of a live proof is live)
+    const uint8_t *sibs = reinterpret_cast<const uint8_t *>(ws + lay.ws_sib) + (size_t)inst * 32;
     for (uint32_t l = 0; l <= K; l++) {
         QM31 w = {wit[((size_t)l * 4 + 0) * nip + inst], wit[((size_t)l * 4 + 1) * nip + inst],
                   wit[((size_t)l * 4 + 2) * nip + inst], wit[((size_t)l * 4 + 3) * nip + inst]};
+        if (lay.minimal) {
+            const uint32_t sb = sibs[l];
+            const int src = (int)(lane - q + (sb == 0xff ? q : sb));
+            const QM31 o = {(uint32_t)__shfl((int)eval.a, src), (uint32_t)__shfl((int)eval.b, src),
+                            (uint32_t)__shfl((int)eval.c, src), (uint32_t)__shfl((int)eval.d, src)};
+            if (sb != 0xff) w = o;
+        }
         const bool odd = cur & 1;  // adjacent_leaves (fri/layers.simf:29-37)
         const uint32_t position = cur & ~1u;
         QM31 e0 = odd ? w : eval, e1 = odd ? eval : w;
@@ -464,7 +475,9 @@ stwo_query_kernel(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *
 // ============================================================================== merkle
 // One wavefront = 64 chains of one kind.  Tile order: trace, cp, FRI layer 0..K (longest
 // chains first, so the tail of the grid is made of the shortest ones).
-template <int HF>
+// MIN: the batch was filled from minimal records (ss_minimal.hip) -- its own instantiation, so that the per-query
+// kernels are the code they were.
+template <int HF, bool MIN = false>
 __device__ __forceinline__ void stwo_merkle_body(const StwoLayout &lay, const uint32_t *__restrict__ batch,
                                                  uint32_t *__restrict__ ws, uint32_t *__restrict__ status)
 {
@@ -521,6 +534,8 @@ __device__ __forceinline__ void stwo_merkle_body(const StwoLayout &lay, const ui
     const uint32_t n_lvl = len - top;
     // (the tiles hold only the n_lvl levels hashed here; the top ones live in the `top` section)
     const uint4 *tp = reinterpret_cast<const uint4 *>(path) + ((size_t)g * n_lvl * 2) * 64 + lane;
+    const uint8_t *sibs = reinterpret_cast<const uint8_t *>(ws + lay.ws_sib) + (size_t)inst * 32;  // (minimal records only)
+    const uint32_t min_shift = type < 2 ? 0 : type - 1;  // absolute level of the tree's first sibling (ss_minimal.h)
     uint4 s0 = make_uint4(0, 0, 0, 0), s1 = s0;
     if (n_lvl) { s0 = tp[0]; s1 = tp[64]; }
     for (uint32_t lvl = 0; lvl < n_lvl; lvl++) {
@@ -529,9 +544,22 @@ __device__ __forceinline__ void stwo_merkle_body(const StwoLayout &lay, const ui
             n0 = tp[(size_t)(lvl + 1) * 128];
             n1 = tp[(size_t)(lvl + 1) * 128 + 64];
         }
-        const uint32_t sib[8] = {Hasher<HF>::native(s0.x), Hasher<HF>::native(s0.y), Hasher<HF>::native(s0.z),
-                                 Hasher<HF>::native(s0.w), Hasher<HF>::native(s1.x), Hasher<HF>::native(s1.y),
-                                 Hasher<HF>::native(s1.z), Hasher<HF>::native(s1.w)};
+        uint32_t sib[8] = {Hasher<HF>::native(s0.x), Hasher<HF>::native(s0.y), Hasher<HF>::native(s0.z),
+                           Hasher<HF>::native(s0.w), Hasher<HF>::native(s1.x), Hasher<HF>::native(s1.y),
+                           Hasher<HF>::native(s1.z), Hasher<HF>::native(s1.w)};
+        if (MIN) {
+            // minimal records: a sibling that another query of the proof computes is not in the proof; that chain is a
+            // lane of this wavefront and at the same level (same tree, lockstep), so its node is the sibling
+            const uint32_t sb = live ? sibs[min_shift + lvl] : 0xffu;
+            if (__any(sb != 0xff)) {
+                const int src = (int)(lane - q + (sb == 0xff ? q : sb));
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t o = (uint32_t)__shfl((int)node[j], src);
+                    if (sb != 0xff) sib[j] = o;
+                }
+            }
+        }
         const bool right = auth & 1;  // node is the right child: H(sibling || node)
         uint32_t lft[8], rgt[8];
 #pragma unroll
@@ -554,7 +582,7 @@ __device__ __forceinline__ void stwo_merkle_body(const StwoLayout &lay, const ui
         uint4 *out = reinterpret_cast<uint4 *>(ws + lay.ws_top) + ((size_t)type * nip + inst) * 2;
         out[0] = make_uint4(node[0], node[1], node[2], node[3]);
         out[1] = make_uint4(node[4], node[5], node[6], node[7]);
-        if (lay.mchk) {
+        if (lay.mchk && !MIN) {  // (minimal records hold every sibling once: nothing to compare)
             // The byte compares of the pair memoisation (stwo_top_kernel: "same", "edge", "cross at the edge"), lane
             // against lane: 64 % Q == 0, so the Q chains of this tree of proof p are lanes lane - q .. lane - q + Q - 1
             // of this wavefront, all live (dead lanes pad whole proofs).  Every sibling of the top levels is read once,
@@ -655,7 +683,7 @@ __device__ __forceinline__ void stwo_merkle_body(const StwoLayout &lay, const ui
 #endif
 constexpr uint32_t kTopLights = SS_TOP_LIGHTS;  // light checks that ride along one pair hash
 
-template <int HF, bool LIGHTS>
+template <int HF, bool LIGHTS, bool MIN = false>
 __device__ __forceinline__ void stwo_top_body(const StwoLayout &lay, const uint32_t *__restrict__ batch,
                                               uint32_t *__restrict__ ws, uint32_t *__restrict__ status)
 {
@@ -930,6 +958,13 @@ __device__ __forceinline__ void stwo_top_body(const StwoLayout &lay, const uint3
                 nd_ = node_at(ti_, c, d + 1);
                 sb_ = sibling(ti_, c, len - 1 - d);
                 fl_ = (s_query[c] >> (L - d - 1)) & 1;
+                if (MIN) {
+                    // minimal records: the sibling is the node another query's leader has just produced wherever there is
+                    // one (c leads its depth-(d+1) node too: it is the lowest chain below the node it leads here)
+                    const uint32_t o = s_sibl[d + 1][s_slot[d + 1][c]];
+                    if (o != kNone) sb_ = node_at(ti_, o, d + 1);
+                    return;  // ... and no proof bytes exist that the produced node could be compared with
+                }
                 const uint32_t y = d ? s_sibl[d][k_] : kNone;
                 if (y != kNone) { ys_ = sibling(ti_, y, len - d); fl_ |= 2; }
             };
@@ -1055,6 +1090,18 @@ stwo_merkle_kernel_b2s(StwoLayout lay, const uint32_t *__restrict__ batch, uint3
 {
     stwo_merkle_body<1>(lay, batch, ws, status);
 }
+__global__ void __launch_bounds__(256)
+stwo_merkle_min_kernel_sha(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,
+                           uint32_t *__restrict__ status)
+{
+    stwo_merkle_body<0, true>(lay, batch, ws, status);
+}
+__global__ void __launch_bounds__(256)
+stwo_merkle_min_kernel_b2s(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,
+                           uint32_t *__restrict__ status)
+{
+    stwo_merkle_body<1, true>(lay, batch, ws, status);
+}
 __global__ void __launch_bounds__(kTopChains, SS_TOP_WAVES)
 stwo_top_kernel_sha(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,
                     uint32_t *__restrict__ status)
@@ -1079,6 +1126,20 @@ stwo_top_hash_kernel_b2s(StwoLayout lay, const uint32_t *__restrict__ batch, uin
                          uint32_t *__restrict__ status)
 {
     stwo_top_body<1, false>(lay, batch, ws, status);
+}
+
+// ... and behind minimal records: a sibling is the stored node of its position's leader wherever one exists
+__global__ void __launch_bounds__(kTopChains, SS_TOP_HASH_WAVES)
+stwo_top_min_kernel_sha(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,
+                        uint32_t *__restrict__ status)
+{
+    stwo_top_body<0, false, true>(lay, batch, ws, status);
+}
+__global__ void __launch_bounds__(kTopChains, SS_TOP_HASH_WAVES)
+stwo_top_min_kernel_b2s(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,
+                        uint32_t *__restrict__ status)
+{
+    stwo_top_body<1, false, true>(lay, batch, ws, status);
 }
 
 __global__ void __launch_bounds__(256)

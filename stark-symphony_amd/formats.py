@@ -536,6 +536,200 @@ def _expand_shared(data: dict, lde_log: int, Q: int) -> dict:
     return out
 
 
+# ------------------------------------------------------------------ minimal decommitment
+def minimal_order(lde_log: int, queries: Sequence[int]):
+    """The structure of upstream stwo's one-decommitment-per-tree form ("sorted multi-proof Merkle
+    (real stwo format)"; the reference keeps one full path per query instead, stwo-verifier/src/fri/queries.simf:41,
+    scripts/generate_wit.py:36-42, merkle.simf:22-44).  With Nodes(a) = the distinct positions `query >> a` of the
+    queries at absolute level a (0 = the leaves of the LDE-sized trees), ascending, and Lone(a) = the nodes of
+    Nodes(a) whose sibling `x ^ 1` is NOT in Nodes(a):
+      * a tree's queried values are listed once per node of Nodes(0);
+      * its hash witness holds, level by level from the leaves, the siblings of Lone(a) -- every other sibling is a
+        node the verifier computes itself (stwo MerkleVerifier::verify reads a child from the witness only when the
+        layer below did not produce it, left before right);
+      * FRI layer l lives at levels >= l: its fold pairs are Nodes(l + 1), the evaluations of a pair's member that is
+        not queried -- the partners of Lone(l) -- are its fri_witness (stwo FriLayerVerifier::extract_evaluation), and
+        its tree's witness starts above the pairs: Lone(l + 1), Lone(l + 2), ...
+    -> (nodes, lone): two lists indexed by level 0..lde_log - 1.  Definition by sets; the closed form the library uses
+    (csrc/ss_minimal.h) and the oracle's sorted walk are compared with it in tests/test_minimal.py."""
+    nodes, lone = [], []
+    for a in range(lde_log):
+        ns = sorted({int(q) >> a for q in queries})
+        present = set(ns)
+        nodes.append(ns)
+        lone.append([x for x in ns if (x ^ 1) not in present])
+    return nodes, lone
+
+
+@dataclass
+class StwoMinimalProof:
+    """An stwo proof with one decommitment per tree (minimal_order): what upstream stwo's prover emits before the
+    reference's adapter-side convention of one path per query.  Parity unpinned (no bytes of it in the reference)."""
+    cfg: StwoConfig
+    roots: np.ndarray            # uint8[3, 32]
+    oods_trace: np.ndarray       # uint32[n_cols, 4]
+    oods_cp: np.ndarray          # uint32[16, 4]
+    fri_roots: np.ndarray        # uint8[K+1, 32]
+    last_layer: np.ndarray       # uint32[4]
+    pow_nonce: int
+    trace_vals: np.ndarray       # uint32[distinct positions, n_cols], ascending position
+    cp_vals: np.ndarray          # uint32[distinct positions, 16]
+    fri_witness: List[np.ndarray]   # (K+1) x uint32[n_l, 4]
+    hash_witness: List[np.ndarray]  # (K+3) x uint8[n_t, 32]: trace, composition, FRI layer 0..K
+
+    def copy(self) -> "StwoMinimalProof":
+        return StwoMinimalProof(self.cfg, self.roots.copy(), self.oods_trace.copy(), self.oods_cp.copy(),
+                                self.fri_roots.copy(), self.last_layer.copy(), self.pow_nonce, self.trace_vals.copy(),
+                                self.cp_vals.copy(), [w.copy() for w in self.fri_witness],
+                                [h.copy() for h in self.hash_witness])
+
+
+def stwo_minimise(p: "StwoProof", queries: "Sequence[int] | None" = None) -> StwoMinimalProof:
+    """Per-query proof -> minimal proof: a selection, no hashing (a prover holds every node anyway; this is what it
+    would not send).  `queries`: the positions the prover drew, else the public transcript is replayed.  Only proofs
+    whose paths all have the config's lengths and whose queries agree wherever they present the same thing have a
+    minimal form (MalformedProof otherwise).  Siblings that the verifier recomputes are dropped WITHOUT being
+    checked -- checking them is verifying."""
+    c = p.cfg
+    L, Q, K = c.lde_log, c.n_queries, c.n_layers
+    qs = [int(x) for x in (queries if queries is not None else stwo_queries(p))]
+    if len(qs) != Q or any(q >> L for q in qs):
+        raise MalformedProof("one position inside the LDE domain per query expected")
+    nodes, lone = minimal_order(L, qs)
+
+    def pick(items, what):  # the chains at one node must present the same thing
+        first = items[0]
+        for x in items[1:]:
+            if not np.array_equal(first, x):
+                raise MalformedProof("two queries present different %s for one position: no minimal form" % what)
+        return first
+
+    def at(a, x):
+        return [q for q in range(Q) if (qs[q] >> a) == x]
+    tv = np.array([pick([p.trace_vals[q] for q in at(0, x)], "values") for x in nodes[0]], dtype=np.uint32).reshape(-1, c.n_cols)
+    cv = np.array([pick([p.cp_vals[q] for q in at(0, x)], "values") for x in nodes[0]], dtype=np.uint32).reshape(-1, 16)
+
+    def tree(paths, shift):
+        ln = L - shift
+        if any(len(pth) != ln for pth in paths):
+            raise MalformedProof("only full-length Merkle paths have a minimal form")
+        out = [pick([paths[q][a - shift] for q in at(a, x)], "siblings") for a in range(shift, L) for x in lone[a]]
+        return np.array(out, dtype=np.uint8).reshape(-1, 32)
+    hw = [tree(p.trace_paths, 0), tree(p.cp_paths, 0)]
+    fw = []
+    for l in range(K + 1):
+        fw.append(np.array([pick([p.fri_witness[l, q] for q in at(l, x)], "evaluations") for x in lone[l]],
+                           dtype=np.uint32).reshape(-1, 4))
+        hw.append(tree(p.fri_paths[l], l + 1))
+    return StwoMinimalProof(c, p.roots.copy(), p.oods_trace.copy(), p.oods_cp.copy(), p.fri_roots.copy(),
+                            p.last_layer.copy(), p.pow_nonce, tv, cv, fw, hw)
+
+
+def stwo_minimal_to_json(m: StwoMinimalProof) -> dict:
+    """The proof.json of a minimal proof: the schema of format C (stwo-verifier/scripts/generate_wit.py:106-245 reads
+    it) with the lists as upstream stwo fills them -- `queried_values` once per distinct position, `hash_witness` and
+    `fri_witness` without what the verifier computes.  Nothing in the text says which form it is: a reader tells by
+    the list lengths (stwo_from_json_any) or is told (SS_TEXT_JSON_MINIMAL)."""
+    def q(v: Sequence[int]) -> List[List[int]]:
+        return [[int(v[0]), int(v[1])], [int(v[2]), int(v[3])]]
+
+    def hw(a: np.ndarray) -> List[List[int]]:
+        return [[int(b) for b in node] for node in a]
+    c = m.cfg
+    conf = {"pow_bits": c.pow_bits,
+            "fri_config": {"log_blowup_factor": c.log_blowup, "log_last_layer_degree_bound": 0, "n_queries": c.n_queries}}
+    if c.hash != "sha256":
+        conf["hash"] = c.hash
+    layers = [{"fri_witness": [q(w) for w in m.fri_witness[l]],
+               "decommitment": {"hash_witness": hw(m.hash_witness[2 + l]), "column_witness": []},
+               "commitment": [int(b) for b in m.fri_roots[l]]} for l in range(c.n_layers + 1)]
+    return {
+        "config": conf,
+        "commitments": [[int(b) for b in r] for r in m.roots],
+        "sampled_values": [[], [[q(v)] for v in m.oods_trace], [[q(v)] for v in m.oods_cp]],
+        "decommitments": [{"hash_witness": [], "column_witness": []},
+                          {"hash_witness": hw(m.hash_witness[0]), "column_witness": []},
+                          {"hash_witness": hw(m.hash_witness[1]), "column_witness": []}],
+        "queried_values": [[], [int(x) for x in m.trace_vals.reshape(-1)], [int(x) for x in m.cp_vals.reshape(-1)]],
+        "proof_of_work": int(m.pow_nonce),
+        "fri_proof": {"first_layer": layers[0], "inner_layers": layers[1:],
+                      "last_layer_poly": {"coeffs": [q(m.last_layer)], "log_size": 0}},
+    }
+
+
+def stwo_minimal_from_json(data: Any, expect: StwoConfig) -> StwoMinimalProof:
+    """Reads a minimal proof.json against the config the caller expects (a minimal text has no path whose length
+    would give the LDE size away, so there is no reading it without one).  The returned cfg is what the text DECLARES
+    where it declares (pow_bits, blow-up, n_queries, hash, the column and layer counts); list lengths are data."""
+    if isinstance(data, (str, bytes)):
+        data = json.loads(data)
+    try:
+        conf = data.get("config", {})
+        fri_conf = conf.get("fri_config", {})
+        Q = _uint(fri_conf["n_queries"], 32) if "n_queries" in fri_conf else expect.n_queries
+        pow_bits = _uint(conf["pow_bits"], 32) if "pow_bits" in conf else expect.pow_bits
+        blow = _uint(fri_conf["log_blowup_factor"], 32) if "log_blowup_factor" in fri_conf else expect.log_blowup
+        if "hash" in conf and (not isinstance(conf["hash"], str) or conf["hash"] not in ("sha256", "blake2s")):
+            raise MalformedProof("unknown hash %r" % (conf["hash"],))
+        hname = conf.get("hash") or expect.hash
+        roots = np.stack([np.frombuffer(bytes(c), dtype=np.uint8) for c in data["commitments"]])
+        if roots.shape != (3, 32):
+            raise MalformedProof("expected three 32-byte commitments")
+        sv = data["sampled_values"]
+        oods_trace = np.array([_qm31(c) for c in sv[1]], dtype=np.uint32).reshape(-1, 4)
+        oods_cp = np.array([_qm31(c) for c in sv[2]], dtype=np.uint32).reshape(-1, 4)
+        if oods_cp.shape[0] != N_CP_PARTITIONS:
+            raise MalformedProof("expected 16 composition-polynomial partitions")
+        N = oods_trace.shape[0]
+        qv, dec = data["queried_values"], data["decommitments"]
+        if N == 0 or len(qv[1]) % N or len(qv[2]) % N_CP_PARTITIONS:
+            raise MalformedProof("queried values are listed column-count at a time")
+        tv = np.array([_u32(x) for x in qv[1]], dtype=np.uint32).reshape(-1, N)
+        cv = np.array([_u32(x) for x in qv[2]], dtype=np.uint32).reshape(-1, N_CP_PARTITIONS)
+
+        def hashes(lst) -> np.ndarray:
+            out = np.zeros((len(lst), 32), dtype=np.uint8)
+            for i, n in enumerate(lst):
+                b = bytes(n)
+                if len(b) != 32:
+                    raise MalformedProof("expected 32 bytes")
+                out[i] = np.frombuffer(b, dtype=np.uint8)
+            return out
+        fri = data["fri_proof"]
+        layers = [fri["first_layer"]] + list(fri.get("inner_layers", []))
+        K = len(layers) - 1
+        if K > MAX_LIST:
+            raise MalformedProof("too many FRI layers")
+        hw = [hashes(dec[1]["hash_witness"]), hashes(dec[2]["hash_witness"])]
+        fw = []
+        for l in layers:
+            fw.append(np.array([_qm31(x) for x in l["fri_witness"]], dtype=np.uint32).reshape(-1, 4))
+            hw.append(hashes(l["decommitment"]["hash_witness"]))
+        fri_roots = np.stack([np.frombuffer(bytes(l["commitment"]), dtype=np.uint8) for l in layers])
+        coeffs = fri["last_layer_poly"]["coeffs"]
+        if len(coeffs) != 1:
+            raise MalformedProof("expected a degree-0 last layer")
+        cfg = StwoConfig(N, expect.lde_log - blow, expect.lde_log, Q, K, pow_bits, hname)
+        return StwoMinimalProof(cfg, roots.copy(), oods_trace, oods_cp, fri_roots.copy(),
+                                np.array(_qm31(coeffs[0]), dtype=np.uint32), _uint(data.get("proof_of_work", 0), 64),
+                                tv, cv, fw, hw)
+    except (KeyError, IndexError, TypeError, AttributeError, ValueError) as e:
+        if isinstance(e, MalformedProof):
+            raise
+        raise MalformedProof(str(e)) from e
+
+
+def stwo_json_is_minimal(data: dict, expect: StwoConfig) -> bool:
+    """Which of the two forms a proof.json of the expected config is: per-query lists hold n_queries equal shares --
+    n_queries x n_cols queried values and n_queries x lde_log trace siblings -- and a minimal text with two or more
+    queries always has fewer siblings (the paths meet below the root); with ONE query the two forms are the same bytes."""
+    try:
+        return not (len(data["queried_values"][1]) == expect.n_queries * expect.n_cols
+                    and len(data["decommitments"][1]["hash_witness"]) == expect.n_queries * expect.lde_log)
+    except (KeyError, IndexError, TypeError) as e:
+        raise MalformedProof(str(e)) from e
+
+
 def stwo_queries(p: "StwoProof") -> List[int]:
     """The query positions of a proof: the public part of the Fiat-Shamir transcript replayed with hashlib
     (stwo-verifier/src/channel.simf:31-172 in the order of verifier.simf:32-58).  No check of the proof is made;

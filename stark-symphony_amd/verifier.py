@@ -275,6 +275,89 @@ def stwo_shared_counts(cfg: StwoConfig, queries: Sequence[int], mode: int = MODE
     return out
 
 
+def stwo_minimal_record(m) -> np.ndarray:
+    """StwoMinimalProof -> minimal record (include/ss_verify.h: head, the list lengths, then the lists)."""
+    c = m.cfg
+    K = c.n_layers
+    if len(m.fri_witness) != K + 1 or len(m.hash_witness) != K + 3:
+        raise ValueError("a minimal proof has one fri_witness list per layer and one hash_witness list per tree")
+    parts: List[np.ndarray] = [
+        _hash_words(m.roots.tobytes()), m.oods_trace.astype(np.uint32).reshape(-1),
+        m.oods_cp.astype(np.uint32).reshape(-1), _hash_words(m.fri_roots.tobytes()),
+        m.last_layer.astype(np.uint32).reshape(-1),
+        np.array([m.pow_nonce >> 32, m.pow_nonce & 0xFFFFFFFF], dtype=np.uint32),
+        np.array([len(m.trace_vals), len(m.cp_vals)] + [len(w) for w in m.fri_witness] + [len(h) for h in m.hash_witness],
+                 dtype=np.uint32),
+        np.asarray(m.trace_vals, dtype=np.uint32).reshape(-1), np.asarray(m.cp_vals, dtype=np.uint32).reshape(-1)]
+    parts += [np.asarray(w, dtype=np.uint32).reshape(-1) for w in m.fri_witness]
+    parts += [_hash_words(np.ascontiguousarray(h, dtype=np.uint8).tobytes()) for h in m.hash_witness]
+    return np.ascontiguousarray(np.concatenate(parts), dtype=np.uint32)
+
+
+def stwo_minimal_from_record(cfg: StwoConfig, rec: np.ndarray):
+    """Inverse of stwo_minimal_record (ValueError when the size is not what the record's own counts give)."""
+    from .formats import StwoMinimalProof
+    N, K = cfg.n_cols, cfg.n_layers
+    rec = np.ascontiguousarray(rec, dtype=np.uint32)
+    head = 24 + 4 * N + 64 + 8 * (K + 1) + 6
+    if rec.size < head + 2 + (K + 1) + (K + 3):
+        raise ValueError("shorter than the fixed words of a minimal record")
+    pos = 0
+
+    def take(n: int) -> np.ndarray:
+        nonlocal pos
+        if pos + n > rec.size:
+            raise ValueError("the record ends inside a list")
+        out = rec[pos:pos + n]
+        pos += n
+        return out
+
+    def hashes(words: np.ndarray) -> np.ndarray:
+        return words.astype(">u4").view(np.uint8).reshape(-1, 32).copy()
+    roots = hashes(take(24))
+    oods_trace = take(4 * N).reshape(N, 4).copy()
+    oods_cp = take(64).reshape(16, 4).copy()
+    fri_roots = hashes(take(8 * (K + 1)))
+    last = take(4).copy()
+    hi, lo = take(2)
+    nv = [int(x) for x in take(2)]
+    nfw = [int(x) for x in take(K + 1)]
+    nhw = [int(x) for x in take(K + 3)]
+    tv = take(nv[0] * N).reshape(-1, N).copy()
+    cv = take(nv[1] * 16).reshape(-1, 16).copy()
+    fw = [take(4 * n).reshape(-1, 4).copy() for n in nfw]
+    hw = [hashes(take(8 * n)) for n in nhw]
+    if pos != rec.size:
+        raise ValueError("the record is longer than its lists")
+    return StwoMinimalProof(cfg, roots, oods_trace, oods_cp, fri_roots, last, (int(hi) << 32) | int(lo), tv, cv, fw, hw)
+
+
+def stwo_minimise_record(cfg: StwoConfig, record: np.ndarray, queries: Sequence[int], mode: int = MODE_FIXTURE) -> np.ndarray:
+    """Per-query record + the positions its prover drew -> MINIMAL record (ss_stwo_minimise_record: a selection, no
+    hashing).  ValueError for a proof that has no minimal form."""
+    cs = stwo_cfg_struct(cfg, mode)
+    L = B.lib()
+    rec = np.ascontiguousarray(record, dtype=np.uint32)
+    qs = np.ascontiguousarray(queries, dtype=np.uint32)
+    if qs.size != cfg.n_queries or rec.size != L.ss_stwo_record_words(C.byref(cs)):
+        raise ValueError("a record of the config and one position per query expected")
+    out = np.zeros(L.ss_stwo_minimal_max_words(C.byref(cs)), dtype=np.uint32)
+    words = C.c_size_t(0)
+    rc = B.check(L.ss_stwo_minimise_record(C.byref(cs), rec.ctypes.data, qs.ctypes.data, out.ctypes.data, out.size, C.byref(words)))
+    if rc:
+        raise ValueError("this proof has no minimal form")
+    return out[:words.value].copy()
+
+
+def stwo_minimal_counts(cfg: StwoConfig, queries: Sequence[int], mode: int = MODE_FIXTURE) -> np.ndarray:
+    """List lengths of a minimal record for these positions: [n_vals x 2, n_fw per layer, n_hw per tree]."""
+    cs = stwo_cfg_struct(cfg, mode)
+    qs = np.ascontiguousarray(queries, dtype=np.uint32)
+    out = np.zeros(2 + (cfg.n_layers + 1) + (cfg.n_layers + 3), dtype=np.uint32)
+    B.check(B.lib().ss_stwo_minimal_counts(C.byref(cs), qs.ctypes.data, out.ctypes.data))
+    return out
+
+
 STATUS_CONFIG_MISMATCH = 1
 """Status of a proof whose shape / declared parameters are not the config the caller expects.  The
 reference fixes NUM_COLUMNS, LDE_LOG_SIZE, NUM_FRI_QUERIES, NUM_FRI_LAYERS and POW_TARGET_64 at
@@ -527,6 +610,44 @@ class StwoDeviceBatch(_DeviceBatch):
         return out
 
 
+class StwoMinimalDeviceBatch(_DeviceBatch):
+    """Minimal records resident in HBM (back to back + their offset table) with the scratch batch / workspace the
+    verification fills: ss_stwo_verify_minimal_dev.  `index`: proof i is records[index[i]] (replicated on the device)."""
+
+    def __init__(self, ver: "Verifier", cfg: StwoConfig, mode: int, records: Sequence[np.ndarray],
+                 index: Optional[Sequence[int]] = None):
+        torch = _torch()
+        L = B.lib()
+        self.cfg, self.mode = cfg, mode
+        self.cs = stwo_cfg_struct(cfg, mode, ver.stwo_flags)
+        order = list(range(len(records))) if index is None else [int(i) for i in index]
+        n = len(order)
+        sizes = np.array([records[i].size for i in order], dtype=np.uint64)
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum(sizes)
+        distinct = _to_dev(np.concatenate([np.ascontiguousarray(r, dtype=np.uint32) for r in records]), ver.device)
+        starts = np.zeros(len(records) + 1, dtype=np.int64)
+        starts[1:] = np.cumsum([r.size for r in records])
+        if index is None:
+            flat = distinct
+        else:  # gather on the device: element j of proof i comes from starts[order[i]] + j
+            src0 = torch.as_tensor(starts[:-1][order], device=ver.device)
+            rep = torch.as_tensor(sizes.astype(np.int64), device=ver.device)
+            base = torch.repeat_interleave(src0 - torch.as_tensor(offs[:-1].astype(np.int64), device=ver.device), rep)
+            flat = distinct[base + torch.arange(int(offs[-1]), device=ver.device)]
+        self.records = flat
+        self.offs = torch.from_numpy(offs.view(np.int64)).to(ver.device)
+        self.record_bytes = int(offs[-1]) * 4
+        packed = torch.empty(L.ss_stwo_minimal_batch_words(C.byref(self.cs), n), dtype=torch.int32, device=ver.device)
+        super().__init__(ver, n, packed, L.ss_stwo_minimal_workspace_bytes(C.byref(self.cs), n))
+
+    def run(self, stream=None, phases: int = PHASE_ALL) -> None:
+        B.check(B.lib().ss_stwo_verify_minimal_dev(
+            self.ver.ctx, C.byref(self.cs), self.n, self.records.data_ptr(), self.offs.data_ptr(), self.batch.data_ptr(),
+            self.ws.data_ptr(), self.ws.numel() * 4, self.status_dev.data_ptr(), self.accept_dev.data_ptr(), phases,
+            self._stream(stream)))
+
+
 class S101DeviceBatch(_DeviceBatch):
     def __init__(self, ver: "Verifier", max_layers: int, max_path: int, records: Sequence[np.ndarray]):
         L = B.lib()
@@ -673,6 +794,39 @@ class Verifier:
         status = np.full(n, 0xFFFFFFFF, dtype=np.uint32)  # unwritten = REJECT
         B.check(B.lib().ss_stwo_verify_shared_records(self.ctx, C.byref(cs), n, ptrs, words, status.ctypes.data))
         return status
+
+    def verify_stwo_minimal_records(self, cfg: StwoConfig, minimal: Sequence[np.ndarray], mode: int = MODE_FIXTURE) -> np.ndarray:
+        """Host-buffer path for MINIMAL records (ss_stwo_verify_minimal_records): one sorted, deduplicated decommitment
+        per tree, verified without an expansion pass (csrc/ss_minimal.hip).  A record that is no minimal record of
+        `cfg` gets STATUS_MALFORMED."""
+        cs = stwo_cfg_struct(cfg, mode, self.stwo_flags)
+        if B.lib().ss_stwo_record_words(C.byref(cs)) == 0:
+            raise B.SsError(B.SS_ERR_ARG, "unsupported stwo config %r" % (cfg,))
+        for r in minimal:
+            if r.dtype != np.uint32 or r.ndim != 1 or not r.flags["C_CONTIGUOUS"]:
+                raise ValueError("a minimal record is a contiguous 1-d uint32 array")
+        n = len(minimal)
+        if n == 0:
+            return np.empty(0, dtype=np.uint32)
+        status = np.full(n, 0xFFFFFFFF, dtype=np.uint32)  # unwritten = REJECT
+        words = (C.c_size_t * n)(*[int(r.size) for r in minimal])
+        B.check(B.lib().ss_stwo_verify_minimal_records(self.ctx, C.byref(cs), n, _ptr_array(minimal), words, status.ctypes.data))
+        return status
+
+    def verify_stwo_minimal(self, proofs, mode: int = MODE_FIXTURE, *, cfg: StwoConfig) -> np.ndarray:
+        """Status word per StwoMinimalProof against the config the caller expects (others: STATUS_CONFIG_MISMATCH)."""
+        out = np.full(len(proofs), 0xFFFFFFFF, dtype=np.uint32)
+        idx = [i for i, p in enumerate(proofs) if p.cfg == cfg]
+        for i, p in enumerate(proofs):
+            if p.cfg != cfg:
+                out[i] = STATUS_CONFIG_MISMATCH
+        if idx:
+            out[idx] = self.verify_stwo_minimal_records(cfg, [stwo_minimal_record(proofs[i]) for i in idx], mode)
+        return out
+
+    def stwo_minimal_batch(self, cfg: StwoConfig, records: Sequence[np.ndarray], mode: int = MODE_FIXTURE,
+                           index: Optional[Sequence[int]] = None) -> StwoMinimalDeviceBatch:
+        return StwoMinimalDeviceBatch(self, cfg, mode, records, index)
 
     def expand_shared_on_device(self, cfg: StwoConfig, shared: Sequence[np.ndarray], mode: int = MODE_FIXTURE):
         """The expansion kernel alone (ss_stwo_expand_shared_dev): -> (records uint32[n, W], outcome uint32[n])."""

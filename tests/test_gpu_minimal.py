@@ -1,0 +1,147 @@
+"""Minimal records on the GPU (csrc/ss_minimal.hip; SURVEY.md 8f row 4 "sorted multi-proof Merkle (real stwo format)"):
+status(minimal record) == status(the per-query record R(M) it corresponds to) == the oracle's walk -- on the committed
+fixtures, on seeded corruptions incl. lists that are too short / too long, on query counts that do not divide 64 and on
+duplicate / neighbouring queries, in both modes, with the pair memoisation on and off.  Anchors:
+stwo-verifier/src/fri/queries.simf:41, scripts/generate_wit.py:36-42, merkle.simf:22-44.  Parity unpinned (no bytes of the
+form in the reference): the GPU is held to the oracle's restatement of upstream stwo's walk AND to the per-query path."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import stark_symphony_amd as ss  # noqa: E402
+from stark_symphony_amd import formats, records, verifier  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+from test_minimal import corrupt_minimal, fixtures, per_query_status  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ver():
+    return verifier.Verifier(0)
+
+
+def minimal_of(p):
+    return verifier.stwo_minimise_record(p.cfg, verifier.stwo_record(p), formats.stwo_queries(p))
+
+
+def check(ver, cfg, recs, mode):
+    """GPU(minimal) == oracle walk == GPU(per-query R(M)) == oracle(per-query R(M)) for every record of `recs`."""
+    got = ver.verify_stwo_minimal_records(cfg, recs, mode)
+    want = np.array([O.stwo_verify_minimal(cfg, r, mode) for r in recs], dtype=np.uint32)
+    assert got.tolist() == want.tolist(), [(i, hex(int(g)), hex(int(w))) for i, (g, w) in enumerate(zip(got, want)) if g != w][:8]
+    full, idx = [], []
+    for i, r in enumerate(recs):
+        st, back = O.stwo_minimal_expand(cfg, r, mode)
+        assert st == want[i]
+        if st != 2:
+            full.append(back)
+            idx.append(i)
+            assert per_query_status(cfg, back, mode) == st
+    if full:
+        std = ver.verify_stwo_records(cfg, np.stack(full), mode)
+        assert std.tolist() == want[idx].tolist()
+    return want
+
+
+@pytest.mark.parametrize("i", range(6))
+def test_fixtures_accept_and_corruptions_match(ver, i):
+    """The six committed fixtures: accepted as minimal records in FIXTURE mode, the per-query status in LITERAL mode;
+    40 corruptions each (bit flips, lists one element short / long, truncated, extended), both modes."""
+    p = fixtures()[i]
+    cfg = p.cfg
+    m = minimal_of(p)
+    rng = np.random.default_rng(0x5EED2025 + 80 + i)
+    muts = [corrupt_minimal(m, cfg, rng)[0] for _ in range(40)]
+    for mode in (verifier.MODE_FIXTURE, verifier.MODE_LITERAL):
+        want = check(ver, cfg, [m] + muts, mode)
+        assert int(want[0]) == O.stwo_verify(p, mode)
+        if mode == verifier.MODE_FIXTURE:
+            assert want[0] == 0 and (want[1:] != 0).sum() >= 30
+
+
+@pytest.mark.parametrize("flags", [verifier.FLAG_NO_DEDUP, verifier.FLAG_TOP_CHECKS])
+def test_flags_do_not_change_the_verdicts(flags, ver):
+    """SS_FLAG_NO_DEDUP: no top kernel, every omitted sibling comes from a lane of the merkle kernel.  SS_FLAG_TOP_CHECKS has
+    nothing to act on (a minimal record holds every sibling once)."""
+    v2 = verifier.Verifier(0)
+    v2.stwo_flags = flags
+    for i in (0, 2):
+        p = fixtures()[i]
+        m = minimal_of(p)
+        rng = np.random.default_rng(0x5EED2025 + 90 + i)
+        recs = [m] + [corrupt_minimal(m, p.cfg, rng)[0] for _ in range(24)]
+        a = v2.verify_stwo_minimal_records(p.cfg, recs, verifier.MODE_FIXTURE)
+        b = ver.verify_stwo_minimal_records(p.cfg, recs, verifier.MODE_FIXTURE)
+        assert a.tolist() == b.tolist() == [O.stwo_verify_minimal(p.cfg, r, verifier.MODE_FIXTURE) for r in recs]
+        assert a[0] == 0
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n_cols=4, trace_log=5, log_blowup=2, n_queries=3, pow_bits=5, seed=0, hash="sha256"),   # 3 queries: padded to 4
+    dict(n_cols=8, trace_log=4, log_blowup=1, n_queries=9, pow_bits=3, seed=7, hash="sha256"),   # 9 of 32 positions: siblings, duplicates
+    dict(n_cols=3, trace_log=2, log_blowup=1, n_queries=24, pow_bits=0, seed=2, hash="sha256"),  # 24 queries on 8 positions
+    dict(n_cols=3, trace_log=1, log_blowup=2, n_queries=64, pow_bits=1, seed=4, hash="sha256"),  # 64 queries on 8 positions
+    dict(n_cols=32, trace_log=6, log_blowup=3, n_queries=5, pow_bits=8, seed=1, hash="blake2s"),
+    dict(n_cols=5, trace_log=12, log_blowup=2, n_queries=11, pow_bits=10, seed=5, hash="blake2s"),
+    dict(n_cols=4, trace_log=10, log_blowup=3, n_queries=48, pow_bits=4, seed=9, hash="sha256"),
+])
+def test_any_query_count_duplicates_and_neighbours(ver, kw):
+    """Prover-made proofs of shapes whose queries collide: query counts that do not divide 64 (the kernels give a proof
+    the next power of two of chains, the extra ones repeating query 0), more queries than positions, sibling positions."""
+    from stark_symphony_amd import prover
+    p = ss.stwo_from_json(prover.GpuProver(ver).prove(**kw))
+    cfg = p.cfg
+    qs = formats.stwo_queries(p)
+    m = minimal_of(p)
+    assert np.array_equal(m, verifier.stwo_minimal_record(formats.stwo_minimise(p, qs)))
+    rng = np.random.default_rng(0x5EED2025 + 100 + kw["seed"])
+    recs = [m] + [corrupt_minimal(m, cfg, rng)[0] for _ in range(30)]
+    for mode in (verifier.MODE_FIXTURE, verifier.MODE_LITERAL):
+        want = check(ver, cfg, recs, mode)
+        if mode == verifier.MODE_FIXTURE:
+            assert want[0] == 0
+
+
+def test_batch_of_mixed_records_across_chunks(ver):
+    """2 500 minimal records of the reference's production shape in one call (several upload chunks): the accepted
+    fixture, corruptions, malformed ones; statuses in input order."""
+    p = fixtures()[0]
+    m = minimal_of(p)
+    rng = np.random.default_rng(0x5EED2025 + 120)
+    pool = [m] + [corrupt_minimal(m, p.cfg, rng)[0] for _ in range(48)]
+    want_pool = [O.stwo_verify_minimal(p.cfg, r, verifier.MODE_FIXTURE) for r in pool]
+    order = rng.integers(0, len(pool), size=2500)
+    got = ver.verify_stwo_minimal_records(p.cfg, [pool[i] for i in order], verifier.MODE_FIXTURE)
+    assert got.tolist() == [want_pool[i] for i in order]
+    assert (got == 0).sum() > 20 and (got == 2).sum() > 20
+
+
+def test_resident_minimal_batch_and_phases(ver):
+    """ss_stwo_verify_minimal_dev on records resident in HBM: HEAD and TAIL enqueued separately give the one-call result;
+    the minimal records are smaller than the per-query ones by the share the shapes predict."""
+    import torch
+    p = fixtures()[5]  # 2^20 shape
+    m = minimal_of(p)
+    full_words = verifier.stwo_record(p).size
+    assert 0.6 < m.size / full_words < 0.8
+    rng = np.random.default_rng(0x5EED2025 + 130)
+    recs = [m] + [corrupt_minimal(m, p.cfg, rng)[0] for _ in range(7)]
+    recs = [r for r in recs if O.stwo_verify_minimal(p.cfg, r, verifier.MODE_FIXTURE) != 2 or r.size >= 64]
+    idx = [int(i) for i in rng.integers(0, len(recs), size=512)]
+    b = ver.stwo_minimal_batch(p.cfg, recs, verifier.MODE_FIXTURE, index=idx)
+    b.run()
+    one = b.status()
+    b.run(phases=verifier.PHASE_HEAD)
+    b.run(phases=verifier.PHASE_TAIL)
+    torch.cuda.synchronize()
+    two = b.status()
+    want = [O.stwo_verify_minimal(p.cfg, r, verifier.MODE_FIXTURE) for r in recs]
+    assert one.tolist() == two.tolist() == [want[i] for i in idx]
+    assert b.accepted() == sum(1 for i in idx if want[i] == 0)

@@ -1,0 +1,199 @@
+"""Minimal records and the minimal proof.json ("sorted multi-proof Merkle (real stwo format)"; ABI 2.3):
+one sorted, deduplicated decommitment per tree, as upstream stwo's prover sends it, instead of the reference's one path
+per query (stwo-verifier/src/fri/queries.simf:41, scripts/generate_wit.py:36-42, merkle.simf:22-44).  PARITY UNPINNED:
+the reference holds no bytes of that form.  What is checked here, on the CPU:
+  * the ORDER -- three independent statements: formats.minimal_order (sets), the library's closed form
+    (csrc/ss_minimal.h via ss_stwo_minimal_counts / ss_stwo_minimise_record) and the oracle's sorted walk;
+  * the VERDICT -- the oracle's layer-by-layer walk (so_stwo_verify_minimal, a restatement of upstream's MerkleVerifier /
+    SparseEvaluation) against its definition: status(M) == so_stwo_verify(R(M)), R(M) = the per-query record in which
+    every omitted value is the computed one -- on the committed fixtures, on corruptions and on records whose lists have
+    the wrong lengths.
+The GPU path is held against the same two in tests/test_gpu_minimal.py."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import stark_symphony_amd as ss
+from stark_symphony_amd import formats, records, verifier
+from oracle import oracle as O
+
+from conftest import GOLDEN
+
+
+def fixtures():
+    out = [ss.stwo_from_json(json.load(open(os.path.join(GOLDEN, "stwo_proof.json")))),
+           ss.stwo_from_json(json.load(open(os.path.join(GOLDEN, "stwo_proof_test.json"))))]
+    for npz in ("stwo_trace16.npz", "stwo_wide256.npz", "stwo_trace16_blake2s.npz", "stwo_trace20.npz"):
+        out.append(records.load_stwo_npz(os.path.join(GOLDEN, npz))[0])
+    return out
+
+
+def random_queries(rng, L, Q, kind):
+    if kind == 0:    # uniform
+        return rng.integers(0, 1 << L, size=Q)
+    if kind == 1:    # clustered: many shared prefixes, duplicates, siblings
+        base = int(rng.integers(0, 1 << L))
+        return np.array([(base ^ int(rng.integers(0, 1 << int(rng.integers(0, min(L, 6) + 1))))) for _ in range(Q)])
+    if kind == 2:    # all equal
+        return np.full(Q, int(rng.integers(0, 1 << L)))
+    return np.array([(i * 2 + int(rng.integers(0, 2))) % (1 << L) for i in range(Q)])  # neighbours
+
+
+def expected_counts(L, K, qs):
+    nodes, lone = formats.minimal_order(L, qs)
+    n_hw = [sum(len(lone[a]) for a in range(sh, L)) for sh in [0, 0] + [l + 1 for l in range(K + 1)]]
+    return [len(nodes[0])] * 2 + [len(lone[l]) for l in range(K + 1)] + n_hw
+
+
+def test_counts_closed_form_equals_the_sets():
+    rng = np.random.default_rng(0x5EED2025 + 51)
+    for case in range(200):
+        L = int(rng.integers(2, 25))
+        K = int(rng.integers(0, L - 1))
+        Q = int(rng.choice([1, 2, 3, 7, 16, 24, 32, 64]))
+        cfg = ss.StwoConfig(4, max(1, L - 1), L, Q, K, 5)
+        qs = random_queries(rng, L, Q, case % 4).astype(np.uint32)
+        assert verifier.stwo_minimal_counts(cfg, qs).tolist() == expected_counts(L, K, [int(q) for q in qs]), case
+
+
+@pytest.mark.parametrize("i", range(6))
+def test_minimise_python_equals_library(i):
+    """formats.stwo_minimise (sets) and ss_stwo_minimise_record (closed form) select the same words; the record
+    converters round-trip; the minimal proof.json round-trips and is told from the per-query text by its lengths."""
+    p = fixtures()[i]
+    qs = formats.stwo_queries(p)
+    m = formats.stwo_minimise(p, qs)
+    rec_py = verifier.stwo_minimal_record(m)
+    rec_c = verifier.stwo_minimise_record(p.cfg, verifier.stwo_record(p), qs)
+    assert np.array_equal(rec_py, rec_c)
+    back = verifier.stwo_minimal_from_record(p.cfg, rec_c)
+    assert np.array_equal(verifier.stwo_minimal_record(back), rec_c)
+    if p.cfg.lde_log <= 16:  # (text of the big fixtures: seconds of json in pure Python, nothing new)
+        obj = formats.stwo_minimal_to_json(m)
+        text = json.dumps(obj)
+        m2 = formats.stwo_minimal_from_json(json.loads(text), p.cfg)
+        assert m2.cfg == p.cfg and np.array_equal(verifier.stwo_minimal_record(m2), rec_c)
+        assert formats.stwo_json_is_minimal(obj, p.cfg) == (p.cfg.n_queries > 1)
+        assert not formats.stwo_json_is_minimal(formats.stwo_to_json(p), p.cfg)
+    full = verifier.stwo_record(p).size
+    if p.cfg.n_queries > 1:
+        assert rec_c.size < full
+
+
+@pytest.mark.parametrize("i", range(6))
+def test_fixtures_verify_and_expand_to_themselves(i):
+    """An honest proof: the minimal record gets the per-query record's status in both modes (accepted in FIXTURE mode),
+    and in the mode the proof was made for R(M) is the per-query record itself -- every sibling and fold partner the
+    minimal form drops is the value the walk computes.  (LITERAL mode computes other fold values, fri/answers.simf:97-130,
+    so there R(M) differs from the prover's record in exactly the partners it recomputes; its status is still R(M)'s.)"""
+    p = fixtures()[i]
+    rec = verifier.stwo_record(p)
+    m = verifier.stwo_minimise_record(p.cfg, rec, formats.stwo_queries(p))
+    for mode in (O.MODE_FIXTURE, O.MODE_LITERAL):
+        want = O.stwo_verify(p, mode)
+        assert O.stwo_verify_minimal(p.cfg, m, mode) == want
+        st, back = O.stwo_minimal_expand(p.cfg, m, mode)
+        assert st == want == per_query_status(p.cfg, back, mode)
+        if mode == O.MODE_FIXTURE:
+            assert np.array_equal(back, rec)
+    assert O.stwo_verify_minimal(p.cfg, m, O.MODE_FIXTURE) == 0
+
+
+def corrupt_minimal(rec, cfg, rng):
+    """One seeded mutation of a minimal record -> (record, what): a bit flip somewhere (head, counts, lists), a list
+    made shorter / longer by one element with the size kept consistent, or the record truncated / extended."""
+    N, K = cfg.n_cols, cfg.n_layers
+    head = 24 + 4 * N + 64 + 8 * (K + 1) + 6
+    n_counts = 2 + (K + 1) + (K + 3)
+    r = rec.copy()
+    kind = int(rng.integers(0, 10))
+    if kind <= 5:
+        i = int(rng.integers(0, r.size))
+        if head <= i < head + n_counts and kind > 2:  # (count words are hit by the structural mutations below)
+            i = int(rng.integers(head + n_counts, r.size))
+        r[i] ^= np.uint32(1 << int(rng.integers(0, 32)))
+        return r, "bit flip in word %d" % i
+    if kind <= 7:  # one list one element shorter or longer, the record's size following it
+        which = int(rng.integers(0, n_counts))
+        elem = [N, 16][which] if which < 2 else 4 if which < 2 + K + 1 else 8
+        counts = [int(x) for x in r[head:head + n_counts]]
+        widths = [N, 16] + [4] * (K + 1) + [8] * (K + 3)
+        start = head + n_counts + sum(c * w for c, w in zip(counts[:which], widths[:which]))
+        end = start + counts[which] * elem
+        if kind == 6 and counts[which] > 0:
+            r = np.concatenate([r[:end - elem], r[end:]])
+            r[head + which] -= 1
+            return r, "list %d one shorter" % which
+        r = np.concatenate([r[:end], rng.integers(0, 1 << 31, size=elem).astype(np.uint32), r[end:]])
+        r[head + which] += 1
+        return r, "list %d one longer" % which
+    if kind == 8:
+        return r[:int(rng.integers(0, r.size))].copy(), "truncated"
+    return np.concatenate([r, np.zeros(int(rng.integers(1, 9)), np.uint32)]), "extended"
+
+
+def per_query_status(cfg, rec_full, mode):
+    return O.stwo_verify(records.stwo_from_record(cfg, rec_full), mode)
+
+
+@pytest.mark.parametrize("i", [0, 1, 2, 4])
+def test_walk_equals_its_definition_on_corruptions(i):
+    """status(M) == so_stwo_verify(R(M)) for mutated minimal records; malformed ones are told apart (status 2)."""
+    p = fixtures()[i]
+    cfg = p.cfg
+    m = verifier.stwo_minimise_record(cfg, verifier.stwo_record(p), formats.stwo_queries(p))
+    rng = np.random.default_rng(0x5EED2025 + 60 + i)
+    seen = set()
+    for case in range(60):
+        mut, what = corrupt_minimal(m, cfg, rng)
+        mode = O.MODE_FIXTURE if case % 3 else O.MODE_LITERAL
+        st = O.stwo_verify_minimal(cfg, mut, mode)
+        st2, back = O.stwo_minimal_expand(cfg, mut, mode)
+        assert st == st2, what
+        if st == 2:
+            seen.add("malformed")
+            continue
+        assert st == per_query_status(cfg, back, mode), (what, hex(st))
+        seen.add(st >> 24)
+    assert "malformed" in seen and len(seen) >= 3, seen
+
+
+def test_random_positions_minimise_and_expand():
+    """Records with random node bytes on random / clustered / equal / neighbouring positions: minimise (library) ->
+    R(M) by the oracle gives back the record wherever the walk does not replace a sibling by a computed node, and the
+    lists have the lengths the sets give.  (Random bytes verify nowhere: this checks the ORDER, not the hashing.)"""
+    rng = np.random.default_rng(0x5EED2025 + 70)
+    for case in range(40):
+        L = int(rng.integers(3, 12))
+        K = int(rng.integers(0, L - 1))
+        Q = int(rng.choice([1, 2, 3, 5, 8, 16]))
+        cfg = ss.StwoConfig(int(rng.integers(1, 6)), max(1, L - 2), L, Q, K, 5)
+        qs = [int(x) for x in random_queries(rng, L, Q, case % 4)]
+        nodes, lone = formats.minimal_order(L, qs)
+        # a per-query proof whose queries agree wherever they present the same thing
+        val = {x: rng.integers(0, 1 << 31, size=cfg.n_cols + 16).astype(np.uint32) for x in nodes[0]}
+        sibs = {}
+
+        def sib(t, a, x):
+            return sibs.setdefault((t, a, x), rng.integers(0, 256, size=32).astype(np.uint8))
+        fw = {}
+        p = formats.StwoProof(
+            cfg, rng.integers(0, 256, size=(3, 32)).astype(np.uint8), rng.integers(0, 1 << 31, size=(cfg.n_cols, 4)).astype(np.uint32),
+            rng.integers(0, 1 << 31, size=(16, 4)).astype(np.uint32),
+            np.array([val[q][:cfg.n_cols] for q in qs], dtype=np.uint32).reshape(Q, cfg.n_cols),
+            np.array([val[q][cfg.n_cols:] for q in qs], dtype=np.uint32).reshape(Q, 16),
+            [np.array([sib(0, a, (q >> a) ^ 1) for a in range(L)]) for q in qs],
+            [np.array([sib(1, a, (q >> a) ^ 1) for a in range(L)]) for q in qs],
+            rng.integers(0, 256, size=(K + 1, 32)).astype(np.uint8), rng.integers(0, 1 << 31, size=4).astype(np.uint32),
+            np.array([[fw.setdefault((l, (q >> l) ^ 1), rng.integers(0, 1 << 31, size=4).astype(np.uint32)) for q in qs]
+                      for l in range(K + 1)], dtype=np.uint32).reshape(K + 1, Q, 4),
+            [[np.array([sib(2 + l, a, (q >> a) ^ 1) for a in range(l + 1, L)]).reshape(-1, 32) for q in qs] for l in range(K + 1)],
+            int(rng.integers(0, 1 << 62)))
+        rec = verifier.stwo_record(p)
+        m = verifier.stwo_minimise_record(cfg, rec, qs)
+        assert np.array_equal(m, verifier.stwo_minimal_record(formats.stwo_minimise(p, qs)))
+        counts = expected_counts(L, K, qs)
+        head = 24 + 4 * cfg.n_cols + 64 + 8 * (K + 1) + 6
+        assert m[head:head + len(counts)].tolist() == counts, case
