@@ -211,15 +211,15 @@ def end_to_end_s101(ver, proof, n: int):
         batch = [texts[kind][:1] + texts[kind][1:] for _ in range(n)]  # distinct buffers
         ver.verify_stark101_texts(batch[:64], fmt=fmt)
         ver.verify_stark101_texts(batch, fmt=fmt)
-        best = None
-        for _ in range(3):
+        runs = []
+        for _ in range(5):  # the median of five is reported
             t0 = time.perf_counter()
             status, st = ver.verify_stark101_texts(batch, fmt=fmt)
             dt = time.perf_counter() - t0
             assert (status == 0).all(), "e2e: the stark101 proof was not accepted"
-            if best is None or dt < best[0]:
-                best = (dt, st)
-        dt, st = best
+            runs.append((dt, st))
+        runs.sort(key=lambda r: r[0])
+        dt, st = runs[len(runs) // 2]
         out[kind] = {"proofs_per_s": n / dt, "total_s": dt, "text_GB_per_s": st["text_bytes"] / dt / 1e9,
                      "host_parsed_texts": st["host_parsed"], "text_bytes_per_proof": st["text_bytes"] // n}
     return out
@@ -256,10 +256,10 @@ def end_to_end(ver, proofs, n: int, rank: int = 0, world: int = 1, dist=None):
     errors = []
 
     def timed(call):
-        """best of three; with several ranks: all start together, the slowest one's time counts.  A failure on this rank
+        """MEDIAN of five; with several ranks: all start together, the slowest one's time counts.  A failure on this rank
         is recorded, not raised: the other ranks are waiting in the next collective."""
-        best = None
-        for _ in range(3):
+        runs = []
+        for _ in range(5):
             if dist is not None:
                 dist.barrier()
             t0 = time.perf_counter()
@@ -273,9 +273,9 @@ def end_to_end(ver, proofs, n: int, rank: int = 0, world: int = 1, dist=None):
             dt = time.perf_counter() - t0
             if st is None and status is None and errors:
                 dt = float("inf")
-            if best is None or dt < best[0]:
-                best = (dt, st)
-        return best
+            runs.append((dt, st))
+        runs.sort(key=lambda r: r[0])
+        return runs[len(runs) // 2]
 
     def across_ranks(dt: float, link_bytes: int):
         """-> (slowest rank's time, per-rank GB/s on the host link)"""
@@ -320,15 +320,19 @@ def end_to_end(ver, proofs, n: int, rank: int = 0, world: int = 1, dist=None):
             row["python_reader_proofs_per_s_one_thread"] = k / (time.perf_counter() - t1)
         out[kind] = row
         del batch
-    # records in host memory -> verdicts: per-query records, and shared records (19 % fewer bytes at this shape,
-    # expanded by the GPU behind the link)
+    # records in host memory -> verdicts: per-query records, shared records (19 % fewer bytes at this shape, expanded by
+    # the GPU behind the link) and minimal records (one sorted, deduplicated decommitment per tree: 27 % fewer bytes,
+    # verified without an expansion pass -- csrc/ss_minimal.hip; parity unpinned, no such bytes in the reference)
+    from stark_symphony_amd import formats
     recs = [verifier.stwo_record(p) for p in distinct]
     shared = [verifier.stwo_shared_record(p) for p in distinct]
-    for kind, src, call in (("records", recs, ver.verify_stwo_records), ("shared_records", shared, ver.verify_stwo_shared_records)):
+    minimal = [verifier.stwo_minimise_record(cfg, r, formats.stwo_queries(p)) for p, r in zip(distinct, recs)]
+    for kind, src, call in (("records", recs, ver.verify_stwo_records), ("shared_records", shared, ver.verify_stwo_shared_records),
+                            ("minimal_records", minimal, ver.verify_stwo_minimal_records)):
         batch = [src[(lo + i) % len(distinct)].copy() for i in range(n_local)]
         if kind == "records":  # one 2-d array, a record per row (every record still has its own memory)
             batch = np.stack(batch)
-        else:                  # the variable-length shared records back to back + their offsets
+        else:                  # the variable-length shared / minimal records back to back + their offsets
             offs = np.zeros(len(batch) + 1, dtype=np.uint64)
             offs[1:] = np.cumsum([b.size for b in batch])
             batch = (np.concatenate(batch), offs)

@@ -323,6 +323,18 @@ int ss_stwo_verify_shared_records(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n,
 #define SS_STATUS_CONFIG_MISMATCH 1u
 #define SS_STATUS_MALFORMED 2u
 
+/* The minimal proof.json: proof.json with one decommitment per tree (minimal record above; formats.stwo_minimal_to_json,
+ * `cli convert --to json-minimal`) -- the lists as upstream stwo's prover fills them before the reference's adapter cuts them
+ * per query (scripts/generate_wit.py:36-42).  Nothing in the text names its form; with two or more queries its lists are
+ * shorter than n_queries equal shares, with one query the two forms are the same bytes.  Read by the host reader.  */
+#define SS_TEXT_JSON_MINIMAL 4
+/* text -> minimal record (0 / SS_STATUS_CONFIG_MISMATCH / SS_STATUS_MALFORMED; *words_out = its size, written when it fits
+ * cap_words, SS_ERR_ARG otherwise) and back (the text's length, 0 = no minimal record of the config).  No GPU involved. */
+int ss_stwo_parse_minimal(const ss_stwo_cfg *cfg, const char *text, size_t len, uint32_t *minimal_out, size_t cap_words,
+                          size_t *words_out);
+size_t ss_stwo_write_minimal_text(const ss_stwo_cfg *cfg, const uint32_t *minimal, size_t words, int python_separators,
+                                  char *buf, size_t cap);
+
 /* One text -> one record (ss_stwo_record_words words).  Returns 0 = parsed, SS_STATUS_CONFIG_MISMATCH,
  * SS_STATUS_MALFORMED (record_out untouched or zeroed), or < 0 on a bad argument.  No GPU involved. */
 int ss_stwo_parse(const ss_stwo_cfg *cfg, const char *text, size_t len, int fmt, uint32_t *record_out);
@@ -356,6 +368,9 @@ int ss_stwo_verify_texts(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const ch
                          const size_t *lens, int fmt, uint32_t *status_host, ss_ingest_stats *stats);
 int ss_stwo_verify_files(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const char *const *paths, int fmt,
                          uint32_t *status_host, ss_ingest_stats *stats);
+/* minimal proof.json texts -> verdicts (host reader on the library's worker threads, then ss_stwo_verify_minimal_records) */
+int ss_stwo_verify_minimal_texts(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const char *const *texts,
+                                 const size_t *lens, uint32_t *status_host, ss_ingest_stats *stats);
 int ss_s101_verify_texts(ss_ctx *ctx, size_t n, const char *const *texts, const size_t *lens, int fmt,
                          uint32_t *status_host, ss_ingest_stats *stats);
 int ss_s101_verify_files(ss_ctx *ctx, size_t n, const char *const *paths, int fmt, uint32_t *status_host,

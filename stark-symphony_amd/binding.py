@@ -49,7 +49,7 @@ class IngestStats(C.Structure):
                 ("host_parsed", C.c_uint32)]
 
 
-TEXT_AUTO, TEXT_JSON, TEXT_WIT, TEXT_JSON_SHARED = 0, 1, 2, 3
+TEXT_AUTO, TEXT_JSON, TEXT_WIT, TEXT_JSON_SHARED, TEXT_JSON_MINIMAL = 0, 1, 2, 3, 4
 STATUS_CONFIG_MISMATCH, STATUS_MALFORMED = 1, 2
 
 EXPORTS = [
@@ -67,7 +67,7 @@ EXPORTS = [
     "ss_stwo_unshare_record", "ss_stwo_expand_shared_dev", "ss_stwo_verify_shared_records", "ss_stwo_write_shared_text",
     "ss_stwo_minimal_fixed_words", "ss_stwo_minimal_max_words", "ss_stwo_minimal_counts", "ss_stwo_minimise_record",
     "ss_stwo_minimal_batch_words", "ss_stwo_minimal_workspace_bytes", "ss_stwo_verify_minimal_dev",
-    "ss_stwo_verify_minimal_records",
+    "ss_stwo_verify_minimal_records", "ss_stwo_parse_minimal", "ss_stwo_write_minimal_text", "ss_stwo_verify_minimal_texts",
 ]
 
 _lib = None
@@ -154,6 +154,9 @@ def lib() -> C.CDLL:
     sig("ss_stwo_minimal_workspace_bytes", sz, cp, sz)
     sig("ss_stwo_verify_minimal_dev", C.c_int, vp, cp, sz, vp, vp, vp, vp, sz, vp, vp, C.c_int, vp)
     sig("ss_stwo_verify_minimal_records", C.c_int, vp, cp, sz, pp, szp, vp)
+    sig("ss_stwo_parse_minimal", C.c_int, cp, C.c_char_p, sz, vp, sz, szp)
+    sig("ss_stwo_write_minimal_text", sz, cp, vp, sz, C.c_int, vp, sz)
+    sig("ss_stwo_verify_minimal_texts", C.c_int, vp, cp, sz, cpp, szp, vp, stp)
     _lib = L
     return L
 

@@ -8,6 +8,8 @@
     python -m stark_symphony_amd.cli convert --family stwo --to wit tests/data/proof.json     # generate_wit.py
     python -m stark_symphony_amd.cli convert --family stwo --to simf tests/data/proof.json    # generate_simf.py
     python -m stark_symphony_amd.cli convert --family stwo --to json-shared tests/data/proof.json   # shared Merkle paths
+    python -m stark_symphony_amd.cli convert --family stwo --to json-minimal tests/data/proof.json  # one decommitment per tree
+    python -m stark_symphony_amd.cli verify --family stwo --minimal-proof minimal.json               # ... verified as such
     python -m stark_symphony_amd.cli prove --family stark101 --out target/proof.json      # `make proof` (python -m fibsquare)
     python -m stark_symphony_amd.cli prove --family stwo --trace-log 20 --seed 0 --to wit --out target/proof.wit
 
@@ -50,7 +52,9 @@ def convert(args) -> int:
             out = {"wit": formats.stwo_to_wit, "simf": formats.stwo_to_simf,
                    "json": lambda q: json.dumps(formats.stwo_to_json(q)),
                    # every distinct Merkle sibling once + the query positions (formats.shared_path_order)
-                   "json-shared": lambda q: json.dumps(formats.stwo_to_json(q, shared=True))}[args.to](p)
+                   "json-shared": lambda q: json.dumps(formats.stwo_to_json(q, shared=True)),
+                   # one sorted, deduplicated decommitment per tree, as upstream stwo's prover sends it (formats.minimal_order)
+                   "json-minimal": lambda q: json.dumps(formats.stwo_minimal_to_json(formats.stwo_minimise(q)))}[args.to](p)
     except (formats.MalformedProof, OSError, ValueError) as e:
         print("Error: %s" % e, file=sys.stderr)
         return 1
@@ -80,7 +84,8 @@ def prove(args) -> int:
             proof = gp.prove_proof(n_cols=args.n_cols, trace_log=args.trace_log, log_blowup=args.log_blowup,
                                    n_queries=args.n_queries, pow_bits=args.pow_bits, seed=args.seed or 0, hash=args.hash)
             out = {"json": lambda: json.dumps(formats.stwo_to_json(proof)), "wit": lambda: formats.stwo_to_wit(proof),
-                   "simf": lambda: formats.stwo_to_simf(proof)}[args.to]()
+                   "simf": lambda: formats.stwo_to_simf(proof),
+                   "json-minimal": lambda: json.dumps(formats.stwo_minimal_to_json(formats.stwo_minimise(proof, gp.queries)))}[args.to]()
     except (binding.SsError, ValueError) as e:
         print("Error: %s" % e, file=sys.stderr)
         return 1
@@ -99,6 +104,8 @@ def main(argv=None) -> int:
     v.add_argument("--family", choices=["stark101", "stwo"], required=True)
     v.add_argument("--witness", nargs="*", default=[], help=".wit files (formats B / D)")
     v.add_argument("--proof", nargs="*", default=[], help="proof.json files (formats A / C)")
+    v.add_argument("--minimal-proof", nargs="*", default=[], help="stwo: minimal proof.json files (one sorted, deduplicated "
+                                                                  "decommitment per tree, as upstream stwo's prover sends it)")
     v.add_argument("--config", choices=["production", "testing"], default="production",
                    help="stwo: the config.simf profile the verifier enforces (default: production, "
                         "i.e. the reference built without -DTESTING)")
@@ -114,13 +121,13 @@ def main(argv=None) -> int:
     c = sub.add_parser("convert", help="proof.json -> .wit / .simf snippet (the reference's "
                                        "scripts/generate_wit.py and generate_simf.py, same text), or back")
     c.add_argument("--family", choices=["stark101", "stwo"], required=True)
-    c.add_argument("--to", choices=["wit", "simf", "json", "json-shared"], required=True)
+    c.add_argument("--to", choices=["wit", "simf", "json", "json-shared", "json-minimal"], required=True)
     c.add_argument("path", help="proof.json, .wit or .simf snippet (by extension; anything else = json)")
     c.add_argument("--trace-log", type=int, default=None)
     c.add_argument("--pow-bits", type=int, default=5)
     g = sub.add_parser("prove", help="make a proof on the GPU (`make proof`: python -m fibsquare / the stwo prover fork)")
     g.add_argument("--family", choices=["stark101", "stwo"], required=True)
-    g.add_argument("--to", choices=["json", "wit", "simf"], default="json")
+    g.add_argument("--to", choices=["json", "wit", "simf", "json-minimal"], default="json")
     g.add_argument("--out", default=None, help="file to write (default: stdout)")
     g.add_argument("--seed", type=int, default=None, help="stark101: a_1 of the trace (default: the reference's); stwo: r of "
                                                           "the rows [1, r, ...] (default 0 = the reference's proofs)")
@@ -143,8 +150,11 @@ def main(argv=None) -> int:
     over = {k: getattr(args, k) for k in ("n_cols", "trace_log", "lde_log", "n_queries", "n_layers",
                                           "pow_bits", "hash") if getattr(args, k) is not None}
     expected = dataclasses.replace(expected, **over)
-    if not args.witness and not args.proof:
+    if not args.witness and not args.proof and not args.minimal_proof:
         print("Error: nothing to verify", file=sys.stderr)
+        return 1
+    if args.minimal_proof and args.family != "stwo":
+        print("Error: --minimal-proof is an stwo form", file=sys.stderr)
         return 1
     # The files go to the library as they are: its native readers (csrc/ss_ingest.cpp) parse them on
     # host threads into the upload staging; nothing is parsed in Python on this path.
@@ -160,6 +170,17 @@ def main(argv=None) -> int:
                 mode = verifier.MODE_FIXTURE if args.mode == "fixture" else verifier.MODE_LITERAL
                 st, _ = ver.verify_stwo_files(expected, paths, mode, fmt)
             names += list(paths)
+            status += st.tolist()
+        if args.minimal_proof:
+            mode = verifier.MODE_FIXTURE if args.mode == "fixture" else verifier.MODE_LITERAL
+            texts = []
+            for path in args.minimal_proof:
+                try:
+                    texts.append(open(path, "rb").read())
+                except OSError:
+                    texts.append(b"")  # unreadable = not a witness: malformed, exit 1 (main.rs:77-81)
+            st, _ = ver.verify_stwo_minimal_texts(expected, texts, mode)
+            names += list(args.minimal_proof)
             status += st.tolist()
     except binding.SsError as e:  # no GPU / unsupported config: an error, never a verdict
         print("Error: %s" % e, file=sys.stderr)

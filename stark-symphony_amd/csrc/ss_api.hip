@@ -802,6 +802,98 @@ extern "C" size_t ss_stwo_write_text(const ss_stwo_cfg *c, const uint32_t *recor
     return out.size();
 }
 
+// The minimal proof.json (formats.stwo_minimal_to_json) <-> minimal record; host only.
+extern "C" int ss_stwo_parse_minimal(const ss_stwo_cfg *c, const char *text, size_t len, uint32_t *minimal_out, size_t cap_words,
+                                     size_t *words_out)
+{
+    if (!cfg_ok(c)) return set_err(SS_ERR_ARG, "unsupported stwo config");
+    if (!text || !words_out) return set_err(SS_ERR_ARG, "bad argument");
+    *words_out = 0;
+    try {
+        std::vector<uint32_t> rec;
+        const ParseResult r = stwo_parse_minimal_text(*c, text, len, rec);
+        if (r != kParsed) return r == kConfigMismatch ? (int)SS_STATUS_CONFIG_MISMATCH : (int)SS_STATUS_MALFORMED;
+        *words_out = rec.size();
+        if (!minimal_out || cap_words < rec.size()) return set_err(SS_ERR_ARG, "minimal record needs %zu words", rec.size());
+        memcpy(minimal_out, rec.data(), rec.size() * 4);
+        return 0;
+    } catch (const std::exception &e) {
+        return set_err(SS_ERR_NOMEM, "host reader: %s", e.what());
+    }
+}
+
+extern "C" size_t ss_stwo_write_minimal_text(const ss_stwo_cfg *c, const uint32_t *minimal, size_t words, int python_separators,
+                                             char *buf, size_t cap)
+{
+    if (!cfg_ok(c) || !minimal) { set_err(SS_ERR_ARG, "bad argument"); return 0; }
+    try {
+        std::string out;
+        if (!stwo_write_json_minimal(*c, minimal, words, python_separators ? kStylePython : kStyleCompact, out)) {
+            set_err(SS_ERR_ARG, "not a minimal record of this config (or a pow_target no proof.json can declare)");
+            return 0;
+        }
+        if (buf && out.size() <= cap) memcpy(buf, out.data(), out.size());
+        return out.size();
+    } catch (const std::exception &) {
+        set_err(SS_ERR_NOMEM, "out of host memory");
+        return 0;
+    }
+}
+
+// Minimal proof.json texts -> verdicts: read by the host reader on the library's worker threads (the GPU reader has no
+// template for a text whose list lengths depend on the queries), verified as minimal records.
+extern "C" int ss_stwo_verify_minimal_texts(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *const *texts,
+                                            const size_t *lens, uint32_t *status_host, ss_ingest_stats *stats)
+{
+    if (!ctx || !texts || !lens || !status_host) return set_err(SS_ERR_ARG, "null argument");
+    if (!cfg_ok(c)) return set_err(SS_ERR_ARG, "unsupported stwo config");
+    if (!n) return set_err(SS_ERR_ARG, "empty batch");
+    try {
+        const double t0 = now_s();
+        std::vector<std::vector<uint32_t>> recs(n);
+        std::vector<uint32_t> outcome(n, 0);
+        std::vector<int> failed(n, 0);
+        const size_t threads = std::max<size_t>(1, effective_cpus());
+        parallel_for(n, [&](size_t i) {
+            try {
+                const ParseResult r = texts[i] ? stwo_parse_minimal_text(*c, texts[i], lens[i], recs[i]) : kMalformed;
+                outcome[i] = r == kParsed ? 0 : r == kConfigMismatch ? SS_STATUS_CONFIG_MISMATCH : SS_STATUS_MALFORMED;
+            } catch (const std::exception &) {
+                failed[i] = 1;
+            }
+        }, threads);
+        for (size_t i = 0; i < n; i++)
+            if (failed[i]) return set_err(SS_ERR_NOMEM, "host reader: out of memory");
+        const double t1 = now_s();
+        std::vector<const uint32_t *> ptrs;
+        std::vector<size_t> words, where;
+        uint64_t text_bytes = 0, rec_bytes = 0;
+        for (size_t i = 0; i < n; i++) {
+            text_bytes += lens[i];
+            status_host[i] = outcome[i];
+            if (!outcome[i]) { ptrs.push_back(recs[i].data()); words.push_back(recs[i].size()); where.push_back(i); rec_bytes += recs[i].size() * 4; }
+        }
+        if (!ptrs.empty()) {
+            std::vector<uint32_t> st(ptrs.size());
+            const int rc = ss_stwo_verify_minimal_records(ctx, c, ptrs.size(), ptrs.data(), words.data(), st.data());
+            if (rc) return rc;
+            for (size_t k = 0; k < where.size(); k++) status_host[where[k]] = st[k];
+        }
+        if (stats) {
+            memset(stats, 0, sizeof *stats);
+            stats->parse_s = t1 - t0;
+            stats->total_s = now_s() - t0;
+            stats->text_bytes = text_bytes;
+            stats->record_bytes = rec_bytes;
+            stats->threads = (uint32_t)threads;
+            stats->host_parsed = (uint32_t)n;
+        }
+        return SS_OK;
+    } catch (const std::exception &) {
+        return set_err(SS_ERR_NOMEM, "out of host memory");
+    }
+}
+
 extern "C" size_t ss_stwo_write_shared_text(const ss_stwo_cfg *c, const uint32_t *shared, size_t words, int python_separators,
                                             char *buf, size_t cap)
 {

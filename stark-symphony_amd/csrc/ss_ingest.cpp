@@ -7,6 +7,7 @@
 // Every acceptance / rejection rule mirrors stark-symphony_amd/formats.py, which tests/test_ingest.py
 // holds this file against on the reference's own files, on random proofs and on malformed inputs.
 #include "ss_ingest.h"
+#include "ss_minimal.h"
 #include "ss_shared.h"
 
 #include <sched.h>
@@ -928,6 +929,153 @@ ParseResult stwo_from_json(const ss_stwo_cfg &cfg, const Tree &t, uint32_t *rec)
     return kParsed;
 }
 
+// ------------------------------------------------------ stwo, the minimal proof.json (ss_minimal.h)
+// formats.stwo_minimal_from_json against the expected config: the schema of format C with one decommitment per tree,
+// as upstream stwo's prover fills it (queried values once per distinct position, only the siblings / fold partners the
+// verifier cannot compute).  List lengths are data; what the text declares must agree with the verifier's config.
+ParseResult stwo_min_from_json(const ss_stwo_cfg &cfg, const Tree &t, std::vector<uint32_t> &out)
+{
+    const MinMap m = min_map(cfg.n_cols, cfg.lde_log, cfg.n_queries, cfg.n_layers);
+    if (t.nodes.empty() || t.nodes[0].kind != kObj) return kMalformed;
+    bool mismatch = false;
+    const uint32_t conf = t.member(0, "config");
+    const uint32_t fconf = conf ? t.member(conf, "fri_config") : 0;
+    uint32_t v;
+    if (conf && t.nodes[conf].kind != kObj) return kMalformed;
+    if (fconf && t.nodes[fconf].kind != kObj) return kMalformed;
+    if (uint32_t x = fconf ? t.member(fconf, "n_queries") : 0) {
+        if (!get_u32(t, x, v)) return kMalformed;
+        mismatch |= v != cfg.n_queries;
+    }
+    if (uint32_t x = conf ? t.member(conf, "pow_bits") : 0) {
+        if (!get_u32(t, x, v)) return kMalformed;
+        mismatch |= v > 64 || pow_target_of_bits(v) != cfg.pow_target;
+    }
+    if (uint32_t x = fconf ? t.member(fconf, "log_blowup_factor") : 0) {
+        if (!get_u32(t, x, v)) return kMalformed;
+        mismatch |= v != cfg.lde_log - cfg.trace_log;
+    }
+    if (uint32_t x = conf ? t.member(conf, "hash") : 0) {
+        const Node &s = t.nodes[x];
+        if (s.kind != kStr) return kMalformed;
+        const bool sha = s.len == 6 && memcmp(t.text + s.val, "sha256", 6) == 0;
+        const bool b2s = s.len == 7 && memcmp(t.text + s.val, "blake2s", 7) == 0;
+        if (!sha && !b2s) return kMalformed;
+        mismatch |= (b2s ? SS_HASH_BLAKE2S : SS_HASH_SHA256) != cfg.hash;
+    }
+    const uint32_t com = t.member(0, "commitments");
+    if (!com || !t.is_list(com) || t.count(com) != 3) return kMalformed;
+    uint32_t roots[24];
+    for (uint32_t k = 0; k < 3; k++) {
+        const uint32_t c = t.child(com, k);
+        if (!t.is_list(c) || !get_hash(t, c, roots + 8 * k)) return kMalformed;
+    }
+    const uint32_t sv = t.member(0, "sampled_values");
+    const uint32_t sv1 = sv ? t.child(sv, 1) : 0, sv2 = sv ? t.child(sv, 2) : 0;
+    if (!sv1 || !sv2 || !t.is_list(sv1) || !t.is_list(sv2) || t.count(sv2) != kCp) return kMalformed;
+    const uint32_t N = t.count(sv1);
+    mismatch |= N != cfg.n_cols;
+    const uint32_t dec = t.member(0, "decommitments"), qv = t.member(0, "queried_values");
+    const uint32_t d1 = dec ? t.child(dec, 1) : 0, d2 = dec ? t.child(dec, 2) : 0;
+    const uint32_t hw1 = d1 ? t.member(d1, "hash_witness") : 0, hw2 = d2 ? t.member(d2, "hash_witness") : 0;
+    const uint32_t qv1 = qv ? t.child(qv, 1) : 0, qv2 = qv ? t.child(qv, 2) : 0;
+    if (!hw1 || !hw2 || !qv1 || !qv2 || !t.is_list(hw1) || !t.is_list(hw2) || !t.is_list(qv1) || !t.is_list(qv2))
+        return kMalformed;
+    if (N == 0 || t.count(qv1) % N || t.count(qv2) % kCp) return kMalformed;
+    const uint32_t fri = t.member(0, "fri_proof");
+    const uint32_t first = fri ? t.member(fri, "first_layer") : 0;
+    if (!fri || !first) return kMalformed;
+    const uint32_t inner = t.member(fri, "inner_layers");
+    if (inner && !t.is_list(inner)) return kMalformed;
+    const uint32_t K = inner ? t.count(inner) : 0;
+    if (K > kMaxList) return kMalformed;
+    mismatch |= K != cfg.n_layers;
+    const uint32_t llp = t.member(fri, "last_layer_poly");
+    const uint32_t coeffs = llp ? t.member(llp, "coeffs") : 0;
+    if (!coeffs || !t.is_list(coeffs) || t.count(coeffs) != 1) return kMalformed;
+    uint64_t nonce = 0;
+    if (uint32_t x = t.member(0, "proof_of_work")) {
+        if (!get_u64(t, x, nonce)) return kMalformed;
+    }
+    // everything is validated even when the shape already mismatches (malformed wins, as in the Python reader);
+    // the record is only kept on a match
+    out.clear();
+    out.resize(m.data, 0);
+    uint32_t tmp[8];
+    const bool keep = !mismatch;
+    if (keep) memcpy(out.data(), roots, 96);
+    {
+        uint32_t c1 = t.first_child(sv1), c2 = t.first_child(sv2);
+        for (uint32_t k = 0; k < N; k++) {
+            if (!get_qm31(t, t.next_child(c1), tmp)) return kMalformed;
+            if (keep) memcpy(out.data() + 24 + 4 * k, tmp, 16);
+        }
+        for (uint32_t k = 0; k < kCp; k++) {
+            if (!get_qm31(t, t.next_child(c2), tmp)) return kMalformed;
+            if (keep) memcpy(out.data() + 24 + 4 * m.N + 4 * k, tmp, 16);
+        }
+    }
+    // list lengths beyond what any set of n_queries positions gives: no witness of this config (and no reason to
+    // let a text size the record)
+    const uint32_t n0 = t.count(qv1) / N, n1 = t.count(qv2) / kCp;
+    if (n0 > cfg.n_queries || n1 > cfg.n_queries) return kMalformed;
+    if (keep) { out[m.nv] = n0; out[m.nv + 1] = n1; }
+    auto u32_list = [&](uint32_t lst) -> bool {
+        ListIter it(t, lst);
+        for (uint32_t i = 0, n = t.count(lst); i < n; i++) {
+            if (!it.u32(v)) return false;
+            if (keep) out.push_back(v);
+        }
+        return true;
+    };
+    if (!u32_list(qv1) || !u32_list(qv2)) return kMalformed;
+    // the layers: fri_witness lists first (the record keeps them in front of the hashes), then every tree's hashes
+    std::vector<uint32_t> layers(K + 1);
+    {
+        uint32_t inner_c = inner ? t.first_child(inner) : 0;
+        for (uint32_t l = 0; l <= K; l++) {
+            const uint32_t layer = l == 0 ? first : t.next_child(inner_c);
+            if (!layer || t.nodes[layer].kind != kObj) return kMalformed;
+            layers[l] = layer;
+            const uint32_t w = t.member(layer, "fri_witness"), cm = t.member(layer, "commitment");
+            if (!w || !cm || !t.is_list(w) || !t.is_list(cm)) return kMalformed;
+            if (t.count(w) > cfg.n_queries) return kMalformed;
+            if (!get_hash(t, cm, tmp)) return kMalformed;
+            if (keep && l <= m.K) { memcpy(out.data() + 24 + 4 * m.N + 64 + 8 * l, tmp, 32); out[m.nfw + l] = t.count(w); }
+            ListIter iw(t, w);
+            for (uint32_t i = 0, n = t.count(w); i < n; i++) {
+                uint32_t q4[4];
+                if (!iw.qm31(q4)) return kMalformed;
+                if (keep) out.insert(out.end(), q4, q4 + 4);
+            }
+        }
+    }
+    auto hashes = [&](uint32_t hw, uint32_t tree) -> bool {
+        if (!hw || !t.is_list(hw)) return false;
+        const uint32_t n = t.count(hw);
+        if (tree < m.K + 3 && n > cfg.n_queries * min_tree_len(cfg.lde_log, tree)) return false;
+        if (n > kMaxQueries * kMaxList) return false;
+        if (keep) out[m.nhw + tree] = n;
+        ListIter it(t, hw);
+        for (uint32_t i = 0; i < n; i++) {
+            if (!it.hash(tmp)) return false;
+            if (keep) out.insert(out.end(), tmp, tmp + 8);
+        }
+        return true;
+    };
+    if (!hashes(hw1, 0) || !hashes(hw2, 1)) return kMalformed;
+    for (uint32_t l = 0; l <= K; l++) {
+        const uint32_t d = t.member(layers[l], "decommitment");
+        if (!d || !hashes(t.member(d, "hash_witness"), 2 + l)) return kMalformed;
+    }
+    if (!get_qm31(t, t.child(coeffs, 0), tmp)) return kMalformed;
+    if (mismatch) { out.clear(); return kConfigMismatch; }
+    memcpy(out.data() + 24 + 4 * m.N + 64 + 8 * (m.K + 1), tmp, 16);
+    out[m.head - 2] = (uint32_t)(nonce >> 32);
+    out[m.head - 1] = (uint32_t)nonce;
+    return kParsed;
+}
+
 // ------------------------------------------------------------------ stwo, format D (proof.wit)
 // formats.stwo_from_wit / _stwo_from_parts: six literals; a .wit declares nothing, so TRACE_LOG_SIZE,
 // the PoW target and the hash are the verifier's and only the shape is compared.
@@ -1058,6 +1206,18 @@ ParseResult stwo_parse_text(const ss_stwo_cfg &cfg, const char *text, size_t len
         if (fmt == SS_TEXT_AUTO) fmt = j.member(0, "COMMITMENTS") ? SS_TEXT_WIT : SS_TEXT_JSON;
         r = fmt == SS_TEXT_WIT ? stwo_from_wit(cfg, j, record) : stwo_from_json(cfg, j, record);
     }
+    tree_trim(j);
+    return r;
+}
+
+ParseResult stwo_parse_minimal_text(const ss_stwo_cfg &cfg, const char *text, size_t len, std::vector<uint32_t> &out)
+{
+    static thread_local Tree j;
+    out.clear();
+    if (len > kMaxTextBytes) return kMalformed;
+    ParseResult r = kMalformed;
+    if (parse_json(j, text, len) && !j.nodes.empty() && j.nodes[0].kind == kObj) r = stwo_min_from_json(cfg, j, out);
+    if (r != kParsed) out.clear();
     tree_trim(j);
     return r;
 }

@@ -11,6 +11,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "../../include/ss_verify.h"
 
 namespace ss {
@@ -24,6 +26,10 @@ enum ParseResult : int {
 
 // fmt: SS_TEXT_AUTO sniffs (a .wit is a JSON object with a "COMMITMENTS" / "P_MT_ROOT" member)
 ParseResult stwo_parse_text(const ss_stwo_cfg &cfg, const char *text, size_t len, int fmt, uint32_t *record);
+
+// The minimal proof.json (one sorted, deduplicated decommitment per tree; formats.stwo_minimal_from_json): the same
+// schema with lists whose lengths are data.  out receives the minimal record (include/ss_verify.h) when parsed.
+ParseResult stwo_parse_minimal_text(const ss_stwo_cfg &cfg, const char *text, size_t len, std::vector<uint32_t> &out);
 
 // stark101: a proof's shape is data (List<_, 32>), so parsing yields the shape too
 struct S101Parsed;

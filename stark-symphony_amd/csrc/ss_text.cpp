@@ -5,6 +5,7 @@
 #include <cstring>
 
 #include "ss_layout.h"
+#include "ss_minimal.h"
 #include "ss_shared.h"
 
 namespace ss {
@@ -36,6 +37,8 @@ struct Rec {
     uint32_t fri_wit(uint32_t l, uint32_t q) const { return fbase + foff[l] + q * (4 + 8 * (L - 1 - l)); }
     // the hash_witness list of tree t (0 trace, 1 composition, 2 + l FRI layer l): one full path per query
     bool shared() const { return false; }
+    uint32_t n_vals(uint32_t) const { return Q; }  // entries of queried_values[1 + t] / of a layer's fri_witness
+    uint32_t n_fw(uint32_t) const { return Q; }
     uint32_t tree_len(uint32_t t) const { return t < 2 ? L : L + 1 - t; }
     uint32_t n_entries(uint32_t t) const { return Q * tree_len(t); }
     uint32_t entry(uint32_t t, uint32_t e) const
@@ -71,9 +74,42 @@ struct SRec {
     uint32_t cp_vals(uint32_t q) const { return trace_vals(q) + N; }
     uint32_t fri_wit(uint32_t l, uint32_t q) const { return m.wit + (l * Q + q) * 4; }
     bool shared() const { return true; }
+    uint32_t n_vals(uint32_t) const { return Q; }
+    uint32_t n_fw(uint32_t) const { return Q; }
     uint32_t n_entries(uint32_t t) const { return count[t]; }
     uint32_t entry(uint32_t t, uint32_t e) const { return node0[t] + 8 * e; }
     uint32_t query(uint32_t q) const { return m.qry + q; }
+};
+
+// word offsets of a MINIMAL record (include/ss_verify.h, csrc/ss_minimal.h): the lists are as long as the record says
+struct MRec {
+    uint32_t N, L, Q, K;
+    uint32_t nv[2], nfw[kMaxList + 1], nhw[kMaxTrees];
+    uint32_t tv, cv, fw[kMaxList + 1], hw[kMaxTrees];
+    MRec(const ss_stwo_cfg &c, const uint32_t *rec) : N(c.n_cols), L(c.lde_log), Q(c.n_queries), K(c.n_layers)
+    {
+        const MinMap m = min_map(N, L, Q, K);
+        uint32_t o = m.data;
+        nv[0] = rec[m.nv]; nv[1] = rec[m.nv + 1];
+        tv = o; o += nv[0] * N;
+        cv = o; o += nv[1] * kCp;
+        for (uint32_t l = 0; l <= K; l++) { nfw[l] = rec[m.nfw + l]; fw[l] = o; o += 4 * nfw[l]; }
+        for (uint32_t t = 0; t < K + 3; t++) { nhw[t] = rec[m.nhw + t]; hw[t] = o; o += 8 * nhw[t]; }
+    }
+    uint32_t oods_trace() const { return 24; }
+    uint32_t oods_cp() const { return 24 + 4 * N; }
+    uint32_t fri_root(uint32_t l) const { return 24 + 4 * N + 64 + 8 * l; }
+    uint32_t last() const { return fri_root(K + 1); }
+    uint32_t nonce() const { return last() + 4; }
+    uint32_t trace_vals(uint32_t i) const { return tv + i * N; }
+    uint32_t cp_vals(uint32_t i) const { return cv + i * kCp; }
+    uint32_t fri_wit(uint32_t l, uint32_t i) const { return fw[l] + 4 * i; }
+    bool shared() const { return false; }
+    uint32_t n_vals(uint32_t t) const { return nv[t]; }
+    uint32_t n_fw(uint32_t l) const { return nfw[l]; }
+    uint32_t n_entries(uint32_t t) const { return nhw[t]; }
+    uint32_t entry(uint32_t t, uint32_t e) const { return hw[t] + 8 * e; }
+    uint32_t query(uint32_t) const { return 0; }
 };
 
 bool pow_bits_of(uint64_t target, uint32_t &bits)
@@ -192,16 +228,16 @@ void json_text(const ss_stwo_cfg &cfg, const M &m, uint32_t pow_bits, TextStyle 
     s.lit("{"); hash_witness(0); s.lit("}"); s.lit(cm);
     s.lit("{"); hash_witness(1); s.lit("}]"); s.lit(cm);
     key("queried_values"); s.lit("[[]"); s.lit(cm); s.lit("[");
-    for (uint32_t q = 0; q < m.Q; q++)
+    for (uint32_t q = 0, n = m.n_vals(0); q < n; q++)
         for (uint32_t k = 0; k < m.N; k++) { if (q | k) s.lit(cm); s.u32(m.trace_vals(q) + k); }
     s.lit("]"); s.lit(cm); s.lit("[");
-    for (uint32_t q = 0; q < m.Q; q++)
+    for (uint32_t q = 0, n = m.n_vals(1); q < n; q++)
         for (uint32_t k = 0; k < kCp; k++) { if (q | k) s.lit(cm); s.u32(m.cp_vals(q) + k); }
     s.lit("]]"); s.lit(cm);
     key("proof_of_work"); s.u64(m.nonce()); s.lit(cm);
     auto layer = [&](uint32_t l) {
         s.lit("{"); key("fri_witness"); s.lit("[");
-        for (uint32_t q = 0; q < m.Q; q++) { if (q) s.lit(cm); qm31(m.fri_wit(l, q)); }
+        for (uint32_t q = 0, n = m.n_fw(l); q < n; q++) { if (q) s.lit(cm); qm31(m.fri_wit(l, q)); }
         s.lit("]"); s.lit(cm); key("decommitment"); s.lit("{");
         hash_witness(2 + l);
         s.lit("}"); s.lit(cm); key("commitment"); hash_bytes(m.fri_root(l)); s.lit("}");
@@ -445,6 +481,31 @@ bool stwo_write_json_shared(const ss_stwo_cfg &cfg, const uint32_t *shared, size
     if (total != words) return false;
     TextSink s{out, shared};
     json_text(cfg, SRec(cfg, shared + m.cnt), bits, style, s);
+    return true;
+}
+
+// formats.stwo_minimal_to_json: the same members with the lists as upstream stwo fills them
+bool stwo_write_json_minimal(const ss_stwo_cfg &cfg, const uint32_t *rec, size_t words, TextStyle style, std::string &out)
+{
+    uint32_t bits;
+    out.clear();
+    if (!cfg_writable(cfg) || !pow_bits_of(cfg.pow_target, bits) || !rec) return false;
+    const MinMap m = min_map(cfg.n_cols, cfg.lde_log, cfg.n_queries, cfg.n_layers);
+    if (words < m.data) return false;
+    size_t total = m.data;
+    if (rec[m.nv] > m.Q || rec[m.nv + 1] > m.Q) return false;
+    total += (size_t)rec[m.nv] * m.N + (size_t)rec[m.nv + 1] * kCp;
+    for (uint32_t l = 0; l <= m.K; l++) {
+        if (rec[m.nfw + l] > m.Q) return false;
+        total += 4 * (size_t)rec[m.nfw + l];
+    }
+    for (uint32_t t = 0; t < m.K + 3; t++) {
+        if (rec[m.nhw + t] > m.Q * min_tree_len(m.L, t)) return false;
+        total += 8 * (size_t)rec[m.nhw + t];
+    }
+    if (total != words) return false;
+    TextSink s{out, rec};
+    json_text(cfg, MRec(cfg, rec), bits, style, s);
     return true;
 }
 

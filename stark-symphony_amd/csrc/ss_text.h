@@ -204,6 +204,8 @@ void stwo_build_template(const ss_stwo_cfg &cfg, int fmt, TextTemplateHost &out)
 // shared record (include/ss_verify.h) -> the shared-path proof.json, byte for byte json.dumps(formats.stwo_to_json(p,
 // shared=True)); false when `shared` is no shared record of the config
 bool stwo_write_json_shared(const ss_stwo_cfg &cfg, const uint32_t *shared, size_t words, TextStyle style, std::string &out);
+// minimal record -> the minimal proof.json (formats.stwo_minimal_to_json); false = no minimal record of the config
+bool stwo_write_json_minimal(const ss_stwo_cfg &cfg, const uint32_t *minimal, size_t words, TextStyle style, std::string &out);
 // Scalar statement of the fast path for format 3: hint from the tail, gaps, the scan of text_scan_reference through the
 // gap maps into a capacity-form shared record, the stored positions against the hint, expansion (ss_stwo_unshare_record's
 // rule) into `record` (the per-query record).  scratch: shared_capacity_words(cfg) words.

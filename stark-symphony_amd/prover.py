@@ -434,6 +434,7 @@ class GpuProver:
         while len(queries) < n_queries:
             queries += [w & mask for w in ch.draw_words()]
         queries = queries[:n_queries]
+        self.queries = list(queries)  # (of the last proof made by this call path; prove_minimal uses them)
         # every gather of the decommitment is enqueued first, then downloaded at once
         g = self._Gather(self)
         lde_t, cp_lde_t = lde.T, cp_lde.T  # views: row = LDE position
@@ -531,6 +532,15 @@ class GpuProver:
         dt = time.perf_counter() - t0
         self.timings = {"total": dt, "proofs_per_s": len(seeds) / dt, "workers": len(threads)}
         return out
+
+    def prove_minimal(self, **kw):
+        """The proof with ONE decommitment per tree -- queries sorted and deduplicated, only the siblings and fold
+        partners the verifier cannot compute (formats.StwoMinimalProof; what upstream stwo's prover sends, where the
+        reference's format repeats a full path per query: fri/queries.simf:41, scripts/generate_wit.py:36-42).  The
+        prover holds every node anyway, so this is prove_proof() minus what is not sent."""
+        from .formats import stwo_minimise
+        proof = self.prove_proof(**kw)
+        return stwo_minimise(proof, self.queries)
 
     def prove(self, n_cols: int = 4, trace_log: int = 9, log_blowup: int = 4, n_queries: int = 16,
               pow_bits: int = 5, seed: int = 0, hash: str = "sha256") -> dict:

@@ -349,6 +349,32 @@ def stwo_minimise_record(cfg: StwoConfig, record: np.ndarray, queries: Sequence[
     return out[:words.value].copy()
 
 
+def parse_stwo_minimal_text(cfg: StwoConfig, text: bytes, mode: int = MODE_FIXTURE):
+    """One minimal proof.json -> (outcome, minimal record or None) with the library's native reader (ss_stwo_parse_minimal;
+    no GPU): outcome 0 = parsed, STATUS_CONFIG_MISMATCH (1), STATUS_MALFORMED (2)."""
+    cs = stwo_cfg_struct(cfg, mode)
+    L = B.lib()
+    text = bytes(text)
+    out = np.zeros(L.ss_stwo_minimal_max_words(C.byref(cs)), dtype=np.uint32)
+    words = C.c_size_t(0)
+    rc = B.check(L.ss_stwo_parse_minimal(C.byref(cs), text, len(text), out.ctypes.data, out.size, C.byref(words)))
+    return rc, (out[:words.value].copy() if rc == 0 else None)
+
+
+def write_stwo_minimal_text(cfg: StwoConfig, minimal: np.ndarray, python_separators: bool = True, mode: int = MODE_FIXTURE) -> bytes:
+    """Minimal record -> the minimal proof.json, byte for byte what json.dumps prints for formats.stwo_minimal_to_json
+    (ss_stwo_write_minimal_text).  ValueError when `minimal` is no minimal record of the config."""
+    cs = stwo_cfg_struct(cfg, mode)
+    L = B.lib()
+    rec = np.ascontiguousarray(minimal, dtype=np.uint32)
+    n = L.ss_stwo_write_minimal_text(C.byref(cs), rec.ctypes.data, rec.size, 1 if python_separators else 0, None, 0)
+    if n == 0:
+        raise ValueError("not a minimal record of this config")
+    buf = C.create_string_buffer(n)
+    L.ss_stwo_write_minimal_text(C.byref(cs), rec.ctypes.data, rec.size, 1 if python_separators else 0, buf, n)
+    return buf.raw[:n]
+
+
 def stwo_minimal_counts(cfg: StwoConfig, queries: Sequence[int], mode: int = MODE_FIXTURE) -> np.ndarray:
     """List lengths of a minimal record for these positions: [n_vals x 2, n_fw per layer, n_hw per tree]."""
     cs = stwo_cfg_struct(cfg, mode)
@@ -795,23 +821,52 @@ class Verifier:
         B.check(B.lib().ss_stwo_verify_shared_records(self.ctx, C.byref(cs), n, ptrs, words, status.ctypes.data))
         return status
 
-    def verify_stwo_minimal_records(self, cfg: StwoConfig, minimal: Sequence[np.ndarray], mode: int = MODE_FIXTURE) -> np.ndarray:
+    def verify_stwo_minimal_records(self, cfg: StwoConfig, minimal, mode: int = MODE_FIXTURE) -> np.ndarray:
         """Host-buffer path for MINIMAL records (ss_stwo_verify_minimal_records): one sorted, deduplicated decommitment
         per tree, verified without an expansion pass (csrc/ss_minimal.hip).  A record that is no minimal record of
-        `cfg` gets STATUS_MALFORMED."""
+        `cfg` gets STATUS_MALFORMED.  `minimal`: a list of 1-d uint32 arrays, or a pair (flat, offsets) as for
+        verify_stwo_shared_records."""
         cs = stwo_cfg_struct(cfg, mode, self.stwo_flags)
         if B.lib().ss_stwo_record_words(C.byref(cs)) == 0:
             raise B.SsError(B.SS_ERR_ARG, "unsupported stwo config %r" % (cfg,))
-        for r in minimal:
-            if r.dtype != np.uint32 or r.ndim != 1 or not r.flags["C_CONTIGUOUS"]:
-                raise ValueError("a minimal record is a contiguous 1-d uint32 array")
-        n = len(minimal)
+        if isinstance(minimal, tuple):
+            flat, offs = minimal
+            offs = np.ascontiguousarray(offs, dtype=np.uint64)
+            if flat.dtype != np.uint32 or flat.ndim != 1 or not flat.flags["C_CONTIGUOUS"] or offs.ndim != 1 or offs.size < 1 \
+                    or (np.diff(offs.astype(np.int64)) < 0).any() or int(offs[-1]) > flat.size:
+                raise ValueError("(flat, offsets): a contiguous uint32 array and ascending word offsets inside it")
+            n = offs.size - 1
+            ptr_vals = np.uint64(flat.ctypes.data) + offs[:-1] * np.uint64(4)
+            ptrs = (C.c_void_p * n).from_buffer(ptr_vals) if n else None
+            lens = np.ascontiguousarray(np.diff(offs), dtype=np.uint64)
+            words = (C.c_size_t * n).from_buffer(lens) if n else None
+        else:
+            for r in minimal:
+                if r.dtype != np.uint32 or r.ndim != 1 or not r.flags["C_CONTIGUOUS"]:
+                    raise ValueError("a minimal record is a contiguous 1-d uint32 array")
+            n = len(minimal)
+            ptrs = _ptr_array(minimal) if n else None
+            words = (C.c_size_t * n)(*[int(r.size) for r in minimal]) if n else None
         if n == 0:
             return np.empty(0, dtype=np.uint32)
         status = np.full(n, 0xFFFFFFFF, dtype=np.uint32)  # unwritten = REJECT
-        words = (C.c_size_t * n)(*[int(r.size) for r in minimal])
-        B.check(B.lib().ss_stwo_verify_minimal_records(self.ctx, C.byref(cs), n, _ptr_array(minimal), words, status.ctypes.data))
+        B.check(B.lib().ss_stwo_verify_minimal_records(self.ctx, C.byref(cs), n, ptrs, words, status.ctypes.data))
         return status
+
+    def verify_stwo_minimal_texts(self, cfg: StwoConfig, texts: Sequence[bytes], mode: int = MODE_FIXTURE):
+        """Minimal proof.json texts -> (status, stats) (ss_stwo_verify_minimal_texts: the library's host reader on its
+        worker threads, then the minimal-record path)."""
+        cs = stwo_cfg_struct(cfg, mode, self.stwo_flags)
+        n = len(texts)
+        status = np.full(n, 0xFFFFFFFF, dtype=np.uint32)
+        stats = B.IngestStats()
+        if n == 0:
+            return status, {k: 0 for k, _ in B.IngestStats._fields_}
+        bufs = [bytes(t) for t in texts]
+        arr = (C.c_char_p * n)(*bufs)
+        lens = (C.c_size_t * n)(*[len(b) for b in bufs])
+        B.check(B.lib().ss_stwo_verify_minimal_texts(self.ctx, C.byref(cs), n, arr, lens, status.ctypes.data, C.byref(stats)))
+        return status, {k: getattr(stats, k) for k, _ in B.IngestStats._fields_}
 
     def verify_stwo_minimal(self, proofs, mode: int = MODE_FIXTURE, *, cfg: StwoConfig) -> np.ndarray:
         """Status word per StwoMinimalProof against the config the caller expects (others: STATUS_CONFIG_MISMATCH)."""

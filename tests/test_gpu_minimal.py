@@ -145,3 +145,34 @@ def test_resident_minimal_batch_and_phases(ver):
     want = [O.stwo_verify_minimal(p.cfg, r, verifier.MODE_FIXTURE) for r in recs]
     assert one.tolist() == two.tolist() == [want[i] for i in idx]
     assert b.accepted() == sum(1 for i in idx if want[i] == 0)
+
+
+def test_minimal_texts_and_cli(ver, tmp_path):
+    """The minimal proof.json as text: ss_stwo_verify_minimal_texts (host reader, then the minimal-record path) gives the
+    records' verdicts and the stage-0 codes for texts that are no witness / of another config; `cli verify
+    --minimal-proof` keeps the exit-status contract of simfony-cli/src/main.rs:254-257; `cli convert --to json-minimal`
+    writes the text the library's writer writes."""
+    import json
+    import subprocess
+    p = fixtures()[0]
+    cfg = p.cfg
+    m = minimal_of(p)
+    rng = np.random.default_rng(0x5EED2025 + 150)
+    recs = [m] + [r for r in (corrupt_minimal(m, cfg, rng)[0] for _ in range(40)) if O.stwo_verify_minimal(cfg, r, 1) != 2][:12]
+    texts = [verifier.write_stwo_minimal_text(cfg, r) for r in recs]
+    other = formats.stwo_minimal_to_json(formats.stwo_minimise(fixtures()[1]))
+    texts += [b"not a witness", json.dumps(other).encode()]
+    got, stats = ver.verify_stwo_minimal_texts(cfg, texts)
+    want = [O.stwo_verify_minimal(cfg, r, 1) for r in recs] + [2, 1]
+    assert got.tolist() == want and got[0] == 0 and stats["host_parsed"] == len(texts)
+    good, bad = tmp_path / "good.json", tmp_path / "bad.json"
+    good.write_bytes(texts[0])
+    bad.write_bytes(texts[1])
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    run = lambda *a: subprocess.run([sys.executable, "-m", "stark_symphony_amd.cli", *a], env=env, capture_output=True, text=True)
+    r = run("verify", "--family", "stwo", "--minimal-proof", str(good))
+    assert r.returncode == 0 and "ACCEPT" in r.stdout
+    r = run("verify", "--family", "stwo", "--minimal-proof", str(good), str(bad))
+    assert r.returncode == 1 and "REJECT" in r.stderr
+    r = run("convert", "--family", "stwo", "--to", "json-minimal", os.path.join(ROOT, "tests", "golden", "stwo_proof.json"))
+    assert r.returncode == 0 and r.stdout.strip().encode() == texts[0]

@@ -197,3 +197,83 @@ def test_random_positions_minimise_and_expand():
         counts = expected_counts(L, K, qs)
         head = 24 + 4 * cfg.n_cols + 64 + 8 * (K + 1) + 6
         assert m[head:head + len(counts)].tolist() == counts, case
+
+
+# ------------------------------------------------------------------------------------------- the minimal proof.json
+def _min_text_mutants(text: bytes, rng):
+    """Texts near a minimal proof.json: dropped / duplicated list elements, numbers out of range, structure damage."""
+    obj = json.loads(text)
+    out = []
+
+    def variant(f):
+        o = json.loads(text)
+        f(o)
+        out.append(json.dumps(o).encode())
+    variant(lambda o: o["queried_values"][1].pop())                                  # not a multiple of the column count
+    variant(lambda o: o["queried_values"][1].extend(o["queried_values"][1][:4]))     # one position more
+    variant(lambda o: o["decommitments"][1]["hash_witness"].pop())                   # a sibling short
+    variant(lambda o: o["decommitments"][2]["hash_witness"].append([0] * 32))        # one too many
+    variant(lambda o: o["fri_proof"]["first_layer"]["fri_witness"].pop() if o["fri_proof"]["first_layer"]["fri_witness"] else None)
+    variant(lambda o: o["fri_proof"]["inner_layers"].pop())                          # another layer count: config mismatch
+    variant(lambda o: o["config"].__setitem__("pow_bits", 7))                        # declared parameter: config mismatch
+    variant(lambda o: o["config"]["fri_config"].__setitem__("n_queries", 3))
+    variant(lambda o: o["config"].__setitem__("hash", "md5"))                        # malformed
+    variant(lambda o: o["commitments"][1].__setitem__(3, 256))                       # a byte that is no byte
+    variant(lambda o: o["queried_values"][2].__setitem__(0, 1 << 32))
+    variant(lambda o: o["decommitments"][1]["hash_witness"][0].pop())                # 31 bytes
+    variant(lambda o: o.pop("fri_proof"))
+    variant(lambda o: o["sampled_values"][1].pop())                                  # another column count
+    variant(lambda o: o["fri_proof"]["last_layer_poly"]["coeffs"].append([[1, 2], [3, 4]]))
+    variant(lambda o: o["decommitments"][1]["hash_witness"].extend([[1] * 32] * 2000))  # more hashes than any record holds
+    out.append(text[:len(text) // 2])
+    out.append(b"[]")
+    out.append(text.replace(b"hash_witness", b"hash_witnes", 1))
+    for _ in range(8):  # random byte damage
+        b = bytearray(text)
+        b[int(rng.integers(0, len(b)))] = int(rng.integers(32, 127))
+        out.append(bytes(b))
+    del obj
+    return out
+
+
+@pytest.mark.parametrize("i", [0, 1, 2, 4])
+def test_minimal_text_native_reader_equals_python(i):
+    """ss_stwo_parse_minimal == formats.stwo_minimal_from_json + the config policy, on the fixtures' minimal texts and on
+    mutants; ss_stwo_write_minimal_text prints json.dumps(formats.stwo_minimal_to_json(..)) byte for byte."""
+    p = fixtures()[i]
+    cfg = p.cfg
+    m = formats.stwo_minimise(p)
+    rec = verifier.stwo_minimal_record(m)
+    obj = formats.stwo_minimal_to_json(m)
+    for seps, text in ((True, json.dumps(obj).encode()), (False, json.dumps(obj, separators=(",", ":")).encode())):
+        assert verifier.write_stwo_minimal_text(cfg, rec, python_separators=seps) == text
+        rc, got = verifier.parse_stwo_minimal_text(cfg, text)
+        assert rc == 0 and np.array_equal(got, rec)
+    text = json.dumps(obj).encode()
+    rng = np.random.default_rng(0x5EED2025 + 140 + i)
+    outcomes = set()
+    for mut in _min_text_mutants(text, rng):
+        rc, got = verifier.parse_stwo_minimal_text(cfg, mut)
+        try:
+            mp = formats.stwo_minimal_from_json(json.loads(mut), cfg)
+            want = 0 if mp.cfg == cfg else 1
+            if want == 0:
+                try:
+                    wrec = verifier.stwo_minimal_record(mp)
+                    N, L, Q, K = cfg.n_cols, cfg.lde_log, cfg.n_queries, cfg.n_layers
+                    lens = [L, L] + [L - 1 - l for l in range(K + 1)]
+                    if (len(mp.trace_vals) > Q or len(mp.cp_vals) > Q or any(len(w) > Q for w in mp.fri_witness)
+                            or any(len(h) > Q * ln for h, ln in zip(mp.hash_witness, lens))):
+                        want = 2  # longer lists than any set of n_queries positions gives: no witness of the config
+                except ValueError:
+                    want = 2
+        except (formats.MalformedProof, ValueError, RecursionError):
+            want = 2
+        assert rc == want, (rc, want, mut[:80])
+        outcomes.add(rc)
+        if rc == 0:
+            assert np.array_equal(got, wrec)
+    assert outcomes == {0, 1, 2}
+    # a one-query proof: the two forms are the same text
+    if cfg.n_queries == 1:
+        assert json.dumps(formats.stwo_to_json(p)) == json.dumps(obj)

@@ -532,6 +532,9 @@ def main():
     ap.add_argument("--pow-bits", type=int, default=5)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--hash", choices=["sha256", "blake2s"], default="sha256")
+    ap.add_argument("--minimal", action="store_true",
+                    help="print the minimal proof.json: one sorted, deduplicated decommitment per tree, as upstream stwo's "
+                         "prover sends it (formats.stwo_minimal_to_json), instead of one path per query")
     ap.add_argument("-o", "--out", default="-")
     args = ap.parse_args()
     here = os.path.dirname(os.path.abspath(__file__))
@@ -540,6 +543,10 @@ def main():
         return
     proof = prove(args.n_cols, args.trace_log, args.log_blowup, args.n_queries, args.pow_bits,
                   verbose=True, seed=args.seed, hash=args.hash)
+    if args.minimal:  # a selection from the per-query proof: nothing new is computed
+        sys.path.insert(0, os.path.join(here, ".."))
+        from stark_symphony_amd import formats
+        proof = formats.stwo_minimal_to_json(formats.stwo_minimise(formats.stwo_from_json(proof, trace_log=args.trace_log)))
     text = json.dumps(proof)
     if args.out == "-":
         print(text)
