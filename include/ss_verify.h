@@ -438,6 +438,17 @@ int ss_stwo_read_intermediates(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, co
                                size_t proof, void *stream, uint32_t *queries, uint32_t *oods_point,
                                uint32_t *deep_alpha, uint32_t *fold_alphas, uint32_t *fri_answers);
 
+/* The stark101 twin (any out pointer may be NULL; `workspace_dev` as passed to ss_s101_verify_*_dev):
+ *   alphas[3]            the composition coefficients (air.simf:30-35)
+ *   idx, x, cp           the query (verifier.simf:33), its domain point (:37), the composition value (air.simf:94-101)
+ *   folds[max_layers+1]  the value entering FRI layer i -- what fri.simf:77 compares with the layer's cpa -- and, at
+ *                        [n_layers], the final one (fri.simf:90); what stark101/scripts/fibsquare/prover_test.py:32-104
+ *                        recomputes as `rhs`
+ *   state[8]             the channel state after the commitments, before the query draw (verifier.simf:31-33)   */
+int ss_s101_read_intermediates(ss_ctx *ctx, const ss_s101_shape *shape, size_t n, const void *workspace_dev, size_t proof,
+                               void *stream, uint32_t *alphas, uint32_t *idx, uint32_t *x, uint32_t *cp, uint32_t *folds,
+                               uint32_t *state);
+
 /* Kernel timing.  With timing enabled every *_verify_batch_dev call records a HIP event pair
  * around each kernel ON THE CALLER'S STREAM (no synchronisation; not graph-capturable, so off
  * by default).  ss_ctx_collect_timing waits for the recorded events, sums them per kernel

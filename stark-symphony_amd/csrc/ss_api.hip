@@ -384,6 +384,29 @@ extern "C" int ss_s101_verify_phase_dev(ss_ctx *ctx, const ss_s101_shape *sh, si
     return SS_OK;
 }
 
+// Per-stage values of one stark101 proof after a verify call (the twin of ss_stwo_read_intermediates).
+extern "C" int ss_s101_read_intermediates(ss_ctx *ctx, const ss_s101_shape *sh, size_t n, const void *workspace, size_t proof,
+                                          void *stream_, uint32_t *alphas, uint32_t *idx, uint32_t *x, uint32_t *cp,
+                                          uint32_t *folds, uint32_t *state)
+{
+    if (!ctx || !workspace) return set_err(SS_ERR_ARG, "null argument");
+    if (!shape_ok(sh) || !n || proof >= n) return set_err(SS_ERR_ARG, "bad shape or proof index");
+    const S101Layout y = s101_layout(sh->max_layers, sh->max_path, n);
+    const uint32_t *ws = (const uint32_t *)workspace;
+    SS_DEVICE_GUARD(ctx);
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream_));
+    auto rows = [&](uint32_t *dst, uint32_t row0, size_t count) {  // int[row][np]: `count` consecutive rows of one proof
+        return hipMemcpy2D(dst, 4, ws + y.ws_int + (size_t)row0 * y.np + proof, (size_t)y.np * 4, 4, count, hipMemcpyDeviceToHost);
+    };
+    if (idx) HIP_TRY(hipMemcpy(idx, ws + proof, 4, hipMemcpyDeviceToHost));
+    if (alphas) HIP_TRY(rows(alphas, 0, 3));
+    if (x) HIP_TRY(rows(x, 3, 1));
+    if (cp) HIP_TRY(rows(cp, 4, 1));
+    if (folds) HIP_TRY(rows(folds, 5, (size_t)y.ML + 1));
+    if (state) HIP_TRY(rows(state, 5 + y.ML + 1, 8));
+    return SS_OK;
+}
+
 extern "C" int ss_s101_verify_batch_dev(ss_ctx *ctx, const ss_s101_shape *sh, size_t n,
                                         const uint32_t *batch, void *workspace, size_t workspace_bytes,
                                         uint32_t *status, uint32_t *accept_count, void *stream_)

@@ -223,7 +223,13 @@ struct S101Layout {
     uint64_t off_head, off_leaf, off_len, off_path;            // off_path + type * path_stride
     uint64_t path_stride;
     uint64_t total_words;
-    uint64_t ws_total_words;  // idx per proof
+    // workspace: idx[np] (read by the merkle kernel), then the per-stage values of every proof, int[row][np]:
+    // rows 0..2 the composition coefficients (air.simf:30-35), 3 x (verifier.simf:37), 4 cp (air.simf:94-101),
+    // 5 .. 5+ML the value entering FRI layer i / the final one (fri.simf:74-91), then 8 rows: the channel state after
+    // the commitments, before the query draw (verifier.simf:31-33)
+    uint64_t ws_int;
+    uint32_t int_rows;
+    uint64_t ws_total_words;
 };
 
 SS_HD inline bool s101_shape_ok(uint32_t ML, uint32_t PM) { return ML <= kMaxList && PM <= kMaxList; }
@@ -250,7 +256,9 @@ SS_HD inline S101Layout s101_layout(uint32_t ML, uint32_t PM, uint64_t n)
     y.path_stride = (uint64_t)PM * 8 * y.np;
     o += y.path_stride * y.n_types;
     y.total_words = o;
-    y.ws_total_words = y.np;
+    y.ws_int = y.np;
+    y.int_rows = 5 + (ML + 1) + 8;
+    y.ws_total_words = (uint64_t)y.np * (1 + y.int_rows);
     return y;
 }
 

@@ -100,9 +100,16 @@ s101_transcript_kernel(S101Layout lay, const uint32_t *__restrict__ batch, uint3
     }
     const uint32_t last = H(lay.h_last);
     st = s101_hash_state<1>(st, last);  // channel_mix_32(state, last_layer)
+    // per-stage values for ss_s101_read_intermediates (the reference's counterpart: what prover_test.py:32-104 recomputes
+    // and simfony's dbg! tracker prints, simfony-cli/src/tracker.rs:48-80)
+    uint32_t *ints = ws + lay.ws_int + p;
+    auto INT = [&](uint32_t row, uint32_t v) { ints[(size_t)row * np] = v; };
+#pragma unroll
+    for (int i = 0; i < 8; i++) INT(5 + lay.ML + 1 + i, st.v[i]);
     // :33  random query
     const uint32_t idx = s101_draw<8192u>(st);
     ws[p] = idx;
+    INT(0, a0); INT(1, a1); INT(2, a2);
 
     // :37-39  x = 5 * h^idx, composition polynomial (air.simf:58-101)
     // Every divisor of the path is a canonical field element (an output of sub_mod / mul_mod),
@@ -135,11 +142,13 @@ s101_transcript_kernel(S101Layout lay, const uint32_t *__restrict__ batch, uint3
         const uint32_t p2 = f101_mul(f101_mul(num0, num1), i2);
         cp = f101_add(f101_add(f101_mul(p0, a0), f101_mul(p1, a1)), f101_mul(p2, a2));
     }
+    INT(3, x); INT(4, cp);
     // :41  fri_verify_32 without the Merkle checks (fri.simf:58-62,74-91)
     constexpr uint32_t kInv2 = (S101_P + 1) / 2;
     uint32_t xx = x, xx_inv = x_inv, cur = cp;
     for (uint32_t i = 0; i < nl; i++) {
         const uint32_t cpa = EV(3 + 2 * i), cpb = EV(4 + 2 * i), beta = H(lay.h_layer + 9 * i + 8);
+        INT(5 + i, cur);
         if (cur != cpa) FAIL(s101_code(4, 4 * i + 0));
         if (f101_mul(xx, 2) == 0) FAIL(s101_code(4, 4 * i + 3));
         const uint32_t op0 = f101_mul(f101_add(cpa, cpb), kInv2);
@@ -148,6 +157,7 @@ s101_transcript_kernel(S101Layout lay, const uint32_t *__restrict__ batch, uint3
         xx = f101_mul(xx, xx);
         xx_inv = f101_mul(xx_inv, xx_inv);
     }
+    INT(5 + nl, cur);
     if (cur != last) FAIL(s101_code(5, 0));
     if (fail != 0xffffffffu) atomicMin(&status[p], fail);
 }

@@ -687,6 +687,19 @@ class S101DeviceBatch(_DeviceBatch):
             self.ws.numel() * 4, self.status_dev.data_ptr(), self.accept_dev.data_ptr(),
             phases, self._stream(stream)))
 
+    def intermediates(self, proof: int, stream=None) -> dict:
+        """Per-stage values of proof `proof` left by the last run (ss_s101_read_intermediates): the composition
+        coefficients, query, x, cp, the value entering every FRI layer (+ the final one), the channel state before the
+        query draw -- what stark101/scripts/fibsquare/prover_test.py:32-104 recomputes."""
+        ml = self.sh.max_layers
+        out = {"alphas": np.zeros(3, np.uint32), "idx": np.zeros(1, np.uint32), "x": np.zeros(1, np.uint32),
+               "cp": np.zeros(1, np.uint32), "folds": np.zeros(ml + 1, np.uint32), "state": np.zeros(8, np.uint32)}
+        B.check(B.lib().ss_s101_read_intermediates(
+            self.ver.ctx, C.byref(self.sh), self.n, self.ws.data_ptr(), proof, self._stream(stream),
+            out["alphas"].ctypes.data, out["idx"].ctypes.data, out["x"].ctypes.data, out["cp"].ctypes.data,
+            out["folds"].ctypes.data, out["state"].ctypes.data))
+        return {k: (int(v[0]) if k in ("idx", "x", "cp") else v) for k, v in out.items()}
+
 
 class Verifier:
     """One context on one MI355X.  Raises SsError if the GPU or the library is unusable."""

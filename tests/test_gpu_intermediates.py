@@ -126,3 +126,61 @@ def test_last_layer_asserts_in_isolation():
     kinds = {(int(c[0]), w >> 24, w & 15) for c, w in zip(cases, want)}
     assert {(0, 8, 0), (0, 9, 0), (0, 9, 1), (0, 0, 0), (1, 9, 1), (1, 0, 0)} <= kinds
     assert not any(m == 1 and (stage, sub) in ((8, 0), (9, 0)) for m, stage, sub in kinds)   # FIXTURE mode never raises D2 / D3
+
+
+def test_stark101_intermediates_against_the_reference_prover_and_the_oracle(s101_proof):
+    """ss_s101_read_intermediates.  Two references: (1) tests/golden/stark101_transcript.json -- the 59 channel messages
+    of the reference's OWN prover (stark101/scripts/fibsquare/prover.py, imported by make_stark101_golden.py): the value
+    the device carries into FRI layer i is the prover's cp_i message, the final one its last-layer constant, and cp is
+    cp_0 -- what the reference's Python verifier recomputes as `rhs` (prover_test.py:32-104); the query index is the one
+    of SURVEY.md Appendix C; (2) the oracle's so_s101_trace on the proof and on corruptions that keep the transcript
+    well-formed (stark101/src/verifier.simf:24-42)."""
+    import json
+    import os
+    from conftest import GOLDEN
+    ver = verifier.Verifier(0)
+    msgs = json.load(open(os.path.join(GOLDEN, "stark101_transcript.json")))
+    # the message list: p_mt_root, 10 layer roots, the last value, then (value, path) pairs: f(x), f(gx), f(ggx),
+    # cp_i and its sibling per layer, and the last value once more
+    felts = [m["felt"] for m in msgs if "felt" in m]
+    n_layers = len(s101_proof.layers)
+    last, evals, cps = felts[0], felts[1:4], felts[4:4 + 2 * n_layers]
+    assert felts[-1] == last == s101_proof.last and len(felts) == 4 + 2 * n_layers + 1
+    rng = np.random.default_rng(SEED + 31)
+    proofs = [s101_proof]
+    for _ in range(6):
+        p = s101_proof.copy()
+        k = int(rng.integers(4))
+        if k == 0:
+            p.evals[int(rng.integers(3))].ev ^= 1 << int(rng.integers(31))
+        elif k == 1:
+            p.layers[int(rng.integers(n_layers))].cpb.ev ^= 1 << int(rng.integers(31))
+        elif k == 2:
+            p.last ^= 1 << int(rng.integers(31))
+        else:
+            p.root = formats._flip_bytes(p.root, int(rng.integers(256)))
+        proofs.append(p)
+    b = ver.stark101_batch(proofs)
+    b.run()
+    status = b.status()
+    for pi, proof in enumerate(proofs):
+        st, tr = O.s101_verify(proof, trace=True)
+        assert int(status[pi]) == st
+        got = b.intermediates(pi)
+        assert got["alphas"].tolist() == list(tr.alpha) and got["idx"] == tr.idx and got["x"] == tr.x
+        assert bytes(np.asarray(got["state"], dtype=">u4").tobytes()) == bytes(tr.state_after_commit)
+        if (st >> 8) != 3:  # (a division abort leaves the later values unspecified: code 3 is ordered before them)
+            assert got["cp"] == tr.cp
+            upto = n_layers + 1
+            for i in range(n_layers):
+                if st and (st >> 8) == 4 and (st & 0xFF) % 4 == 3 and (st & 0xFF) // 4 <= i:
+                    upto = i + 1  # a fold division aborted in layer i: what follows is ordered behind that code
+                    break
+            assert got["folds"][:upto].tolist() == list(tr.fold[:upto]), pi
+    # the honest proof against the reference prover's own messages
+    got = b.intermediates(0)
+    assert status[0] == 0 and got["idx"] == 6160
+    assert [s101_proof.evals[k].ev for k in range(3)] == evals
+    assert got["cp"] == cps[0] == got["folds"][0]
+    assert got["folds"][:n_layers].tolist() == cps[0::2]
+    assert int(got["folds"][n_layers]) == last

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(binding.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ss_version() == 0x00020002  # 2.2: shared records and shared-path texts, expanded on the GPU
+    assert lib.ss_version() == 0x00020003  # 2.3: minimal records, device replay of the reference KATs, stark101 intermediates
     assert lib.ss_abi_sizeof_cfg() == C.sizeof(binding.StwoCfg) == 40 and lib.ss_abi_sizeof_shape() == 8
 
 
