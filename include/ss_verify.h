@@ -472,6 +472,36 @@ int ss_ctx_collect_timing(ss_ctx *ctx, int cap, const char **names, float *total
  *         -> out the first failing status code, 0 = none (stages 8 / 9 of the stwo status codes)            */
 int ss_selftest(ss_ctx *ctx, int op, size_t n, const uint32_t *in_host, uint32_t *out_host);
 
+/* Device replay of the reference's known-answer tests (tests only; csrc/ss_kat.hip): one reference function per item,
+ * evaluated ON THE GPU through the device functions the kernels are built from; tests/test_gpu_kats.py feeds the literals
+ * of the reference's `fn test_*` bodies (tests/golden/kats.json) and compares with the expected literals directly.
+ * in_words / out_words = n x the op's widths.  Hashes are 8 words (word j = big-endian bytes 4j..4j+3).
+ *   op 0  (97 -> 8)   SHA-256 of in[0] <= 96 big-endian words in[1..]: sha256, sha256_32, sha256_pair, the leaf hashers
+ *                     (hasher.simf:34-104), channel_mix_256 / _mix_oods_evals as digest || values
+ *   op 1  (267 -> 9)  merkle_verify_32: family (0 stark101 merkle.simf:22-43 | 1 stwo :22-44), auth, len, leaf[8], root[8],
+ *                     path[31][8] -> rc (0 | 1 `path == 1` fails | 2 root differs), computed root[8]
+ *   op 2  (34 -> 17)  stwo channel (channel.simf:31-172): digest[8], counter, k, payload[24] -> digest', counter', result[8];
+ *                     k = 0 two draw_qm31 | 1 draw_qm31_point | 2 mix_u256 | 3 check_proof_of_work (nonce hi lo, target hi
+ *                     lo; result[1] = reverse_bytes_32(payload[4])) | 4 draw_queries_8 (mask) | 5 evals_commit (3 roots) |
+ *                     6 mix_u256 + draw_qm31 | 7 mix_line_poly (4 words)
+ *   op 3  (4 -> 10)   cm31: a, b -> add, sub, mul, a / b, inv(a)            (all-ones where the reference aborts)
+ *   op 4  (8 -> 16)   qm31: a, b -> add, sub, a * m31(b[0]), a * cm31(b[0], b[1])
+ *   op 5  (4 -> 4)    m31 points: p, q -> p + q, 2p
+ *   op 6  (3 -> 9)    a, b, log -> bit_reverse_position(a, log), index add / mul / neg(a), circle_domain(log)[3],
+ *                     circle position a -> point index, line position a -> x coordinate
+ *   op 7  (18 -> 16)  qm31 points: P, Q, m -> P + Q, P + m (qm31_point_add_m31_point)
+ *   op 8  (93 -> 18)  log_size, P[8], 4 columns[16], alpha[4], 16 cp parts[64] -> vanishing_poly_eval[4],
+ *                     eval_composition_poly[4], composition_poly_eval_from_decomposed[4], .._from_partitions(parts 0..3)[4],
+ *                     abort flag, 0
+ *   op 9  (19 -> 19)  deep/quotients.simf: sample point[8], value[4], alpha_i[4], domain point[2], queried value ->
+ *                     denominator inverse[2], interpolant coefficients[12], nominator[4], abort flag
+ *   op 10 (15 -> 5)   kind (0 circle_fold | 1 line_fold), position, f_p[4], f_neg_p[4], log_size, alpha[4] -> abort flag, folded[4]
+ *   op 11 (12 -> 10)  stark101: k, args[11]; k = 0 field (a, b -> add sub mul div exp) | 1 channel_draw_32 (state[8], max ->
+ *                     value, state') | 2 read_coefficients (state -> 3 draws, 7 state words) | 3 calc_x / eval_p0 (idx, x, f_x)
+ *                     | 4 eval_cp (a0 a1 a2 f_x f_gx f_ggx x) | 5 fri_eval_cp_next (cpa cpb x beta) | 6 compute_auth_path
+ *                     (idx, domain) | 7 channel_mix_32 (state[8], m -> state')                                        */
+int ss_kat(ss_ctx *ctx, int op, size_t n, const uint32_t *in_host, size_t in_words, uint32_t *out_host, size_t out_words);
+
 #ifdef __cplusplus
 }
 #endif

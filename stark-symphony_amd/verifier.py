@@ -1004,6 +1004,24 @@ class Verifier:
         return out
 
 
+KAT_WIDTHS = [(97, 8), (267, 9), (34, 17), (4, 10), (8, 16), (4, 4), (3, 9), (18, 16), (93, 18), (19, 19), (15, 5), (12, 10)]
+
+
+def kat(ver: "Verifier", op: int, items) -> np.ndarray:
+    """ss_kat: one reference function per row of `items` on the GPU (include/ss_verify.h lists the ops); rows shorter than
+    the op's input width are zero padded.  Tests only."""
+    in_w, out_w = KAT_WIDTHS[op]
+    rows = np.zeros((len(items), in_w), dtype=np.uint32)
+    for i, r in enumerate(items):
+        r = [int(v) for v in r]
+        if len(r) > in_w or any(not (0 <= v < 1 << 32) for v in r):
+            raise ValueError("op %d takes at most %d u32 words" % (op, in_w))
+        rows[i, :len(r)] = r
+    out = np.zeros((len(items), out_w), dtype=np.uint32)
+    B.check(B.lib().ss_kat(ver.ctx, op, len(items), rows.ctypes.data, rows.size, out.ctypes.data, out.size))
+    return out
+
+
 _default: Optional[Verifier] = None
 
 

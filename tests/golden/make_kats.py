@@ -7,7 +7,7 @@ For every `fn test_*` in stark101/src/*.simf and stwo-verifier/src/**/*.simf
 integer literals that appear in the test body (comments stripped, identifiers such
 as `u32`, `eq_256`, `qm31` excluded).  kats.json holds DATA only -- inputs and
 expected outputs -- keyed by "<file>::<test>" with the line number of the test;
-tests/kats.py gives every position its meaning.
+tests/test_oracle_kats.py (CPU oracle) and tests/test_gpu_kats.py (device) give every position its meaning.
 """
 import json, os, re, sys
 

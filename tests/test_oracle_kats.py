@@ -316,17 +316,19 @@ def test_circle_point_index_to_m31_point(kats):
 QM31_GEN = ((1, 0, 478637715, 513582971), (992285211, 649143431, 740191619, 1186584352))
 
 
-def test_add_circle_point_m31():
+def test_add_circle_point_m31(kats):
     """groups/qm31_point.simf:77-87 (identity test; constants from :14 and m31_point.simf:13)."""
+    assert kats(W + "groups/qm31_point.simf::test_add_circle_point_m31") == []  # the body holds no literal
     g = O.qmp(*QM31_GEN)
     m = mp(2, 1268011823)
     as_q = O.qmp((2, 0, 0, 0), (1268011823, 0, 0, 0))
     assert L.so_qm31_point_add_m31_point(g, m).t() == L.so_qm31_point_add(g, as_q).t()
 
 
-def test_m31_point_neg():
+def test_m31_point_neg(kats):
     """groups/qm31_point.simf:89-96: 3G + (-(3G)) == zero.  qm31_neg is wrap-around P - a,
     so the comparison holds on raw words only because no coordinate of y is zero."""
+    assert kats(W + "groups/qm31_point.simf::test_m31_point_neg") == []  # the body holds no literal
     g = O.qmp(*QM31_GEN)
     p = L.so_qm31_point_add(L.so_qm31_point_add(g, g), g)
     y = p.y.t()
@@ -611,5 +613,16 @@ def test_array_macros(kats):
     assert kats(W + "fri/answers.simf::test_cp_evals_zip_arr_4")[1:5] == [1, 2, 3, 4]
 
 
-def test_all_reference_tests_are_covered(kats):
+def test_all_reference_tests_are_covered(kats, request):
+    """Every vector of kats.json has been CONSUMED by a test above (this test runs last in the module), by name."""
     assert len(kats.keys) == 86
+    whole_module = not request.config.getoption("keyword") and not any("::" in a for a in request.config.args)
+    if whole_module and not request.config.getoption("deselect", None):
+        left = sorted(set(kats.keys) - kats.used)
+        assert not left, "reference tests whose vectors no test consumed: %s" % left
+
+
+def test_gpu_replay_has_a_handler_for_every_vector(kats):
+    """tests/test_gpu_kats.py replays every vector on the device (-m gpu); its handler table must cover the file exactly."""
+    import test_gpu_kats
+    assert set(test_gpu_kats.HANDLERS) == set(kats.keys)
