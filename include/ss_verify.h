@@ -296,6 +296,20 @@ int ss_stwo_verify_minimal_dev(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, co
 int ss_stwo_verify_minimal_records(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const uint32_t *const *minimal,
                                    const size_t *words, uint32_t *status_host);
 
+/* The three host-buffer paths WITHOUT the staging copy: the inputs lie back to back in ONE buffer of page-locked host
+ * memory -- allocated by hipHostMalloc, or any memory registered with ss_host_register (hipHostRegister) -- and the DMA
+ * engine reads it directly, chunk by chunk, while the previous chunk is verified.  No host thread touches the bytes
+ * (the staged entry points need about four cores to feed the link; a rank of an 8-GPU host has two).  records: n x
+ * ss_stwo_record_words words; shared / minimal: record i at word offset offs[i], offs[n] = the total (n + 1 ascending
+ * offsets, ordinary memory).  SS_ERR_ARG when the buffer is not page-locked.  Verdicts are those of the staged twins. */
+int ss_host_register(ss_ctx *ctx, void *ptr, size_t bytes);
+int ss_host_unregister(ss_ctx *ctx, void *ptr);
+int ss_stwo_verify_records_pinned(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const uint32_t *records, uint32_t *status_host);
+int ss_stwo_verify_shared_records_pinned(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const uint32_t *flat,
+                                         const uint64_t *offs, uint32_t *status_host);
+int ss_stwo_verify_minimal_records_pinned(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const uint32_t *flat,
+                                          const uint64_t *offs, uint32_t *status_host);
+
 /* The same from shared records (shared[i] has words[i] words): fewer bytes on the host link, expanded behind it. */
 int ss_stwo_verify_shared_records(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const uint32_t *const *shared,
                                   const size_t *words, uint32_t *status_host);

@@ -866,6 +866,49 @@ class Verifier:
         B.check(B.lib().ss_stwo_verify_minimal_records(self.ctx, C.byref(cs), n, ptrs, words, status.ctypes.data))
         return status
 
+    # -- the same three paths from a caller-pinned buffer: no staging copy (csrc/ss_pinned.hip) ----------------------
+    def pinned_buffer(self, words: int) -> np.ndarray:
+        """A uint32 array of `words` words in page-locked host memory (torch's pinned allocator = hipHostMalloc)."""
+        t = _torch().empty(max(int(words), 1), dtype=_torch().int32, pin_memory=True)
+        a = t.numpy().view(np.uint32)[:int(words)]
+        self._pinned_keep = getattr(self, "_pinned_keep", []) + [t]
+        return a
+
+    def register_host(self, a: np.ndarray) -> None:
+        """Page-lock an existing array in place (ss_host_register = hipHostRegister); undo with unregister_host."""
+        B.check(B.lib().ss_host_register(self.ctx, a.ctypes.data, a.nbytes))
+
+    def unregister_host(self, a: np.ndarray) -> None:
+        B.check(B.lib().ss_host_unregister(self.ctx, a.ctypes.data))
+
+    def verify_stwo_pinned(self, cfg: StwoConfig, flat: np.ndarray, offsets=None, kind: str = "records",
+                           mode: int = MODE_FIXTURE) -> np.ndarray:
+        """records / shared / minimal records lying back to back in ONE page-locked uint32 array (pinned_buffer, or any
+        array passed to register_host) -> verdicts, DMA straight from that array (ss_stwo_verify_*_pinned).  `offsets`:
+        n + 1 ascending word offsets (shared, minimal); per-query records are n x record_words words."""
+        cs = stwo_cfg_struct(cfg, mode, self.stwo_flags)
+        if flat.dtype != np.uint32 or flat.ndim != 1 or not flat.flags["C_CONTIGUOUS"]:
+            raise ValueError("a contiguous 1-d uint32 array expected")
+        L = B.lib()
+        if kind == "records":
+            W = L.ss_stwo_record_words(C.byref(cs))
+            if W == 0 or flat.size % W:
+                raise ValueError("n x %d words expected" % W)
+            n = flat.size // W
+            status = np.full(n, 0xFFFFFFFF, dtype=np.uint32)
+            if n:
+                B.check(L.ss_stwo_verify_records_pinned(self.ctx, C.byref(cs), n, flat.ctypes.data, status.ctypes.data))
+            return status
+        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        if offs.ndim != 1 or offs.size < 1 or (np.diff(offs.astype(np.int64)) < 0).any() or int(offs[-1]) > flat.size:
+            raise ValueError("n + 1 ascending word offsets inside the array expected")
+        n = offs.size - 1
+        status = np.full(n, 0xFFFFFFFF, dtype=np.uint32)
+        fn = {"shared": L.ss_stwo_verify_shared_records_pinned, "minimal": L.ss_stwo_verify_minimal_records_pinned}[kind]
+        if n:
+            B.check(fn(self.ctx, C.byref(cs), n, flat.ctypes.data, offs.ctypes.data, status.ctypes.data))
+        return status
+
     def verify_stwo_minimal_texts(self, cfg: StwoConfig, texts: Sequence[bytes], mode: int = MODE_FIXTURE):
         """Minimal proof.json texts -> (status, stats) (ss_stwo_verify_minimal_texts: the library's host reader on its
         worker threads, then the minimal-record path)."""

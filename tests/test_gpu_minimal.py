@@ -176,3 +176,50 @@ def test_minimal_texts_and_cli(ver, tmp_path):
     assert r.returncode == 1 and "REJECT" in r.stderr
     r = run("convert", "--family", "stwo", "--to", "json-minimal", os.path.join(ROOT, "tests", "golden", "stwo_proof.json"))
     assert r.returncode == 0 and r.stdout.strip().encode() == texts[0]
+
+
+def test_pinned_entry_points_give_the_staged_verdicts(ver):
+    """ss_stwo_verify_*_pinned (csrc/ss_pinned.hip): records, shared records and minimal records lying back to back in ONE
+    page-locked buffer -- torch's pinned allocator, or ordinary memory passed to ss_host_register -- are read by the DMA
+    engine directly; verdicts are those of the staged entry points on the same inputs; ordinary memory is refused."""
+    from stark_symphony_amd import binding as B
+    p = fixtures()[0]
+    cfg = p.cfg
+    rng = np.random.default_rng(0x5EED2025 + 160)
+    full = [verifier.stwo_record(p)] + [verifier.stwo_record(formats.stwo_corrupt(p, rng)[0]) for _ in range(700)]
+    m = minimal_of(p)
+    mins = [m] + [corrupt_minimal(m, cfg, rng)[0] for _ in range(300)]
+    qs = formats.stwo_queries(p)
+    shared = []
+    for r in full[:300]:
+        try:
+            shared.append(verifier.stwo_shared_record(records.stwo_from_record(cfg, r), qs))
+        except ValueError:  # (a corruption made two queries disagree: no shared form)
+            pass
+    shared.append(shared[0][:40].copy())  # not a shared record at all
+
+    def flat_of(recs, pinned):
+        offs = np.zeros(len(recs) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([r.size for r in recs])
+        buf = ver.pinned_buffer(int(offs[-1])) if pinned else np.zeros(int(offs[-1]), dtype=np.uint32)
+        buf[:] = np.concatenate(recs)
+        return buf, offs
+    for pinned in (True, False):
+        f, _ = flat_of(full, pinned)
+        s, so = flat_of(shared, pinned)
+        mm, mo = flat_of(mins, pinned)
+        if not pinned:
+            with pytest.raises(B.SsError):  # pageable memory: refused, not silently staged
+                ver.verify_stwo_pinned(cfg, f)
+            for a in (f, s, mm):
+                ver.register_host(a)
+        try:
+            assert ver.verify_stwo_pinned(cfg, f).tolist() == ver.verify_stwo_records(cfg, np.stack(full)).tolist()
+            assert ver.verify_stwo_pinned(cfg, s, so, "shared").tolist() == ver.verify_stwo_shared_records(cfg, shared).tolist()
+            got = ver.verify_stwo_pinned(cfg, mm, mo, "minimal")
+            assert got.tolist() == ver.verify_stwo_minimal_records(cfg, mins).tolist()
+            assert got[0] == 0 and (got == 2).any()
+        finally:
+            if not pinned:
+                for a in (f, s, mm):
+                    ver.unregister_host(a)
