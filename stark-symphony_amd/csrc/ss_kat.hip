@@ -2,7 +2,7 @@
 // and its HIP kernels").  ss_kat runs one reference function per item ON THE GPU, through the device functions the
 // kernels are built from (ss_fields.h, ss_hash.h, ss_channel.h, ss_s101.h); tests/test_gpu_kats.py feeds it the vectors of
 // tests/golden/kats.json -- the literals of the reference's `fn test_*` bodies -- and compares with the expected
-// literals directly, not through the oracle.  Where a kernel evaluates a reference function in a re-associated form
+// literals directly, not through the CPU checker.  Where a kernel evaluates a reference function in a re-associated form
 // (hoisted DEEP coefficients, fold coordinates from a doubling chain: ss_stwo.hip) the op states the function as the
 // .simf text does, over the same primitives; the kernels' own forms are held to the reference through the end-to-end
 // proofs and the intermediates (tests/test_gpu_intermediates.py, which also compares them with KAT constants).

@@ -8,7 +8,7 @@
 // only the siblings (and fold-pair evaluations) the verifier cannot compute from other queried nodes.  No bytes of
 // that form exist in the reference: PARITY UNPINNED.  What pins it here is the correspondence with the per-query
 // record: M verifies exactly as R(M), the record in which every omitted value is the one the walk computes
-// (oracle/ss_oracle.c, so_stwo_minimal_expand).
+// (the test checker's so_stwo_minimal_expand).
 //
 // Structure.  Absolute level a = 0 .. L-1 counts from the leaves of the LDE-sized trees; every tree of a proof sees
 // the queries through the same positions x(q, a) = query >> a (FRI layer l's fold pairs are the nodes of level l + 1).

@@ -5,7 +5,7 @@
 // stwo-verifier/src/merkle.simf:22-44 (the per-path fold this replaces).  A minimal record holds what upstream
 // stwo's prover sends: values once per distinct queried position, and only the siblings / fold-pair evaluations
 // that no other query's chain produces.  PARITY UNPINNED (no bytes of the form in the reference); pinned instead to
-// the per-query path through R(M) (oracle/ss_oracle.c so_stwo_minimal_expand).
+// the per-query path through R(M) (the test checker's so_stwo_minimal_expand).
 //
 // No expansion pass that hashes, no hint from the prover: the transcript kernel draws the verifier's own queries,
 // stwo_min_expand_kernel (one block per proof) turns them into the plan of ss_minimal.h and GATHERS the record's

@@ -1,7 +1,7 @@
 // Minimal records on the host (include/ss_verify.h, "minimal record"): sizes, the expected list lengths for a set of
 // positions, and the writer a prover-side caller uses (per-query record -> minimal record: a selection, no hashing).
 // The way back needs hashing -- it IS the verification -- and exists only on the GPU (ss_minimal.hip) and, as the
-// checker's definition, in oracle/ss_oracle.c.  Host-only; built with the sanitizers by tests/native/host_san.cpp.
+// checker's definition, in the tests' CPU checker.  Host-only; built with the sanitizers by tests/native/host_san.cpp.
 #include "ss_minimal.h"
 
 #include <cstring>

@@ -551,7 +551,7 @@ def minimal_order(lde_log: int, queries: Sequence[int]):
         not queried -- the partners of Lone(l) -- are its fri_witness (stwo FriLayerVerifier::extract_evaluation), and
         its tree's witness starts above the pairs: Lone(l + 1), Lone(l + 2), ...
     -> (nodes, lone): two lists indexed by level 0..lde_log - 1.  Definition by sets; the closed form the library uses
-    (csrc/ss_minimal.h) and the oracle's sorted walk are compared with it in tests/test_minimal.py."""
+    (csrc/ss_minimal.h) and the test checker's sorted walk are compared with it in tests/test_minimal.py."""
     nodes, lone = [], []
     for a in range(lde_log):
         ns = sorted({int(q) >> a for q in queries})
