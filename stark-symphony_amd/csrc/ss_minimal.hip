@@ -255,14 +255,14 @@ extern "C" int ss_stwo_verify_minimal_records(ss_ctx *ctx, const ss_stwo_cfg *c,
         // a record longer than any minimal record of the config is malformed whatever it holds: only its fixed words
         // travel, and the kernel refuses a record whose size is not the one its counts give
         auto sent = [&](size_t i) { return words[i] > max_words ? std::min(words[i], fixed) : words[i]; };
-        const size_t budget = (64u << 20) / 4;
+        const size_t budget = (64u << 20) / 4;  // (staged: equal chunks, so that staging chunk k + 1 takes as long as uploading chunk k)
         std::vector<size_t> first;
         {
             size_t lo = 0, step_words = std::max<size_t>(budget / 16, max_words);
             while (lo < n) {
                 first.push_back(lo);
                 size_t w = 0, hi = lo;
-                while (hi < n && (hi == lo || (w + sent(hi) <= step_words && hi - lo < 4096))) w += sent(hi++);
+                while (hi < n && (hi == lo || (w + sent(hi) <= step_words && hi - lo < 16384))) w += sent(hi++);
                 lo = hi;
                 step_words = std::min(budget, step_words * 2);
             }

@@ -48,15 +48,15 @@ static int verify_pinned(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const uint
     std::lock_guard<std::mutex> lock(ctx->mu);
     SS_DEVICE_GUARD(ctx);
     auto start = [&](size_t i) { return kind ? (size_t)offs[i] : i * W; };
-    // chunks of <= 64 MiB of input (the first ones small and doubling: nothing overlaps the first upload), <= 4096 records
-    const size_t budget = (64u << 20) / 4;
+    // chunks of <= 256 MiB of input (the first ones small and doubling: nothing overlaps the first upload), <= 16384 records
+    const size_t budget = (256u << 20) / 4;  // (no staging to balance against: few, large chunks)
     std::vector<size_t> first;
     {
         size_t lo = 0, step = budget / 16;
         while (lo < n) {
             first.push_back(lo);
             size_t hi = lo + 1;
-            while (hi < n && start(hi + 1) - start(lo) <= step && hi - lo < 4096) hi++;
+            while (hi < n && start(hi + 1) - start(lo) <= step && hi - lo < 16384) hi++;
             lo = hi;
             step = std::min(budget, step * 2);
         }
