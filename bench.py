@@ -96,7 +96,10 @@ def load_workload(name: str):
     raise SystemExit("unknown workload %r" % name)
 
 
-MERKLE_STAGE_SOURCES = ("ss_stwo.hip", "ss_stwo_checks.h", "ss_sha256.h", "ss_hash.h", "ss_layout.h", "ss_fields.h", "ss_channel.h")
+# (kernels, their headers, and what decides launch geometry and batch layout: ss_api.hip's grids / stream split,
+# ss_pack.cpp's lay_of and its flags -- ADVICE r4)
+MERKLE_STAGE_SOURCES = ("ss_stwo.hip", "ss_stwo_checks.h", "ss_sha256.h", "ss_hash.h", "ss_layout.h", "ss_fields.h", "ss_channel.h",
+                        "ss_api.hip", "ss_pack.cpp", "ss_kernels.h")
 
 
 def kernel_sources_digest() -> str:
@@ -349,6 +352,25 @@ def end_to_end(ver, proofs, n: int, rank: int = 0, world: int = 1, dist=None):
         if world > 1:
             row["per_rank_link_GB_s"] = links
         out[kind] = row
+        # the same inputs lying in ONE caller-pinned buffer: no staging copy, no host thread per byte (csrc/ss_pinned.hip) --
+        # what a rank of an 8-GPU host, with two of the 16 granted cores, should use
+        try:
+            flat_src, offs = (batch.reshape(-1), None) if isinstance(batch, np.ndarray) else batch
+            pinned = ver.pinned_buffer(flat_src.size)
+            pinned[:] = flat_src
+            pk = {"records": "records", "shared_records": "shared", "minimal_records": "minimal"}[kind]
+            ver.verify_stwo_pinned(cfg, pinned, offs, pk)
+            dt, _ = timed(lambda: (ver.verify_stwo_pinned(cfg, pinned, offs, pk), {}))
+            slowest, links = across_ranks(dt, nbytes)
+            prow = {"proofs_per_s": n / slowest, "total_s": None if slowest == float("inf") else slowest,
+                    "link_GB_per_s": nbytes * (n / max(n_local, 1)) / slowest / 1e9, "host_threads": 0}
+            if world > 1:
+                prow["per_rank_link_GB_s"] = links
+            out[kind + "_pinned"] = prow
+            del pinned
+            ver._pinned_keep = []
+        except Exception as e:  # noqa: BLE001
+            errors.append("rank %d pinned %s: %r" % (rank, kind, e))
         del batch
     if errors:
         out["errors"] = errors

@@ -83,6 +83,7 @@ int main(int argc, char **argv)
          * counts -- followed by 8 words per counted node.  Whether the counts are the ones its positions imply is
          * the library's business (SS_STATUS_MALFORMED), not this program's. */
         const size_t fixed = ss_stwo_shared_fixed_words(&cfg), trees = 3 + cfg.n_layers, max_words = ss_stwo_shared_max_words(&cfg);
+        if (fixed == 0) { fprintf(stderr, "unsupported stwo config\n"); return 2; }  /* (the size functions return 0 for one) */
         recs = (const uint32_t **)malloc((n_words / fixed + 1) * sizeof *recs);
         lens = (size_t *)malloc((n_words / fixed + 1) * sizeof *lens);
         for (size_t o = 0; o < n_words;) {

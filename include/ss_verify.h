@@ -177,7 +177,8 @@ size_t ss_stwo_shared_max_words(const ss_stwo_cfg *cfg);   /* fixed + 8 * n_quer
 /* counts[3+n_layers] for these positions; SS_ERR_ARG when one lies outside the LDE domain.  Pure. */
 int ss_stwo_shared_counts(const ss_stwo_cfg *cfg, const uint32_t *queries, uint32_t *counts);
 /* per-query record + the positions its prover drew -> shared record.  *words_out receives its size; written when it
- * fits cap_words (SS_ERR_ARG otherwise).  Returns 0, or 1 = this proof has no shared form.  Pure.               */
+ * fits cap_words (SS_ERR_ARG otherwise).  Returns 0, or 1 = this proof has no shared form; SS_ERR_ARG when a position
+ * lies outside the LDE domain (the caller's error, as in ss_stwo_shared_counts -- not "no shared form").  Pure.  */
 int ss_stwo_share_record(const ss_stwo_cfg *cfg, const uint32_t *record, const uint32_t *queries, uint32_t *shared_out,
                          size_t cap_words, size_t *words_out);
 /* shared -> per-query record on the host (what the GPU does in ss_stwo_expand_shared_dev).  Returns 0 or

@@ -921,13 +921,18 @@ extern "C" size_t ss_stwo_write_shared_text(const ss_stwo_cfg *c, const uint32_t
                                             char *buf, size_t cap)
 {
     if (!cfg_ok(c) || !shared) { set_err(SS_ERR_ARG, "bad argument"); return 0; }
-    std::string out;
-    if (!stwo_write_json_shared(*c, shared, words, python_separators ? kStylePython : kStyleCompact, out)) {
-        set_err(SS_ERR_ARG, "not a shared record of this config (or a pow_target no proof.json can declare)");
+    try {
+        std::string out;
+        if (!stwo_write_json_shared(*c, shared, words, python_separators ? kStylePython : kStyleCompact, out)) {
+            set_err(SS_ERR_ARG, "not a shared record of this config (or a pow_target no proof.json can declare)");
+            return 0;
+        }
+        if (buf && out.size() <= cap) memcpy(buf, out.data(), out.size());
+        return out.size();
+    } catch (const std::exception &) {
+        set_err(SS_ERR_NOMEM, "out of host memory");
         return 0;
     }
-    if (buf && out.size() <= cap) memcpy(buf, out.data(), out.size());
-    return out.size();
 }
 
 extern "C" int ss_stwo_text_is_canonical(const ss_stwo_cfg *c, const char *text, size_t len, int fmt, uint32_t *record_out)

@@ -238,7 +238,7 @@ extern "C" int ss_stwo_expand_shared_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size
 // Host shared records -> verdicts.  The twin of ss_stwo_verify_records with 9-21 % fewer bytes on the link: the
 // variable-length records go back to back into pinned staging (streaming stores), each chunk is uploaded with its
 // offset table behind it, expanded, re-tiled and verified on the second stream while the next chunk uploads.
-extern "C" int ss_stwo_verify_shared_records(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const uint32_t *const *shared,
+static int verify_shared_records_impl(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const uint32_t *const *shared,
                                              const size_t *words, uint32_t *status_host)
 {
     if (!ctx || !status_host || !shared || !words) return set_err(SS_ERR_ARG, "null argument");
@@ -335,4 +335,14 @@ extern "C" int ss_stwo_verify_shared_records(ss_ctx *ctx, const ss_stwo_cfg *c, 
     HIP_TRY(e1);
     HIP_TRY(e2);
     return SS_OK;
+}
+
+extern "C" int ss_stwo_verify_shared_records(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const uint32_t *const *shared,
+                                             const size_t *words, uint32_t *status_host)
+{
+    try {  // (std::vector / std::function allocations: a std::bad_alloc must not cross the C ABI -- ADVICE r4)
+        return verify_shared_records_impl(ctx, c, n, shared, words, status_host);
+    } catch (const std::exception &) {
+        return set_err(SS_ERR_NOMEM, "out of host memory");
+    }
 }

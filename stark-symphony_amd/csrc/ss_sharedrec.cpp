@@ -69,7 +69,7 @@ extern "C" int ss_stwo_share_record(const ss_stwo_cfg *c, const uint32_t *rec, c
     const SharedMap m = shared_map(N, L, Q, K);
     const PerQueryMap r(N, L, Q, K);
     SharedPlan p;
-    if (!shared_plan(m, queries, p)) return 1;
+    if (!shared_plan(m, queries, p)) return set_err(SS_ERR_ARG, "query position outside the LDE domain");  // (a caller error, as in ss_stwo_shared_counts: not "no shared form")
     size_t total = m.nodes;
     for (uint32_t t = 0; t < K + 3; t++) total += 8 * (size_t)p.base[t][Q];
     *words_out = total;

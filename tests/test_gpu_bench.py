@@ -54,7 +54,8 @@ def test_bench_two_ranks_share_one_gpu():
     # host's cores divided between the ranks, what each rank moved over its link reported
     e = d["e2e"]
     assert e["ranks"] == 2 and e["proofs"] == 301 and e["host_threads_per_rank"] >= 2
-    for kind in ("json", "wit", "json_shared", "records", "shared_records"):
+    for kind in ("json", "wit", "json_shared", "records", "shared_records", "minimal_records", "records_pinned",
+                 "shared_records_pinned", "minimal_records_pinned"):
         assert e[kind]["proofs_per_s"] > 0 and len(e[kind]["per_rank_link_GB_s"]) == 2, kind
     assert e["json"]["host_threads"] == e["host_threads_per_rank"] and e["json_shared"]["host_parsed_texts"] == 0
     assert e["shared_records"]["bytes_per_proof"] < e["records"]["bytes_per_proof"]
@@ -204,6 +205,47 @@ def test_rccl_two_ranks_verify_sharded_and_bench(tmp_path):
         d = _last_json(r.stdout)
         assert d["n_gpus"] == 2 and d["config"]["proofs_per_gpu"] == 2048 and d["config"]["proofs_per_step"] == 4096
         assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+        _check_multi_rank_line(d, 2, "nccl")
+
+
+def _check_multi_rank_line(d: dict, n: int, backend: str) -> None:
+    """What the driver's first real N > 1 run must carry (SCALE_rNN.json is built from these lines): the roofline of the
+    dominant kernel from the timed steps, how the accept count is reduced and over which backend, and what every rank
+    moved over its own host link in the e2e section, for the staged and the caller-pinned entry points."""
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and rf["achieved"] > 0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["kernel_launches"] >= d["steps"]
+    assert d["config"]["accept_reduce"].startswith("all-reduce(SUM) of every step's accept count over " + backend)
+    assert d["scaling"] in ("strong", "weak") and "cpu_baseline" not in d
+    e = d["e2e"]
+    assert e["ranks"] == n and "errors" not in e
+    for kind in ("json", "wit", "json_shared", "records", "shared_records", "minimal_records",
+                 "records_pinned", "shared_records_pinned", "minimal_records_pinned"):
+        assert e[kind]["proofs_per_s"] > 0 and len(e[kind]["per_rank_link_GB_s"]) == n, kind
+    assert e["minimal_records"]["bytes_per_proof"] < e["shared_records"]["bytes_per_proof"] < e["records"]["bytes_per_proof"]
+
+
+def test_two_ranks_on_one_gpu_over_nccl_or_the_documented_refusal():
+    """`bench.py --gpus 2 --scaling strong` with BOTH ranks on the one GPU of the test box over the nccl backend.  RCCL
+    either accepts two communicator ranks on one device -- then the line is checked like the first real multi-GPU run
+    will be -- or refuses them ("Duplicate GPU detected", ncclInvalidUsage: what DESIGN.md section 7 documents), in which
+    case the launcher must report that rank's own words and the same command over gloo must work."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SS_BENCH_SHARE_GPU="1", SS_BENCH_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scaling", "strong", "--workload", "stwo_fixture",
+           "--batch", "2048", "--steps", "4", "--warmup", "1", "--e2e", "128"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    if r.returncode == 0:
+        d = _last_json(r.stdout)
+        assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["proofs_per_step"] == 2048
+        _check_multi_rank_line(d, 2, "nccl")
+        return
+    text = r.stderr.lower()
+    assert "end of its stderr" in text and ("duplicate gpu" in text or "invalid usage" in text or "ncclinvalidusage" in text), r.stderr[-3000:]
+    env["SS_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    _check_multi_rank_line(_last_json(r.stdout), 2, "gloo")
 
 
 def test_bench_refuses_a_world_size_that_disagrees_with_gpus():

@@ -128,7 +128,8 @@ def test_records_without_a_shared_form():
     short.cp_paths[3] = short.cp_paths[3][:-1]
     with pytest.raises(ValueError):
         verifier.stwo_shared_record(short, qs)
-    with pytest.raises(ValueError):
+    from stark_symphony_amd import binding
+    with pytest.raises(binding.SsError):  # a position outside the LDE domain is the caller's error (SS_ERR_ARG), not "no shared form"
         verifier.stwo_shared_record(p, [1 << p.cfg.lde_log] + qs[1:])
 
 

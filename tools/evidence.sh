@@ -11,19 +11,27 @@ SECTIONS=${*:-bench configs stats pmc e2e host sha prover fuzz}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
 want() { [[ " $SECTIONS " == *" $1 "* ]]; }
+FAILED=0
+ok() { local rc=$?; echo "$1 rc=$rc"; [ $rc -eq 0 ] || FAILED=$((FAILED + 1)); }
+# the runtime reads this when it initialises -- under rocprofv3 that is before bench.py's own setdefault runs, so the profiler
+# passes would otherwise see 4 hardware queues and another stream-to-queue mapping than the benchmark
+export GPU_MAX_HW_QUEUES=24
+# what was measured: the digest of the kernel sources of THIS tree (the GPU box's copy), for tools/profiles.py to stamp the
+# profiles with -- not the digest of whatever tree the summary is later made in
+python3 -c "import bench, json; json.dump({'kernel_sources_sha256': bench.kernel_sources_digest()}, open('$O/measured_tree.json', 'w'))"
 B="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --inflight 1 --distinct 0 --e2e 0 --tail-streams 1"
 
 if want bench; then
-  python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "default rc=$?"
+  python bench.py > $O/bench_default.json 2> $O/bench_default.err; ok default
 fi
 if want configs; then
   for w in stwo_2p16 stwo_2p16_blake2s stwo_wide256 stwo_wide256_blake2s stwo_2p20_blake2s stwo_fixture; do
-    python bench.py --workload $w --steps 60 --warmup 6 --cpu-seconds 4 --e2e 1024 > $O/bench_$w.json 2> $O/bench_$w.err; echo "bench $w rc=$?"
+    python bench.py --workload $w --steps 60 --warmup 6 --cpu-seconds 4 --e2e 1024 > $O/bench_$w.json 2> $O/bench_$w.err; ok "bench $w"
   done
   python bench.py --steps 40 --warmup 4 --no-cpu-baseline --no-dedup --e2e 0 > $O/bench_stwo_2p20_nodedup.json 2> $O/bench_nodedup.err
   python bench.py --proofs-per-gpu 8192 --steps 200 --warmup 6 --no-cpu-baseline --e2e 0 > $O/bench_stwo_2p20_8192.json 2> $O/bench_8192.err
   python bench.py --proofs-per-gpu 8192 --steps 200 --warmup 6 --no-cpu-baseline --e2e 0 --tail-streams 1 > $O/bench_stwo_2p20_8192_ts1.json 2>> $O/bench_8192.err
-  python bench.py --workload stark101 --steps 1920 --warmup 6 --cpu-seconds 3 > $O/bench_stark101_4096.json 2> $O/bench_stark101.err; echo "stark101 rc=$?"
+  python bench.py --workload stark101 --steps 1920 --warmup 6 --cpu-seconds 3 > $O/bench_stark101_4096.json 2> $O/bench_stark101.err; ok stark101
   python bench.py --workload stark101 --proofs-per-gpu 8192 --steps 960 --warmup 6 --no-cpu-baseline --e2e 0 > $O/bench_stark101_8192.json 2>> $O/bench_stark101.err
 fi
 if want sha; then
@@ -38,7 +46,7 @@ if want host; then
   done
 fi
 if want e2e; then
-  python tools/e2e_bench.py --n 4096 --reps 4 --fmt all --files > $O/e2e_4096.json 2> $O/e2e.err; echo "e2e rc=$?"
+  python tools/e2e_bench.py --n 4096 --reps 4 --fmt all --files > $O/e2e_4096.json 2> $O/e2e.err; ok e2e
   python tools/e2e_bench.py --n 4096 --reps 3 --fmt all --noncanonical 0.01 > $O/e2e_4096_nc1.json 2>> $O/e2e.err
   python tools/e2e_bench.py --n 512 --reps 4 --fmt all > $O/e2e_512.json 2>> $O/e2e.err
   python tools/e2e_bench.py --n 4096 --reps 3 --fmt json --python-separators > $O/e2e_4096_pysep.json 2>> $O/e2e.err
@@ -49,22 +57,22 @@ if want prover; then
   python tools/prover101_bench.py >> $O/prover_bench.txt 2>&1
 fi
 if want fuzz; then
-  python tools/fuzz_parity.py 20000 20261004 > $O/fuzz_parity.txt 2>&1; echo "fuzz rc=$?"
-  python tools/text_fuzz.py 4000 20261004 > $O/text_fuzz.txt 2>&1; echo "text fuzz rc=$?"
-  python tools/shape_sweep.py 100 4 > $O/shape_sweep.txt 2>&1; echo "shape sweep rc=$?"
+  python tools/fuzz_parity.py 20000 20261004 > $O/fuzz_parity.txt 2>&1; ok fuzz
+  python tools/text_fuzz.py 4000 20261004 > $O/text_fuzz.txt 2>&1; ok "text fuzz"
+  python tools/shape_sweep.py 100 4 > $O/shape_sweep.txt 2>&1; ok "shape sweep"
 fi
 # the profiler passes last, from /tmp (rocprofv3 writes beside its working directory); the program itself after `--`
 cd /tmp; export TMPDIR=/tmp
 if want stats; then
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline --e2e 0 > $O/stats.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline --e2e 0 > $O/stats.log 2>&1; ok stats
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_e2e -- python3 $R/tools/e2e_bench.py --n 4096 --reps 2 --fmt all > $O/stats_e2e.log 2>&1
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_prover -- python3 $R/tools/prover_bench.py 20 3 sha256 > $O/stats_prover.log 2>&1
 fi
 if want pmc; then  # counters in their own runs, one set per pass (MI355X_MICROARCH.md)
-  rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $O/pmc_valu -- $B > $O/pmc_valu.log 2>&1
-  rocprofv3 --pmc SQ_WAVES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_wait -- $B > $O/pmc_wait.log 2>&1
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- $B > $O/pmc_fetch.log 2>&1
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- $B > $O/pmc_write.log 2>&1
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $O/pmc_valu -- $B > $O/pmc_valu.log 2>&1; ok pmc_valu
+  rocprofv3 --pmc SQ_WAVES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_wait -- $B > $O/pmc_wait.log 2>&1; ok pmc_wait
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- $B > $O/pmc_fetch.log 2>&1; ok pmc_fetch
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- $B > $O/pmc_write.log 2>&1; ok pmc_write
   E="python3 $R/tools/e2e_bench.py --n 1024 --reps 1 --fmt all"
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_e2e -- $E > $O/pmc_fetch_e2e.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_e2e -- $E > $O/pmc_write_e2e.log 2>&1
@@ -97,4 +105,5 @@ PY
 [ -f $O/fuzz_parity.txt ] && tail -1 $O/fuzz_parity.txt
 [ -f $O/text_fuzz.txt ] && tail -1 $O/text_fuzz.txt
 [ -f $O/shape_sweep.txt ] && tail -1 $O/shape_sweep.txt
-exit 0
+echo "sections that failed: $FAILED"
+[ $FAILED -eq 0 ]

@@ -28,10 +28,19 @@ def want(section):
 G = os.path.join(ROOT, "gpurun_out", TAG)
 P = os.path.join(ROOT, "profiles")
 commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=ROOT).stdout.strip()
-digest = bench.kernel_sources_digest()
-dirty = subprocess.run(["git", "status", "--porcelain", "--", "stark-symphony_amd/csrc"], capture_output=True, text=True, cwd=ROOT).stdout.strip()
-if dirty:
-    print("warning: csrc/ has uncommitted changes; the profiles are stamped with the digest of the working tree")
+# The digest the profiles are stamped with is the one evidence.sh computed ON THE GPU BOX, over the sources it measured
+# (gpurun_out/<tag>/measured_tree.json) -- never the digest of the tree this script happens to run in: if csrc changed
+# between the GPU run and this summary, the counters stay tied to the old sources and bench.py stops using them.
+local_digest = bench.kernel_sources_digest()
+try:
+    digest = json.load(open(os.path.join(G, "measured_tree.json")))["kernel_sources_sha256"]
+except (OSError, ValueError, KeyError):
+    raise SystemExit("gpurun_out/%s/measured_tree.json is missing: evidence.sh writes it; without it the profiles cannot be "
+                     "tied to the sources they were measured on" % TAG)
+if digest != local_digest:
+    print("WARNING: the measured tree's kernel sources (%s...) are not this tree's (%s...): the profiles are stamped with the "
+          "MEASURED digest and commit 'unknown'; bench.py will not use their counter figures for this tree" % (digest[:12], local_digest[:12]))
+    commit = "unknown (kernel sources differ from %s)" % commit
 
 
 def one(pattern):
