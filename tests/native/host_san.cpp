@@ -23,6 +23,7 @@
 #include "ss_ingest.h"
 #include "ss_pack.h"
 #include "ss_pool.h"
+#include "ss_minimal.h"
 #include "ss_shared.h"
 #include "ss_text.h"
 
@@ -231,6 +232,80 @@ int main(int argc, char **argv)
         }
     }
 
+    // ---- minimal records (csrc/ss_minimalrec.cpp, ss_text.cpp, ss_ingest.cpp): minimise through exact-size buffers on random
+    // shapes and positions (uniform, clustered, equal), the minimal text writer, the host reader on the text and on mutants
+    // of it, the writer on structure mutants of the record
+    size_t minimal_read = 0;
+    for (const auto &sh : shapes) {
+        const ss_stwo_cfg c = make_cfg(sh[0], sh[1], sh[2], sh[3], sh[4], 0, 0);
+        const size_t Wc = ss_stwo_record_words(&c), cap = ss_stwo_minimal_max_words(&c), fixed = ss_stwo_minimal_fixed_words(&c);
+        const uint32_t N = c.n_cols, L = c.lde_log, Q = c.n_queries, K = c.n_layers;
+        for (int rep = 0; rep < 6; rep++) {
+            std::vector<uint32_t> qs(Q);
+            const uint32_t base_pos = rnd() & ((1u << L) - 1);
+            for (auto &q : qs) q = rep % 3 == 0 ? (rnd() & ((1u << L) - 1)) : rep % 3 == 1 ? (base_pos ^ (rnd() & 7 & ((1u << L) - 1))) : base_pos;
+            // a record whose queries agree wherever they present the same thing: every word a function of (what, level, position)
+            uint32_t *rec = new uint32_t[Wc];
+            for (size_t i = 0; i < Wc; i++) rec[i] = rnd() | 1u;
+            const uint32_t head = 24 + 4 * N + 64 + 8 * (K + 1) + 6, qstride = N + 16 + 16 * L;
+            for (uint32_t q = 0; q < Q; q++)
+                for (uint32_t k = 0; k < N + 16; k++) rec[head + q * qstride + k] = (qs[q] * 2246822519u) ^ (k * 3266489917u);
+            uint32_t fo = head + Q * qstride;
+            for (uint32_t t = 0; t < K + 3; t++) {
+                const uint32_t len = t < 2 ? L : L + 1 - t, shift = t < 2 ? 0 : t - 1;
+                for (uint32_t q = 0; q < Q; q++) {
+                    if (t >= 2)
+                        for (uint32_t w = 0; w < 4; w++) rec[fo + q * (4 + 8 * len) + w] = (((qs[q] >> (t - 2)) ^ 1) * 668265263u) ^ (t * 31u + w);
+                    for (uint32_t lvl = 0; lvl < len; lvl++) {
+                        uint32_t *dst = t < 2 ? rec + head + q * qstride + N + 16 + t * 8 * L + 8 * lvl : rec + fo + q * (4 + 8 * len) + 4 + 8 * lvl;
+                        const uint32_t pos = ((qs[q] >> shift) >> lvl) ^ 1;
+                        for (uint32_t w = 0; w < 8; w++) dst[w] = (pos * 2654435761u) ^ (t * 40503u + lvl * 97u + w) ^ 0x9e3779b9u;
+                    }
+                }
+                if (t >= 2) fo += Q * (4 + 8 * len);
+            }
+            for (uint32_t t = 0; t < K + 3; t++)
+                for (uint32_t q = 0; q < Q; q++) rec[fo + t * Q + q] = t < 2 ? L : L + 1 - t;
+            size_t words = 0;
+            std::vector<uint32_t> big(cap);
+            if (ss_stwo_minimise_record(&c, rec, qs.data(), big.data(), cap, &words) != 0 || words < fixed || words > cap) { fprintf(stderr, "minimise failed\n"); return 1; }
+            uint32_t *mr = new uint32_t[words];  // exact size
+            memcpy(mr, big.data(), words * 4);
+            if (words > 1 && ss_stwo_minimise_record(&c, rec, qs.data(), big.data(), words - 1, &words) >= 0) { fprintf(stderr, "short capacity accepted\n"); return 1; }
+            std::vector<uint32_t> counts(2 + (K + 1) + (K + 3));
+            if (ss_stwo_minimal_counts(&c, qs.data(), counts.data()) != 0 || memcmp(counts.data(), mr + fixed - counts.size(), counts.size() * 4) != 0) { fprintf(stderr, "counts differ from the record's\n"); return 1; }
+            std::string text;
+            if (!ss::stwo_write_json_minimal(c, mr, words, rep & 1 ? ss::kStylePython : ss::kStyleCompact, text)) { fprintf(stderr, "no minimal text\n"); return 1; }
+            std::vector<uint32_t> back;
+            if (ss::stwo_parse_minimal_text(c, text.data(), text.size(), back) != ss::kParsed || back.size() != words || memcmp(back.data(), mr, words * 4) != 0) { fprintf(stderr, "minimal text does not read back\n"); return 1; }
+            for (int i = 0; i < mutants / 20; i++) {
+                const std::string mt = mutate(text);
+                char *exact = new char[mt.size() ? mt.size() : 1];
+                memcpy(exact, mt.data(), mt.size());
+                minimal_read += ss::stwo_parse_minimal_text(c, exact, mt.size(), back) == ss::kParsed;
+                delete[] exact;
+                checks++;
+            }
+            for (int m = 0; m < 40; m++) {  // structure mutants of the record into the writer: any size, any counts
+                size_t mw = words;
+                std::vector<uint32_t> mut(mr, mr + words);
+                switch (rnd() % 4) {
+                case 0: mw = rnd() % (words + 1); break;
+                case 1: mut[fixed - counts.size() + rnd() % counts.size()] += 1 + rnd() % 3; break;
+                case 2: mut[fixed - counts.size() + rnd() % counts.size()] = rnd(); break;
+                default: mut.resize(words + 1 + rnd() % 9, 7); mw = mut.size(); break;
+                }
+                uint32_t *exact = new uint32_t[mw ? mw : 1];
+                memcpy(exact, mut.data(), mw * 4);
+                (void)ss::stwo_write_json_minimal(c, exact, mw, ss::kStyleCompact, text);
+                delete[] exact;
+                checks++;
+            }
+            delete[] mr;
+            delete[] rec;
+        }
+    }
+
     // ---- the worker pool (csrc/ss_pool.cpp): an exception in an item fails the call on the CALLING thread and leaves the
     // pool usable; a fork()ed child (no worker threads of its own) runs items inline and exits without touching the pool
     {
@@ -259,6 +334,6 @@ int main(int argc, char **argv)
         if (waitpid(child, &st, 0) != child || !WIFEXITED(st) || WEXITSTATUS(st) != 0) { fprintf(stderr, "pool: forked child failed (%d)\n", st); return 1; }
         checks += 3;
     }
-    printf("host_san: %zu checks, %zu mutants taken by the scalar rule, %zu shared-text mutants\n", checks, taken, shared_taken);
+    printf("host_san: %zu checks, %zu mutants taken by the scalar rule, %zu shared-text mutants, %zu minimal-text mutants read\n", checks, taken, shared_taken, minimal_read);
     return 0;
 }

@@ -22,7 +22,7 @@ ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPT
 def test_packers_writers_and_the_reader_rule_under_sanitizers(tmp_path):
     exe = str(tmp_path / "host_san")
     subprocess.run(["g++", "-std=c++17"] + SAN + ["-I" + CSRC, os.path.join(NATIVE, "host_san.cpp")]
-                   + [os.path.join(CSRC, f) for f in ("ss_pack.cpp", "ss_text.cpp", "ss_pool.cpp", "ss_ingest.cpp", "ss_sharedrec.cpp")]
+                   + [os.path.join(CSRC, f) for f in ("ss_pack.cpp", "ss_text.cpp", "ss_pool.cpp", "ss_ingest.cpp", "ss_sharedrec.cpp", "ss_minimalrec.cpp")]
                    + ["-o", exe, "-lpthread"], check=True)
     r = subprocess.run([exe, "20261003", "1500", os.path.join(GOLDEN, "stwo_proof.json"),
                         os.path.join(GOLDEN, "formats", "stwo_proof.wit")], capture_output=True, text=True, env=ENV, timeout=900)
