@@ -154,6 +154,29 @@ def main():
             print("stwo %-16s shared records: %d of the mutants have a shared form, %d structure mutants (%d refused), mismatches %d"
                   % (name, len(keep), len(sm), sum(1 for e in exp if e == 2), mism), flush=True)
             bad += mism
+        # MINIMAL records (one sorted, deduplicated decommitment per tree, verified without expansion: round 5): the mutants
+        # that still have a minimal form (a mutation of a sibling the form drops leaves the honest record: accepted), and
+        # mutants of the honest minimal record itself (bit flips, lists one element short / long, sizes); both modes,
+        # against the oracle's layer-by-layer walk
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from test_minimal import corrupt_minimal
+        qs = formats.stwo_queries(base)
+        mins = []
+        for m in muts[:max(1, N // 4)]:
+            try:
+                mins.append(verifier.stwo_minimise_record(base.cfg, verifier.stwo_record(m), formats.stwo_queries(m)))
+            except ValueError:
+                pass
+        honest = verifier.stwo_minimise_record(base.cfg, verifier.stwo_record(base), qs)
+        mins += [corrupt_minimal(honest, base.cfg, rng)[0] for _ in range(N_STRUCT)]
+        mism = 0
+        for mode in (verifier.MODE_FIXTURE, verifier.MODE_LITERAL):
+            got = ver.verify_stwo_minimal_records(base.cfg, mins, mode)
+            want = np.array([O.stwo_verify_minimal(base.cfg, r, mode) for r in mins], dtype=np.uint32)
+            mism += int((got != want).sum())
+        print("stwo %-16s minimal records: %d mutants (%d accepted, %d refused), both modes, mismatches %d"
+              % (name, len(mins), int((want == 0).sum()), int((want == 2).sum()), mism), flush=True)
+        bad += mism
     print("TOTAL mismatches:", bad)
     sys.exit(1 if bad else 0)
 
