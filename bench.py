@@ -481,8 +481,6 @@ def main() -> None:
                          "'on' = hipGraph replay of independent slots; kernel durations for the roofline then "
                          "come from a separate pipelined pass.  'off' = the HEAD/TAIL pipeline")
     ap.add_argument("--streams", type=int, default=16, help="independent streams of --graph streams")
-    ap.add_argument("--split-tail", action="store_true",
-                    help="SS_FLAG_SPLIT_TAIL: the Merkle stage as its two kernels (merkle, top) instead of the fused persistent one (A/B)")
     ap.add_argument("--no-dedup", action="store_true",
                     help="SS_FLAG_NO_DEDUP: hash every query's Merkle path in full (A/B of the pair memoisation)")
     args = ap.parse_args()
@@ -537,8 +535,6 @@ def main() -> None:
     ver = verifier.Verifier(dev_index)
     if args.no_dedup:
         ver.stwo_flags = verifier.FLAG_NO_DEDUP
-    if args.split_tail:
-        ver.stwo_flags |= verifier.FLAG_SPLIT_TAIL
 
     if family == "stwo" and args.distinct > len(proofs) and wname != "stwo_fixture":
         # More distinct valid proofs of the same configuration, made on this GPU by the prover
@@ -749,9 +745,6 @@ def main() -> None:
             k_avg_s += (t_ms / max(t_n, 1)) * 1e-3
             if t_n:
                 dominant = "stwo_merkle+stwo_top"
-            f_ms, f_n = timing.get("stwo_tail", (0.0, 0))
-            if f_n:  # the fused kernel: merkle phase + top phase of every group in one persistent launch
-                k_avg_s, k_n, dominant = (f_ms / f_n) * 1e-3, f_n, "stwo_tail"
             # compressions the kernels really execute: the reference's count minus the pairs memoised,
             # exact for this batch (from the queries of its distinct proofs)
             per_node = 1 if cfg.hash == "blake2s" else 2

@@ -114,10 +114,6 @@ typedef struct ss_stwo_cfg {
  * query count divides 64, they are made by the merkle kernel (a proof's chains are lanes of one wavefront there);
  * other query counts always take the top-kernel path.  Same status words; for A/B runs and tests.             */
 #define SS_FLAG_TOP_CHECKS 2u
-/* SS_FLAG_SPLIT_TAIL: run the Merkle stage as its two kernels (merkle, then top) even where the library would fuse them
- * into one persistent kernel whose blocks run both phases group by group (the default whenever a 256-chain group of the
- * top levels is made of whole 64-chain tiles: every BASELINE config).  Same status words; for A/B runs and tests.  */
-#define SS_FLAG_SPLIT_TAIL 4u
 
 /* SS_HASH_SHA256 is the reference (hasher.simf:13-104, channel.simf:36-172).  SS_HASH_BLAKE2S is
  * the "Blake2s Merkle" variant BASELINE.json names: the same protocol over the same byte

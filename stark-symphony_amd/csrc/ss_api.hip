@@ -64,10 +64,10 @@ static const void *top_kernel(int hf, int hash_only)
                      : (hf ? (const void *)stwo_top_kernel_b2s : (const void *)stwo_top_kernel_sha);
 }
 
-static int top_blocks_per_cu(int hf, int hash_only, const void *fn_override = nullptr)
+static int top_blocks_per_cu(int hf, int hash_only)
 {
     hipFuncAttributes a;
-    const void *fn = fn_override ? fn_override : top_kernel(hf, hash_only);
+    const void *fn = top_kernel(hf, hash_only);
     int per_cu = 4;
     if (hipFuncGetAttributes(&a, fn) == hipSuccess && a.numRegs > 0) {
         const int by_regs = 512 / ((a.numRegs + 7) / 8 * 8);
@@ -96,8 +96,6 @@ extern "C" int ss_ctx_create(int device, ss_ctx **out)
     c->cus = prop.multiProcessorCount;
     for (int hf = 0; hf < 2; hf++)
         for (int ho = 0; ho < 2; ho++) c->top_blocks_per_cu[hf][ho] = top_blocks_per_cu(hf, ho);
-    c->tail_blocks_per_cu[0] = top_blocks_per_cu(0, 1, (const void *)stwo_tail_kernel_sha);
-    c->tail_blocks_per_cu[1] = top_blocks_per_cu(1, 1, (const void *)stwo_tail_kernel_b2s);
     *out = c;
     return SS_OK;
 }
@@ -242,47 +240,29 @@ static int stwo_tail(ss_ctx *ctx, const ss_stwo_cfg *c, const StwoLayout &y, con
     // the top kernel's group counter, its count of flagged trees and -- when the merkle kernel makes the byte
     // compares (y.mchk) -- the flags it raises, which lie directly behind
     if (y.T) HIP_TRY(hipMemsetAsync(ws + y.ws_counter, 0, y.mchk ? (y.ws_plan - y.ws_counter) * 4 : 8, s));
+    t.begin();
     const int hf = c->hash == SS_HASH_BLAKE2S;
-    // One kernel for the whole stage when a group of the top levels is made of whole 64-chain tiles (every BASELINE config:
-    // Q divides 64 and the batch is large enough for groups of 256 chains): each persistent block runs the merkle phase of
-    // the group it has taken and then its top levels (stwo_tail_kernel_*, ss_stwo.hip).  SS_FLAG_SPLIT_TAIL keeps the two
-    // launches (A/B runs, tests); other shapes and minimal records always take them.
-    const bool fused = y.T && y.mchk && !y.minimal && y.top_G * y.Q == kTopChains && (y.top_G & 3) == 0 && !(c->flags & SS_FLAG_SPLIT_TAIL);
-    if (fused) {
+    if (y.minimal)
+        hipLaunchKernelGGL(hf ? stwo_merkle_min_kernel_b2s : stwo_merkle_min_kernel_sha, dim3((tiles + 3) / 4), dim3(256), 0, s, y,
+                           batch, ws, status);
+    else
+        hipLaunchKernelGGL(hf ? stwo_merkle_kernel_b2s : stwo_merkle_kernel_sha, dim3((tiles + 3) / 4), dim3(256), 0, s, y, batch,
+                           ws, status);
+    t.end("stwo_merkle");
+    if (y.T) {
         t.begin();
-        const uint32_t blocks = std::min<uint32_t>(y.top_blocks, (uint32_t)(ctx->tail_blocks_per_cu[hf] * std::min(ctx->cus, 256)));
+        const int ho = y.mchk != 0;
+        const uint32_t blocks = std::min<uint32_t>(y.top_blocks, (uint32_t)(ctx->top_blocks_per_cu[hf][ho] * std::min(ctx->cus, 256)));
         void *args[] = {(void *)&y, (void *)&batch, (void *)&ws, (void *)&status};
-        HIP_TRY(hipLaunchKernel(hf ? (const void *)stwo_tail_kernel_b2s : (const void *)stwo_tail_kernel_sha, dim3(blocks), dim3(kTopChains),
-                                args, 0, s));
-        t.end("stwo_tail");
+        // (behind minimal records the hash-only variant that takes computed siblings from their leaders: same footprint)
+        const void *fn = y.minimal ? (hf ? (const void *)stwo_top_min_kernel_b2s : (const void *)stwo_top_min_kernel_sha) : top_kernel(hf, ho);
+        HIP_TRY(hipLaunchKernel(fn, dim3(blocks), dim3(kTopChains), args, 0, s));
+        t.end("stwo_top");
+        // trees in which queries disagree about a node (none in an honest batch: the grid reads one word and leaves)
         t.begin();
-        hipLaunchKernelGGL(hf ? stwo_top_cold_kernel_b2s : stwo_top_cold_kernel_sha, dim3(4 * ctx->cus), dim3(256), 0, s, y, batch,
-                           (const uint32_t *)ws, status);
+        hipLaunchKernelGGL(hf ? stwo_top_cold_kernel_b2s : stwo_top_cold_kernel_sha, dim3(4 * ctx->cus), dim3(256), 0, s,
+                           y, batch, (const uint32_t *)ws, status);
         t.end("stwo_top_cold");
-    } else {
-        t.begin();
-        if (y.minimal)
-            hipLaunchKernelGGL(hf ? stwo_merkle_min_kernel_b2s : stwo_merkle_min_kernel_sha, dim3((tiles + 3) / 4), dim3(256), 0, s, y,
-                               batch, ws, status);
-        else
-            hipLaunchKernelGGL(hf ? stwo_merkle_kernel_b2s : stwo_merkle_kernel_sha, dim3((tiles + 3) / 4), dim3(256), 0, s, y, batch,
-                               ws, status);
-        t.end("stwo_merkle");
-        if (y.T) {
-            t.begin();
-            const int ho = y.mchk != 0;
-            const uint32_t blocks = std::min<uint32_t>(y.top_blocks, (uint32_t)(ctx->top_blocks_per_cu[hf][ho] * std::min(ctx->cus, 256)));
-            void *args[] = {(void *)&y, (void *)&batch, (void *)&ws, (void *)&status};
-            // (behind minimal records the hash-only variant that takes computed siblings from their leaders: same footprint)
-            const void *fn = y.minimal ? (hf ? (const void *)stwo_top_min_kernel_b2s : (const void *)stwo_top_min_kernel_sha) : top_kernel(hf, ho);
-            HIP_TRY(hipLaunchKernel(fn, dim3(blocks), dim3(kTopChains), args, 0, s));
-            t.end("stwo_top");
-            // trees in which queries disagree about a node (none in an honest batch: the grid reads one word and leaves)
-            t.begin();
-            hipLaunchKernelGGL(hf ? stwo_top_cold_kernel_b2s : stwo_top_cold_kernel_sha, dim3(4 * ctx->cus), dim3(256), 0, s,
-                               y, batch, (const uint32_t *)ws, status);
-            t.end("stwo_top_cold");
-        }
     }
     t.begin();
     hipLaunchKernelGGL(stwo_finalize_kernel, dim3((y.n + 255) / 256), dim3(256), 0, s, y.n, status,

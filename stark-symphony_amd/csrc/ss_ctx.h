@@ -107,7 +107,6 @@ struct ss_ctx {
     int timing;
     int cus;                   // compute units of the device
     int top_blocks_per_cu[2][2];  // resident top-kernel blocks per CU: [hash family][0 = with the byte compares, 1 = hash only]
-    int tail_blocks_per_cu[2];    // ... of the fused TAIL kernel: [hash family]
     std::vector<ss::TimedSpan> spans;  // recorded since the last collect
     std::vector<hipEvent_t> pool;      // recycled events
     ss::HostPath hp;

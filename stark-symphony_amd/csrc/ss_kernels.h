@@ -19,8 +19,6 @@ __global__ void stwo_merkle_min_kernel_sha(StwoLayout lay, const uint32_t *batch
 __global__ void stwo_merkle_min_kernel_b2s(StwoLayout lay, const uint32_t *batch, uint32_t *ws, uint32_t *status);
 __global__ void stwo_top_min_kernel_sha(StwoLayout lay, const uint32_t *batch, uint32_t *ws, uint32_t *status);
 __global__ void stwo_top_min_kernel_b2s(StwoLayout lay, const uint32_t *batch, uint32_t *ws, uint32_t *status);
-__global__ void stwo_tail_kernel_sha(StwoLayout lay, const uint32_t *batch, uint32_t *ws, uint32_t *status);
-__global__ void stwo_tail_kernel_b2s(StwoLayout lay, const uint32_t *batch, uint32_t *ws, uint32_t *status);
 __global__ void stwo_top_cold_kernel_sha(StwoLayout lay, const uint32_t *batch, const uint32_t *ws, uint32_t *status);
 __global__ void stwo_top_cold_kernel_b2s(StwoLayout lay, const uint32_t *batch, const uint32_t *ws, uint32_t *status);
 __global__ void stwo_finalize_kernel(uint32_t n, uint32_t *status, uint32_t *accept_count);

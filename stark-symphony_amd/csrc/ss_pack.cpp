@@ -13,7 +13,7 @@ using namespace ss;
 
 bool ss::cfg_ok(const ss_stwo_cfg *c)
 {
-    return c && c->hash <= SS_HASH_BLAKE2S && c->flags <= (SS_FLAG_NO_DEDUP | SS_FLAG_TOP_CHECKS | SS_FLAG_SPLIT_TAIL) &&
+    return c && c->hash <= SS_HASH_BLAKE2S && c->flags <= (SS_FLAG_NO_DEDUP | SS_FLAG_TOP_CHECKS) &&
            stwo_cfg_ok(c->n_cols, c->trace_log, c->lde_log, c->n_queries, c->n_layers, c->mode);
 }
 // The layout of a batch and of its workspace is a function of (cfg, n) ONLY -- no process state: a caller may size

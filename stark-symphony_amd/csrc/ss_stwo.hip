@@ -477,15 +477,16 @@ stwo_query_kernel(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *
 // chains first, so the tail of the grid is made of the shortest ones).
 // MIN: the batch was filled from minimal records (ss_minimal.hip) -- its own instantiation, so that the per-query
 // kernels are the code they were.
-// SMALL: the instantiation inside the fused TAIL kernel (stwo_tail_kernel_*), where code size is what matters -- blocks of
-// one CU are in different phases, so everything the kernel can execute competes for the instruction cache: leaf hashes go
-// through the out-of-line compression and the pair of the two FRI leaf hashes runs as a first turn of the level loop, so
-// that the kernel holds ONE inlined pair hash for this phase.
-template <int HF, bool MIN = false, bool SMALL = false>
-__device__ __forceinline__ void stwo_merkle_tile(const StwoLayout &lay, const uint32_t *__restrict__ batch,
-                                                 uint32_t *__restrict__ ws, uint32_t *__restrict__ status,
-                                                 const uint32_t type, const uint32_t g, const uint32_t lane)
+template <int HF, bool MIN = false>
+__device__ __forceinline__ void stwo_merkle_body(const StwoLayout &lay, const uint32_t *__restrict__ batch,
+                                                 uint32_t *__restrict__ ws, uint32_t *__restrict__ status)
 {
+    const uint32_t tiles_per_type = lay.nip >> 6;
+    const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t type = tile / tiles_per_type;  // wave-uniform
+    if (type >= lay.K + 3) return;
+    const uint32_t g = tile - type * tiles_per_type;
+    const uint32_t lane = threadIdx.x & 63;
     const uint32_t inst = g * 64 + lane;
     const bool live = inst < lay.ni;
     const uint32_t p = live ? inst / lay.Q : 0, q = live ? inst - p * lay.Q : 0;
@@ -495,7 +496,6 @@ __device__ __forceinline__ void stwo_merkle_tile(const StwoLayout &lay, const ui
     const uint32_t query = ctx[(size_t)(lay.c_queries + q) * np + p];
 
     uint32_t node[8];  // native form
-    uint32_t first_sib[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // (SMALL: the second FRI leaf hash)
     uint32_t auth, len, root_w, code_base;
     const uint32_t *path;
     if (type < 2) {
@@ -503,7 +503,7 @@ __device__ __forceinline__ void stwo_merkle_tile(const StwoLayout &lay, const ui
         // hash_node_m31_trace / hash_node_m31_cp (hasher.simf:85-97): H of ncol value words
         const uint32_t ncol = type == 0 ? lay.N : kCp;
         const uint32_t *vals = batch + (type == 0 ? lay.off_trace_vals : lay.off_cp_vals) + inst;
-        Hasher<HF>::template stream<!SMALL, 0>(nullptr, [&](uint32_t i) { return vals[(size_t)i * nip]; }, ncol, node);
+        Hasher<HF>::template stream<true, 0>(nullptr, [&](uint32_t i) { return vals[(size_t)i * nip]; }, ncol, node);
         auth = query + shl32(lay.L, 1);
         len = lay.L;
         path = batch + (type == 0 ? lay.off_trace_path : lay.off_cp_path);
@@ -516,14 +516,9 @@ __device__ __forceinline__ void stwo_merkle_tile(const StwoLayout &lay, const ui
         uint32_t e0[4], e1[4], l0[8], l1[8];
 #pragma unroll
         for (int j = 0; j < 4; j++) { e0[j] = lf[(size_t)j * nip]; e1[j] = lf[(size_t)(4 + j) * nip]; }
-        Hasher<HF>::template block<!SMALL, 0, 4>(nullptr, e0, l0);  // hash_node_qm31 (hasher.simf:100-104)
-        Hasher<HF>::template block<!SMALL, 0, 4>(nullptr, e1, l1);
-        if (SMALL) {  // H(l0 || l1) is the level loop's first turn
-#pragma unroll
-            for (int j = 0; j < 8; j++) { node[j] = l0[j]; first_sib[j] = l1[j]; }
-        } else {
-            Hasher<HF>::template pair<true>(l0, l1, node);
-        }
+        Hasher<HF>::template block<true, 0, 4>(nullptr, e0, l0);  // hash_node_qm31 (hasher.simf:100-104)
+        Hasher<HF>::template block<true, 0, 4>(nullptr, e1, l1);
+        Hasher<HF>::template pair<true>(l0, l1, node);
         const uint32_t logl = lay.L - l;
         const uint32_t position = (query >> l) & ~1u;
         auth = (position + shl32(logl, 1)) >> 1;
@@ -543,22 +538,15 @@ __device__ __forceinline__ void stwo_merkle_tile(const StwoLayout &lay, const ui
     const uint32_t min_shift = type < 2 ? 0 : type - 1;  // absolute level of the tree's first sibling (ss_minimal.h)
     uint4 s0 = make_uint4(0, 0, 0, 0), s1 = s0;
     if (n_lvl) { s0 = tp[0]; s1 = tp[64]; }
-    const uint32_t lead_in = SMALL && type >= 2 ? 1 : 0;  // (wave-uniform)
-    for (uint32_t it = 0; it < n_lvl + lead_in; it++) {
-        const bool pairing = SMALL && it < lead_in;  // the turn that pairs the two leaf hashes: no tile level is consumed
-        const uint32_t lvl = it - lead_in;
+    for (uint32_t lvl = 0; lvl < n_lvl; lvl++) {
         uint4 n0 = s0, n1 = s1;
-        if (!pairing && lvl + 1 < n_lvl) {  // prefetch the next level while this one is hashed
+        if (lvl + 1 < n_lvl) {  // prefetch the next level while this one is hashed
             n0 = tp[(size_t)(lvl + 1) * 128];
             n1 = tp[(size_t)(lvl + 1) * 128 + 64];
         }
         uint32_t sib[8] = {Hasher<HF>::native(s0.x), Hasher<HF>::native(s0.y), Hasher<HF>::native(s0.z),
                            Hasher<HF>::native(s0.w), Hasher<HF>::native(s1.x), Hasher<HF>::native(s1.y),
                            Hasher<HF>::native(s1.z), Hasher<HF>::native(s1.w)};
-        if (pairing) {
-#pragma unroll
-            for (int j = 0; j < 8; j++) sib[j] = first_sib[j];
-        }
         if (MIN) {
             // minimal records: a sibling that another query of the proof computes is not in the proof; that chain is a
             // lane of this wavefront and at the same level (same tree, lockstep), so its node is the sibling
@@ -572,7 +560,7 @@ __device__ __forceinline__ void stwo_merkle_tile(const StwoLayout &lay, const ui
                 }
             }
         }
-        const bool right = !pairing && (auth & 1);  // node is the right child: H(sibling || node)
+        const bool right = auth & 1;  // node is the right child: H(sibling || node)
         uint32_t lft[8], rgt[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -580,10 +568,8 @@ __device__ __forceinline__ void stwo_merkle_tile(const StwoLayout &lay, const ui
             rgt[j] = right ? node[j] : sib[j];
         }
         Hasher<HF>::template pair<true>(lft, rgt, node);
-        if (!pairing) {
-            auth >>= 1;
-            s0 = n0; s1 = n1;
-        }
+        auth >>= 1;
+        s0 = n0; s1 = n1;
     }
     if (!live) return;
     uint32_t fail = 0xffffffffu;
@@ -642,17 +628,6 @@ __device__ __forceinline__ void stwo_merkle_tile(const StwoLayout &lay, const ui
     if (fail != 0xffffffffu) atomicMin(&status[p], fail);
 }
 
-template <int HF, bool MIN = false>
-__device__ __forceinline__ void stwo_merkle_body(const StwoLayout &lay, const uint32_t *__restrict__ batch,
-                                                 uint32_t *__restrict__ ws, uint32_t *__restrict__ status)
-{
-    const uint32_t tiles_per_type = lay.nip >> 6;
-    const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const uint32_t type = tile / tiles_per_type;  // wave-uniform
-    if (type >= lay.K + 3) return;
-    stwo_merkle_tile<HF, MIN, false>(lay, batch, ws, status, type, tile - type * tiles_per_type, threadIdx.x & 63);
-}
-
 // ================================================================================= top
 // Merkle pair memoisation (the reference notes at fri/queries.simf:41 that it
 // does not deduplicate).  The Q queries of a proof index random leaves, so near the root their
@@ -708,11 +683,7 @@ __device__ __forceinline__ void stwo_merkle_body(const StwoLayout &lay, const ui
 #endif
 constexpr uint32_t kTopLights = SS_TOP_LIGHTS;  // light checks that ride along one pair hash
 
-// FUSED (stwo_tail_kernel_*): the block first runs the merkle phase of the group it has taken -- wave w the 64-chain tile w
-// of the group, tree kind after tree kind -- and then the top levels below, so the two phases of DIFFERENT blocks of a CU
-// overlap: the top phase's barriers and dependent loads hide behind other blocks' hashing, and there is no second launch
-// with its ramp and drain.  What is computed, and by which lane, is what the two kernels compute.
-template <int HF, bool LIGHTS, bool MIN = false, bool FUSED = false>
+template <int HF, bool LIGHTS, bool MIN = false>
 __device__ __forceinline__ void stwo_top_body(const StwoLayout &lay, const uint32_t *__restrict__ batch,
                                               uint32_t *__restrict__ ws, uint32_t *__restrict__ status)
 {
@@ -807,13 +778,6 @@ __device__ __forceinline__ void stwo_top_body(const StwoLayout &lay, const uint3
         p0 = s_grp * unit;
         const uint32_t gp = lay.n - p0 < s_take * unit ? lay.n - p0 : s_take * unit;  // proofs of this group
         const uint32_t nch = gp * Q, inst0 = p0 * Q;
-        if (FUSED) {  // (the launch guarantees unit * Q == 64: a group starts on a tile boundary, a unit is one tile)
-            if (wave < ((nch + 63) >> 6))
-                for (uint32_t type = 0; type < n_types; type++)
-                    stwo_merkle_tile<HF, false, true>(lay, batch, ws, status, type, (inst0 >> 6) + wave, lane);
-            __threadfence_block();  // entering nodes and flags: written by this block's waves, read below by all of them
-            __syncthreads();
-        }
         if (tid < nch) {
             const uint32_t g = tid / Q, q = tid - g * Q;
             s_query[tid] = ws[lay.ws_ctx + (size_t)(lay.c_queries + q) * np + p0 + g];
@@ -1164,22 +1128,6 @@ stwo_top_hash_kernel_b2s(StwoLayout lay, const uint32_t *__restrict__ batch, uin
     stwo_top_body<1, false>(lay, batch, ws, status);
 }
 
-// the fused TAIL kernel (merkle phase + top phase per group; lay.mchk, top_G * Q == 256)
-#ifndef SS_TAIL_WAVES
-#define SS_TAIL_WAVES 3
-#endif
-__global__ void __launch_bounds__(kTopChains, SS_TAIL_WAVES)
-stwo_tail_kernel_sha(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,
-                     uint32_t *__restrict__ status)
-{
-    stwo_top_body<0, false, false, true>(lay, batch, ws, status);
-}
-__global__ void __launch_bounds__(kTopChains, SS_TAIL_WAVES)
-stwo_tail_kernel_b2s(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,
-                     uint32_t *__restrict__ status)
-{
-    stwo_top_body<1, false, false, true>(lay, batch, ws, status);
-}
 // ... and behind minimal records: a sibling is the stored node of its position's leader wherever one exists
 __global__ void __launch_bounds__(kTopChains, SS_TOP_HASH_WAVES)
 stwo_top_min_kernel_sha(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,

@@ -503,7 +503,6 @@ def _ptr_array(records):
 
 FLAG_NO_DEDUP = 1  # SS_FLAG_NO_DEDUP: hash every query's Merkle path in full (A/B and tests)
 FLAG_TOP_CHECKS = 2  # SS_FLAG_TOP_CHECKS: the memoisation's byte compares in the top kernel whatever the query count
-FLAG_SPLIT_TAIL = 4  # SS_FLAG_SPLIT_TAIL: merkle and top as two launches even where the library fuses them
 
 
 def stwo_cfg_struct(cfg: StwoConfig, mode: int, flags: int = 0) -> B.StwoCfg:

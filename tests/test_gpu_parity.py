@@ -702,19 +702,6 @@ def test_pair_memoisation_with_guided_group_sizes(ver, stwo_prod):
     plain.stwo_flags = verifier.FLAG_NO_DEDUP
     assert plain.verify_stwo(batch, cfg=stwo_prod.cfg).tolist() == want.tolist()
     plain.close()
-    # batches of this size take the FUSED kernel by default (merkle phase + top phase of a group in one persistent block,
-    # stwo_tail_kernel_*); SS_FLAG_SPLIT_TAIL runs the two kernels it replaces: the same words
-    split = verifier.Verifier(0)
-    split.stwo_flags = verifier.FLAG_SPLIT_TAIL
-    assert split.verify_stwo(batch, cfg=stwo_prod.cfg).tolist() == want.tolist()
-    split.set_timing(True)
-    split.verify_stwo(batch[:16384], cfg=stwo_prod.cfg)
-    ver.set_timing(True)
-    ver.verify_stwo(batch[:16384], cfg=stwo_prod.cfg)
-    names_split, names_fused = set(split.collect_timing()), set(ver.collect_timing())
-    ver.set_timing(False)
-    split.close()
-    assert "stwo_tail" in names_fused and "stwo_merkle" not in names_fused and {"stwo_merkle", "stwo_top"} <= names_split
     assert (want == 0).sum() > 20 and (want != 0).sum() > n // 2
 
 
