@@ -781,6 +781,10 @@ def main() -> None:
                        "parity": "unpinned (Blake2s is not in the reference)" if hash_name == "blake2s" else "pinned (reference KATs + proofs)",
                        "mode": "fixture_correct", "inflight_streams": nslot,
                        "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
+                       "GPU_MAX_HW_QUEUES_matters_for": "value, ms_per_step and kernels_ms_per_step of every pipelined / multi-stream "
+                                                        "submission (each stream its own hardware queue; with the runtime's 4 the "
+                                                        "8 192-proof share loses up to 10 % and stark101 x 4 096 half its rate: "
+                                                        "profiles/r04_queue_robustness.txt); e2e, cpu_baseline and the status words do not depend on it",
                        "submission": "%d independent streams, whole passes" % args.streams if streams else
                                      "hipGraph replay, independent slots" if graphed else
                                      "eager, HEAD/TAIL pipelined" + (", Merkle halves alternating over %d streams (kernel "
