@@ -39,6 +39,15 @@ def test_integration_md_python_calls(tmp_path):
     # shared records
     shared = [verifier.stwo_shared_record(q, queries=None) for q in (p, p)]
     assert ver.verify_stwo_shared_records(p.cfg, shared).tolist() == [0, 0]
+    # minimal records, the minimal proof.json, a caller-pinned buffer
+    minimal = [verifier.stwo_minimal_record(formats.stwo_minimise(q)) for q in (p, p, bad)]
+    assert ver.verify_stwo_minimal_records(p.cfg, minimal)[:2].tolist() == [0, 0]
+    text = json.dumps(formats.stwo_minimal_to_json(formats.stwo_minimise(p)))
+    status, stats = ver.verify_stwo_minimal_texts(p.cfg, [text.encode()])
+    assert status.tolist() == [0]
+    flat = ver.pinned_buffer(sum(r.size for r in minimal)); flat[:] = np.concatenate(minimal)
+    offs = np.concatenate([[0], np.cumsum([r.size for r in minimal])]).astype(np.uint64)
+    assert ver.verify_stwo_pinned(p.cfg, flat, offs, "minimal")[:2].tolist() == [0, 0]
     # resident batches, pipelined; the accept reduce hook; a hipGraph replay
     batch = ver.stwo_batch([p, bad])
     pipe = verifier.Pipeline([batch, batch.sibling(), batch.sibling()])
