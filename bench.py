@@ -322,6 +322,21 @@ def end_to_end(ver, proofs, n: int, rank: int = 0, world: int = 1, dist=None):
                 k += 1
             row["python_reader_proofs_per_s_one_thread"] = k / (time.perf_counter() - t1)
         out[kind] = row
+        # the same texts lying in ONE caller-pinned buffer (ss_stwo_verify_texts_pinned): no staging copy, no stager threads
+        try:
+            blob, boffs, blens = ver.pinned_text_blob(batch)
+            ver.verify_stwo_texts_pinned(cfg, blob, boffs, blens, fmt=fmt)
+            dt, st = timed(lambda: ver.verify_stwo_texts_pinned(cfg, blob, boffs, blens, fmt=fmt))
+            slowest, links = across_ranks(dt, text_bytes)
+            prow = {"proofs_per_s": n / slowest, "total_s": None if slowest == float("inf") else slowest,
+                    "text_GB_per_s": text_bytes * (n / max(n_local, 1)) / slowest / 1e9,
+                    "host_parsed_texts": (st or {}).get("host_parsed", -1), "stage_threads": 0}
+            if world > 1:
+                prow["per_rank_link_GB_s"] = links
+            out[kind + "_pinned"] = prow
+            del blob
+        except Exception as e:  # noqa: BLE001
+            errors.append("rank %d pinned %s: %r" % (rank, kind, e))
         del batch
     # records in host memory -> verdicts: per-query records, shared records (19 % fewer bytes at this shape, expanded by
     # the GPU behind the link) and minimal records (one sorted, deduplicated decommitment per tree: 27 % fewer bytes,
@@ -368,7 +383,6 @@ def end_to_end(ver, proofs, n: int, rank: int = 0, world: int = 1, dist=None):
                 prow["per_rank_link_GB_s"] = links
             out[kind + "_pinned"] = prow
             del pinned
-            ver._pinned_keep = []
         except Exception as e:  # noqa: BLE001
             errors.append("rank %d pinned %s: %r" % (rank, kind, e))
         del batch

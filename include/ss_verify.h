@@ -383,6 +383,12 @@ int ss_stwo_verify_texts(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const ch
                          const size_t *lens, int fmt, uint32_t *status_host, ss_ingest_stats *stats);
 int ss_stwo_verify_files(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const char *const *paths, int fmt,
                          uint32_t *status_host, ss_ingest_stats *stats);
+/* ss_stwo_verify_texts with the texts in ONE page-locked buffer of the caller's (hipHostMalloc / ss_host_register): text i at
+ * byte offs[i] -- multiples of 16, ascending, at least lens[i] apart, offs[n] = the end -- with lens[i] bytes.  Nothing is
+ * staged: the DMA engine reads the texts where they are (the bytes between a text's end and the next offset are uploaded with
+ * it and ignored); non-canonical texts are read by the host reader from the same buffer.  Same verdicts as ss_stwo_verify_texts. */
+int ss_stwo_verify_texts_pinned(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const char *blob, const uint64_t *offs,
+                                const size_t *lens, int fmt, uint32_t *status_host, ss_ingest_stats *stats);
 /* minimal proof.json texts -> verdicts (host reader on the library's worker threads, then ss_stwo_verify_minimal_records) */
 int ss_stwo_verify_minimal_texts(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const char *const *texts,
                                  const size_t *lens, uint32_t *status_host, ss_ingest_stats *stats);

@@ -1007,6 +1007,18 @@ extern "C" int ss_stwo_verify_texts(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n,
     return stwo_ingest_dev(ctx, c, n, texts, lens, nullptr, fmt, status_host, stats);
 }
 
+// the same with the texts in ONE page-locked buffer of the caller's (text i at byte offs[i], a multiple of 16): no staging copy
+extern "C" int ss_stwo_verify_texts_pinned(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *blob, const uint64_t *offs,
+                                           const size_t *lens, int fmt, uint32_t *status_host, ss_ingest_stats *stats)
+{
+    if (!blob || !offs) return set_err(SS_ERR_ARG, "null argument");
+    try {
+        return stwo_ingest_dev(ctx, c, n, nullptr, lens, nullptr, fmt, status_host, stats, (const uint8_t *)blob, offs);
+    } catch (const std::exception &) {
+        return set_err(SS_ERR_NOMEM, "out of host memory");
+    }
+}
+
 extern "C" int ss_stwo_read_texts(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *const *texts,
                                   const size_t *lens, int fmt, uint32_t *records_host, uint32_t *outcome_host)
 {

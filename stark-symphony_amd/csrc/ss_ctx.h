@@ -148,7 +148,8 @@ bool read_file(const char *path, std::string &out);
 
 // texts (or files) -> verdicts through the GPU reader (csrc/ss_ingest_dev.hip)
 int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *const *texts, const size_t *lens,
-                    const char *const *paths, int fmt, uint32_t *status_host, ss_ingest_stats *stats);
+                    const char *const *paths, int fmt, uint32_t *status_host, ss_ingest_stats *stats,
+                    const uint8_t *blob = nullptr, const uint64_t *blob_offs = nullptr);  // blob: the texts in one caller-pinned buffer
 int s101_ingest_dev(ss_ctx *ctx, size_t n, const char *const *texts, const size_t *lens, const char *const *paths, int fmt,
                     uint32_t *status_host, ss_ingest_stats *stats);
 // ss_s101_verify_records for a caller that already holds ctx->mu

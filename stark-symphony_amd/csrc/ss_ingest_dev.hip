@@ -206,9 +206,12 @@ struct Family {
 };
 constexpr int kDeferred = 3;
 
+// blob / blob_offs (optional): the texts lie in ONE page-locked buffer of the caller's, text i at byte blob_offs[i] (a
+// multiple of 16, ascending, blob_offs[n] = the end): nothing is staged -- the DMA engine reads the chunk's bytes where they
+// are, the stager only writes the chunk's small tables, and the host reader (non-canonical texts) reads the caller's copy.
 static int ingest_pipeline(ss_ctx *ctx, const Family &F, size_t n, const char *const *texts, const size_t *lens,
                            const char *const *paths, int fmt, uint32_t *status_host, std::vector<uint8_t> &outcome,
-                           ss_ingest_stats *stats, double t0)
+                           ss_ingest_stats *stats, double t0, const uint8_t *blob = nullptr, const uint64_t *blob_offs = nullptr)
 {
     TextPath &tp = ctx->tp;
     int rc;
@@ -242,12 +245,14 @@ static int ingest_pipeline(ss_ctx *ctx, const Family &F, size_t n, const char *c
         }
     }
     auto aligned = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    // bytes text i occupies in a chunk's text area: its length rounded up, or (caller-pinned) the distance to the next text
+    auto room = [&](size_t i) { return blob ? (size_t)(blob_offs[i + 1] - blob_offs[i]) : aligned(tlen[i]); };
     // Chunks of kChunkTextBytes of text -- smaller at both ends of the call: nothing can overlap the staging and
     // upload of the first chunk, nor the reading and verification of the last one.
     std::vector<Chunk> chunks;
     {
         size_t total = 0;
-        for (size_t i = 0; i < n; i++) total += aligned(tlen[i]);
+        for (size_t i = 0; i < n; i++) total += room(i);
         size_t done = 0;
         Chunk cur;
         auto cap_now = [&]() {
@@ -256,7 +261,7 @@ static int ingest_pipeline(ss_ctx *ctx, const Family &F, size_t n, const char *c
         };
         size_t cap = cap_now();
         for (size_t i = 0; i < n; i++) {
-            const size_t a = aligned(tlen[i]);
+            const size_t a = room(i);
             if (cur.cnt && (cur.text_bytes + a > cap || (cur.cnt + 1) * W * 4 > kChunkRecordBytes)) {
                 chunks.push_back(cur);
                 done += cur.text_bytes;
@@ -316,20 +321,22 @@ static int ingest_pipeline(ss_ctx *ctx, const Family &F, size_t n, const char *c
         uint8_t *fmts = (uint8_t *)(win_base + ch.cnt + 1);
         {
             size_t o = 0;
-            for (size_t i = 0; i < ch.cnt; i++) { offs[i] = o; o += aligned(tlen[ch.lo + i]); }
+            for (size_t i = 0; i < ch.cnt; i++) { offs[i] = o; o += room(ch.lo + i); }
         }
         parallel_for(ch.cnt, [&](size_t i) {
             const size_t g = ch.lo + i;
-            uint8_t *dst = stage + offs[i];
+            const uint8_t *dst = blob ? blob + blob_offs[g] : stage + offs[i];
             uint32_t len = tlen[g];
             if (unreadable[g]) len = 0;
-            else if (paths) {
-                const long got = read_into(paths[g], dst, len);
+            else if (blob) {
+                // (nothing to copy: the chunk's text area IS blob[blob_offs[lo] .. blob_offs[lo + cnt]))
+            } else if (paths) {
+                const long got = read_into(paths[g], stage + offs[i], len);
                 if (got < 0) { unreadable[g] = 1; len = 0; }
                 else { len = (uint32_t)got; tlen[g] = len; }  // (a file that shrank since stat)
             } else {
                 // (plain memcpy here costs a third of the rate: 84.6k -> 65-71k proofs/s, profiles/r03_text_staging_ab.txt)
-                copy_streaming(dst, texts[g], len);
+                copy_streaming(stage + offs[i], texts[g], len);
             }
             lens32[i] = len;
             // which template to try: a .wit is a JSON object whose first member is COMMITMENTS / P_MT_ROOT.  A wrong
@@ -400,6 +407,7 @@ static int ingest_pipeline(ss_ctx *ctx, const Family &F, size_t n, const char *c
             uint32_t *fix = (uint32_t *)tp.fix_pin[b].p;
             const uint8_t *stage = (const uint8_t *)tp.text_pin[b].p;
             const uint64_t *offs = (const uint64_t *)(stage + meta_off(ch));
+            if (blob) stage = blob + blob_offs[ch.lo];  // (the tables are staged, the texts are where the caller put them)
             try {  // (an exception in a worker -- the host reader allocates its parse tree -- is rethrown here by the pool)
                 parallel_for(todo.size(), [&](size_t j) {
                     const size_t i = todo[j], g = ch.lo + i;
@@ -442,7 +450,14 @@ static int ingest_pipeline(ss_ctx *ctx, const Family &F, size_t n, const char *c
             }
             // ---- upload (the GPU reader of chunk k - kTextBufs has finished with the device buffer: its outcome
             // download completed before finish() freed the pinned buffer this chunk was staged into)
-            HIP_TRY(hipMemcpyAsync(tp.text_dev[b].p, tp.text_pin[b].p, stage_bytes(ch), hipMemcpyHostToDevice, tp.up));
+            if (blob) {  // the texts straight from the caller's page-locked buffer, the chunk's tables from the staging buffer
+                if (ch.text_bytes)
+                    HIP_TRY(hipMemcpyAsync(tp.text_dev[b].p, blob + blob_offs[ch.lo], ch.text_bytes, hipMemcpyHostToDevice, tp.up));
+                HIP_TRY(hipMemcpyAsync((uint8_t *)tp.text_dev[b].p + meta_off(ch), (const uint8_t *)tp.text_pin[b].p + meta_off(ch),
+                                       stage_bytes(ch) - meta_off(ch), hipMemcpyHostToDevice, tp.up));
+            } else {
+                HIP_TRY(hipMemcpyAsync(tp.text_dev[b].p, tp.text_pin[b].p, stage_bytes(ch), hipMemcpyHostToDevice, tp.up));
+            }
             HIP_TRY(hipEventRecord(tp.uploaded[b], tp.up));
             // ---- GPU reader (after rec_dev[b] has been re-tiled for chunk k - kTextBufs)
             HIP_TRY(hipStreamWaitEvent(tp.cx, tp.uploaded[b], 0));
@@ -506,9 +521,23 @@ static int ingest_pipeline(ss_ctx *ctx, const Family &F, size_t n, const char *c
 }
 
 int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *const *texts, const size_t *lens,
-                    const char *const *paths, int fmt, uint32_t *status_host, ss_ingest_stats *stats)
+                    const char *const *paths, int fmt, uint32_t *status_host, ss_ingest_stats *stats, const uint8_t *blob,
+                    const uint64_t *blob_offs)
 {
-    if (!ctx || !status_host || (!texts && !paths) || (texts && !lens)) return set_err(SS_ERR_ARG, "null argument");
+    if (!ctx || !status_host || (!texts && !paths && !blob) || ((texts || blob) && !lens) || (blob && !blob_offs))
+        return set_err(SS_ERR_ARG, "null argument");
+    if (blob) {
+        hipPointerAttribute_t a;
+        for (size_t i = 0; i < n; i++)
+            if ((blob_offs[i] & 15) || blob_offs[i + 1] < blob_offs[i] + lens[i])
+                return set_err(SS_ERR_ARG, "text %zu: offsets are multiples of 16, ascending, at least a text's length apart", i);
+        if ((blob_offs[n] & 15)) return set_err(SS_ERR_ARG, "the end offset is a multiple of 16 too (room for 16-byte reads)");
+        if (hipPointerGetAttributes(&a, blob) != hipSuccess || a.type != hipMemoryTypeHost ||
+            (blob_offs[n] && (hipPointerGetAttributes(&a, blob + blob_offs[n] - 1) != hipSuccess || a.type != hipMemoryTypeHost))) {
+            (void)hipGetLastError();
+            return set_err(SS_ERR_ARG, "the buffer is not page-locked host memory (hipHostMalloc / ss_host_register)");
+        }
+    }
     if (!cfg_ok(c)) return set_err(SS_ERR_ARG, "unsupported stwo config");
     if (!n) return set_err(SS_ERR_ARG, "empty batch");
     if (fmt < SS_TEXT_AUTO || fmt > SS_TEXT_JSON_SHARED) return set_err(SS_ERR_ARG, "unknown text format");
@@ -538,7 +567,13 @@ int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *con
         return r ? r : ss_stwo_verify_batch_dev(ctx, &cv, cnt, batch, ws, wsb, status, nullptr, s);
     };
     std::vector<uint8_t> outcome;
-    return ingest_pipeline(ctx, F, n, texts, lens, paths, fmt, status_host, outcome, stats, t0);
+    std::vector<const char *> ptrs;
+    if (blob) {  // (the pipeline's size / readability rules look at texts[i] and lens[i])
+        ptrs.resize(n);
+        for (size_t i = 0; i < n; i++) ptrs[i] = (const char *)blob + blob_offs[i];
+        texts = ptrs.data();
+    }
+    return ingest_pipeline(ctx, F, n, texts, lens, paths, fmt, status_host, outcome, stats, t0, blob, blob_offs);
 }
 
 // stark101: the protocol's shape has a template (ss_text.h); a proof of another shape is parsed by the host reader

@@ -870,9 +870,7 @@ class Verifier:
     def pinned_buffer(self, words: int) -> np.ndarray:
         """A uint32 array of `words` words in page-locked host memory (torch's pinned allocator = hipHostMalloc)."""
         t = _torch().empty(max(int(words), 1), dtype=_torch().int32, pin_memory=True)
-        a = t.numpy().view(np.uint32)[:int(words)]
-        self._pinned_keep = getattr(self, "_pinned_keep", []) + [t]
-        return a
+        return t.numpy().view(np.uint32)[:int(words)]  # (the array keeps the tensor, i.e. the pinned allocation, alive)
 
     def register_host(self, a: np.ndarray) -> None:
         """Page-lock an existing array in place (ss_host_register = hipHostRegister); undo with unregister_host."""
@@ -908,6 +906,36 @@ class Verifier:
         if n:
             B.check(fn(self.ctx, C.byref(cs), n, flat.ctypes.data, offs.ctypes.data, status.ctypes.data))
         return status
+
+    def pinned_text_blob(self, texts: Sequence[bytes]):
+        """texts -> (blob, offsets, lengths): the texts back to back, each at a multiple of 16, in ONE page-locked uint8
+        array -- what verify_stwo_texts_pinned takes (a caller that reads files would read them straight into such a buffer)."""
+        offs = np.zeros(len(texts) + 1, dtype=np.uint64)
+        lens = np.array([len(t) for t in texts], dtype=np.uint64)
+        offs[1:] = np.cumsum((lens + np.uint64(15)) & ~np.uint64(15))
+        blob = self.pinned_buffer((int(offs[-1]) + 3) // 4 + 4).view(np.uint8)
+        for t, o in zip(texts, offs[:-1]):
+            blob[int(o):int(o) + len(t)] = np.frombuffer(t, dtype=np.uint8)
+        return blob, offs, lens
+
+    def verify_stwo_texts_pinned(self, cfg: StwoConfig, blob: np.ndarray, offsets, lengths, mode: int = MODE_FIXTURE,
+                                 fmt: int = B.TEXT_AUTO):
+        """ss_stwo_verify_texts_pinned: proof.json / proof.wit texts lying in one page-locked uint8 array (pinned_text_blob, or
+        any array passed to register_host) -> (status, stats); the DMA engine reads them where they are."""
+        cs = stwo_cfg_struct(cfg, mode, self.stwo_flags)
+        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        lens = np.ascontiguousarray(lengths, dtype=np.uint64)
+        n = lens.size
+        if blob.dtype != np.uint8 or not blob.flags["C_CONTIGUOUS"] or offs.size != n + 1 or (n and int(offs[-1]) > blob.size):
+            raise ValueError("a contiguous uint8 array, n + 1 byte offsets inside it and n lengths expected")
+        status = np.full(n, 0xFFFFFFFF, dtype=np.uint32)
+        stats = B.IngestStats()
+        if n == 0:
+            return status, {k: 0 for k, _ in B.IngestStats._fields_}
+        clens = (C.c_size_t * n).from_buffer(lens)
+        B.check(B.lib().ss_stwo_verify_texts_pinned(self.ctx, C.byref(cs), n, blob.ctypes.data, offs.ctypes.data, clens, fmt,
+                                                    status.ctypes.data, C.byref(stats)))
+        return status, {k: getattr(stats, k) for k, _ in B.IngestStats._fields_}
 
     def verify_stwo_minimal_texts(self, cfg: StwoConfig, texts: Sequence[bytes], mode: int = MODE_FIXTURE):
         """Minimal proof.json texts -> (status, stats) (ss_stwo_verify_minimal_texts: the library's host reader on its

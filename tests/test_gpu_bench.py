@@ -219,8 +219,8 @@ def _check_multi_rank_line(d: dict, n: int, backend: str) -> None:
     assert d["scaling"] in ("strong", "weak") and "cpu_baseline" not in d
     e = d["e2e"]
     assert e["ranks"] == n and "errors" not in e
-    for kind in ("json", "wit", "json_shared", "records", "shared_records", "minimal_records",
-                 "records_pinned", "shared_records_pinned", "minimal_records_pinned"):
+    for kind in ("json", "wit", "json_shared", "json_pinned", "wit_pinned", "json_shared_pinned", "records", "shared_records",
+                 "minimal_records", "records_pinned", "shared_records_pinned", "minimal_records_pinned"):
         assert e[kind]["proofs_per_s"] > 0 and len(e[kind]["per_rank_link_GB_s"]) == n, kind
     assert e["minimal_records"]["bytes_per_proof"] < e["shared_records"]["bytes_per_proof"] < e["records"]["bytes_per_proof"]
 

@@ -223,3 +223,36 @@ def test_pinned_entry_points_give_the_staged_verdicts(ver):
             if not pinned:
                 for a in (f, s, mm):
                     ver.unregister_host(a)
+
+
+def test_pinned_texts_give_the_staged_verdicts(ver):
+    """ss_stwo_verify_texts_pinned: proof.json / proof.wit / shared-path texts lying in ONE page-locked buffer (each at a
+    multiple of 16) are read by the DMA engine where they are -- canonical texts by the GPU reader, the others (another member
+    order, another config, garbage) by the host reader from the same buffer; verdicts and the host reader's share are those
+    of ss_stwo_verify_texts.  Misaligned offsets and pageable memory are refused."""
+    import json
+    from stark_symphony_amd import binding as B
+    p = fixtures()[0]
+    cfg = p.cfg
+    rng = np.random.default_rng(0x5EED2025 + 170)
+    proofs = [p] + [formats.stwo_corrupt(p, rng)[0] for _ in range(40)]
+    obj = ss.stwo_to_json(p)
+    texts = []
+    for i, q in enumerate(proofs * 8):
+        texts.append(json.dumps(ss.stwo_to_json(q), separators=(",", ":")).encode() if i % 3 == 0 else
+                     ss.stwo_to_wit(q).encode() if i % 3 == 1 else json.dumps(ss.stwo_to_json(q)).encode())
+    texts += [json.dumps(ss.stwo_to_json(p, shared=True), separators=(",", ":")).encode(),
+              json.dumps(dict(reversed(list(obj.items())))).encode(), b"not a witness", b"",
+              json.dumps(ss.stwo_to_json(fixtures()[1])).encode()]
+    want, wstats = ver.verify_stwo_texts(cfg, texts)
+    blob, offs, lens = ver.pinned_text_blob(texts)
+    got, stats = ver.verify_stwo_texts_pinned(cfg, blob, offs, lens)
+    assert got.tolist() == want.tolist() and stats["host_parsed"] == wstats["host_parsed"] >= 3
+    assert got[0] == 0 and (got == 2).sum() >= 2 and (got == 1).sum() >= 1
+    bad = offs.copy()
+    bad[3] += 8
+    with pytest.raises(B.SsError):
+        ver.verify_stwo_texts_pinned(cfg, blob, bad, lens)
+    pageable = np.array(blob)
+    with pytest.raises(B.SsError):
+        ver.verify_stwo_texts_pinned(cfg, pageable, offs, lens)
