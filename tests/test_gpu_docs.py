@@ -48,6 +48,9 @@ def test_integration_md_python_calls(tmp_path):
     flat = ver.pinned_buffer(sum(r.size for r in minimal)); flat[:] = np.concatenate(minimal)
     offs = np.concatenate([[0], np.cumsum([r.size for r in minimal])]).astype(np.uint64)
     assert ver.verify_stwo_pinned(p.cfg, flat, offs, "minimal")[:2].tolist() == [0, 0]
+    blob, boffs, blens = ver.pinned_text_blob([a.read_bytes(), b.read_bytes()])
+    status, stats = ver.verify_stwo_texts_pinned(p.cfg, blob, boffs, blens)
+    assert status.tolist() == [0, 0]
     # resident batches, pipelined; the accept reduce hook; a hipGraph replay
     batch = ver.stwo_batch([p, bad])
     pipe = verifier.Pipeline([batch, batch.sibling(), batch.sibling()])
