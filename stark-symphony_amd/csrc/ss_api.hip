@@ -873,43 +873,51 @@ extern "C" int ss_stwo_verify_minimal_texts(ss_ctx *ctx, const ss_stwo_cfg *c, s
     if (!n) return set_err(SS_ERR_ARG, "empty batch");
     try {
         const double t0 = now_s();
-        std::vector<std::vector<uint32_t>> recs(n);
-        std::vector<uint32_t> outcome(n, 0);
-        std::vector<int> failed(n, 0);
         const size_t threads = std::max<size_t>(1, effective_cpus());
-        parallel_for(n, [&](size_t i) {
-            try {
-                const ParseResult r = texts[i] ? stwo_parse_minimal_text(*c, texts[i], lens[i], recs[i]) : kMalformed;
-                outcome[i] = r == kParsed ? 0 : r == kConfigMismatch ? SS_STATUS_CONFIG_MISMATCH : SS_STATUS_MALFORMED;
-            } catch (const std::exception &) {
-                failed[i] = 1;
-            }
-        }, threads);
-        for (size_t i = 0; i < n; i++)
-            if (failed[i]) return set_err(SS_ERR_NOMEM, "host reader: out of memory");
-        const double t1 = now_s();
-        std::vector<const uint32_t *> ptrs;
-        std::vector<size_t> words, where;
+        double parse_s = 0;
         uint64_t text_bytes = 0, rec_bytes = 0;
-        for (size_t i = 0; i < n; i++) {
-            text_bytes += lens[i];
-            status_host[i] = outcome[i];
-            if (!outcome[i]) { ptrs.push_back(recs[i].data()); words.push_back(recs[i].size()); where.push_back(i); rec_bytes += recs[i].size() * 4; }
-        }
-        if (!ptrs.empty()) {
-            std::vector<uint32_t> st(ptrs.size());
-            const int rc = ss_stwo_verify_minimal_records(ctx, c, ptrs.size(), ptrs.data(), words.data(), st.data());
-            if (rc) return rc;
-            for (size_t k = 0; k < where.size(); k++) status_host[where[k]] = st[k];
+        // blocks of 2 048 texts: the parsed records of one block are all that is held at a time
+        const size_t kBlock = 2048;
+        std::vector<std::vector<uint32_t>> recs(std::min(n, kBlock));
+        std::vector<uint32_t> outcome(recs.size());
+        std::vector<int> failed(recs.size());
+        for (size_t lo = 0; lo < n; lo += kBlock) {
+            const size_t cnt = std::min(kBlock, n - lo);
+            const double tp0 = now_s();
+            std::fill(failed.begin(), failed.end(), 0);
+            parallel_for(cnt, [&](size_t i) {
+                try {
+                    const ParseResult r = texts[lo + i] ? stwo_parse_minimal_text(*c, texts[lo + i], lens[lo + i], recs[i]) : kMalformed;
+                    outcome[i] = r == kParsed ? 0 : r == kConfigMismatch ? SS_STATUS_CONFIG_MISMATCH : SS_STATUS_MALFORMED;
+                } catch (const std::exception &) {
+                    failed[i] = 1;
+                }
+            }, threads);
+            for (size_t i = 0; i < cnt; i++)
+                if (failed[i]) return set_err(SS_ERR_NOMEM, "host reader: out of memory");
+            parse_s += now_s() - tp0;
+            std::vector<const uint32_t *> ptrs;
+            std::vector<size_t> words, where;
+            for (size_t i = 0; i < cnt; i++) {
+                text_bytes += lens[lo + i];
+                status_host[lo + i] = outcome[i];
+                if (!outcome[i]) { ptrs.push_back(recs[i].data()); words.push_back(recs[i].size()); where.push_back(lo + i); rec_bytes += recs[i].size() * 4; }
+            }
+            if (!ptrs.empty()) {
+                std::vector<uint32_t> st(ptrs.size());
+                const int rc = ss_stwo_verify_minimal_records(ctx, c, ptrs.size(), ptrs.data(), words.data(), st.data());
+                if (rc) return rc;
+                for (size_t k = 0; k < where.size(); k++) status_host[where[k]] = st[k];
+            }
         }
         if (stats) {
             memset(stats, 0, sizeof *stats);
-            stats->parse_s = t1 - t0;
+            stats->parse_s = parse_s;
             stats->total_s = now_s() - t0;
             stats->text_bytes = text_bytes;
             stats->record_bytes = rec_bytes;
             stats->threads = (uint32_t)threads;
-            stats->host_parsed = (uint32_t)n;
+            stats->host_parsed = (uint32_t)std::min<size_t>(n, 0xffffffffu);
         }
         return SS_OK;
     } catch (const std::exception &) {
