@@ -338,6 +338,27 @@ def end_to_end(ver, proofs, n: int, rank: int = 0, world: int = 1, dist=None):
         except Exception as e:  # noqa: BLE001
             errors.append("rank %d pinned %s: %r" % (rank, kind, e))
         del batch
+    # the minimal proof.json (one decommitment per tree, 68 % of the per-query text): read by the library's HOST reader -- its
+    # list lengths depend on the queries, so the GPU reader has no template for it -- then verified as minimal records
+    try:
+        from stark_symphony_amd import formats as _f
+        mtexts = [json.dumps(_f.stwo_minimal_to_json(_f.stwo_minimise(p)), separators=(",", ":")).encode() for p in distinct]
+        batch = [mtexts[(lo + i) % len(distinct)][:1] + mtexts[(lo + i) % len(distinct)][1:] for i in range(n_local)]
+        ver.verify_stwo_minimal_texts(cfg, batch[:64])
+        dt, st = timed(lambda: ver.verify_stwo_minimal_texts(cfg, batch))
+        text_bytes = sum(len(b) for b in batch)
+        slowest, links = across_ranks(dt, text_bytes)
+        st = st or {"parse_s": 0.0, "total_s": 1.0, "threads": 0}
+        row = {"proofs_per_s": n / slowest, "total_s": None if slowest == float("inf") else slowest,
+               "text_GB_per_s": text_bytes * (n / max(n_local, 1)) / slowest / 1e9, "host_reader_s": st["parse_s"],
+               "parse_share": st["parse_s"] / st["total_s"], "host_parsed_texts": n_local, "host_threads": st["threads"],
+               "text_bytes_per_proof": text_bytes // max(n_local, 1), "reader": "host (no GPU template for this form)"}
+        if world > 1:
+            row["per_rank_link_GB_s"] = links
+        out["json_minimal"] = row
+        del batch
+    except Exception as e:  # noqa: BLE001
+        errors.append("rank %d minimal texts: %r" % (rank, e))
     # records in host memory -> verdicts: per-query records, shared records (19 % fewer bytes at this shape, expanded by
     # the GPU behind the link) and minimal records (one sorted, deduplicated decommitment per tree: 27 % fewer bytes,
     # verified without an expansion pass -- csrc/ss_minimal.hip; parity unpinned, no such bytes in the reference)
