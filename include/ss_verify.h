@@ -297,8 +297,9 @@ int ss_stwo_verify_minimal_dev(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, co
 int ss_stwo_verify_minimal_records(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const uint32_t *const *minimal,
                                    const size_t *words, uint32_t *status_host);
 
-/* The three host-buffer paths WITHOUT the staging copy: the inputs lie back to back in ONE buffer of page-locked host
- * memory -- allocated by hipHostMalloc, or any memory registered with ss_host_register (hipHostRegister) -- and the DMA
+/* The three host-buffer paths WITHOUT the staging copy (what replaces, for a batch caller, the reference's "one file per
+ * process" hand-over: stwo-verifier/Makefile:17-18, simfony-cli/src/main.rs:163-209): the inputs lie back to back in ONE buffer
+ * of page-locked host memory -- allocated by hipHostMalloc, or any memory registered with ss_host_register (hipHostRegister) -- and the DMA
  * engine reads it directly, chunk by chunk, while the previous chunk is verified.  No host thread touches the bytes
  * (the staged entry points need about four cores to feed the link; a rank of an 8-GPU host has two).  records: n x
  * ss_stwo_record_words words; shared / minimal: record i at word offset offs[i], offs[n] = the total (n + 1 ascending
@@ -493,7 +494,8 @@ int ss_ctx_collect_timing(ss_ctx *ctx, int cap, const char **names, float *total
  *         -> out the first failing status code, 0 = none (stages 8 / 9 of the stwo status codes)            */
 int ss_selftest(ss_ctx *ctx, int op, size_t n, const uint32_t *in_host, uint32_t *out_host);
 
-/* Device replay of the reference's known-answer tests (tests only; csrc/ss_kat.hip): one reference function per item,
+/* Device replay of the reference's known-answer tests -- the `fn test_*` bodies of stark101/src/*.simf and
+ * stwo-verifier/src/**/*.simf, SURVEY.md Appendix A -- (tests only; csrc/ss_kat.hip): one reference function per item,
  * evaluated ON THE GPU through the device functions the kernels are built from; tests/test_gpu_kats.py feeds the literals
  * of the reference's `fn test_*` bodies (tests/golden/kats.json) and compares with the expected literals directly.
  * in_words / out_words = n x the op's widths.  Hashes are 8 words (word j = big-endian bytes 4j..4j+3).
