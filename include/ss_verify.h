@@ -494,8 +494,8 @@ int ss_ctx_collect_timing(ss_ctx *ctx, int cap, const char **names, float *total
  *         -> out the first failing status code, 0 = none (stages 8 / 9 of the stwo status codes)            */
 int ss_selftest(ss_ctx *ctx, int op, size_t n, const uint32_t *in_host, uint32_t *out_host);
 
-/* Device replay of the reference's known-answer tests -- the `fn test_*` bodies of stark101/src/*.simf and
- * stwo-verifier/src/**/*.simf, SURVEY.md Appendix A -- (tests only; csrc/ss_kat.hip): one reference function per item,
+/* Device replay of the reference's known-answer tests -- the `fn test_...` bodies of every .simf file under stark101/src and
+ * stwo-verifier/src, SURVEY.md Appendix A -- (tests only; csrc/ss_kat.hip): one reference function per item,
  * evaluated ON THE GPU through the device functions the kernels are built from; tests/test_gpu_kats.py feeds the literals
  * of the reference's `fn test_*` bodies (tests/golden/kats.json) and compares with the expected literals directly.
  * in_words / out_words = n x the op's widths.  Hashes are 8 words (word j = big-endian bytes 4j..4j+3).
