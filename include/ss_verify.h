@@ -350,6 +350,17 @@ int ss_stwo_parse_minimal(const ss_stwo_cfg *cfg, const char *text, size_t len, 
                           size_t *words_out);
 size_t ss_stwo_write_minimal_text(const ss_stwo_cfg *cfg, const uint32_t *minimal, size_t words, int python_separators,
                                   char *buf, size_t cap);
+/* The host has two readers of this form: a streaming one (one pass, no tree) for texts in the writers' member order that
+ * declare the expected config, and the general one (any member order; the one that judges a text malformed or mismatching).
+ * ss_stwo_parse_minimal and ss_stwo_verify_minimal_texts try the streaming reader and give the general one what it declines;
+ * this call picks one, for tests and diagnosis: SS_READER_STREAM returns SS_READER_DECLINED for a text it does not take.
+ * What the streaming reader takes it reads as the general one does (tests/test_minimal.py).                              */
+#define SS_READER_AUTO 0
+#define SS_READER_GENERAL 1
+#define SS_READER_STREAM 2
+#define SS_READER_DECLINED 3
+int ss_stwo_parse_minimal_route(const ss_stwo_cfg *cfg, const char *text, size_t len, int reader, uint32_t *minimal_out,
+                                size_t cap_words, size_t *words_out);
 
 /* One text -> one record (ss_stwo_record_words words).  Returns 0 = parsed, SS_STATUS_CONFIG_MISMATCH,
  * SS_STATUS_MALFORMED (record_out untouched or zeroed), or < 0 on a bad argument.  No GPU involved. */

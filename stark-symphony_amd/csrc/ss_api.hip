@@ -829,12 +829,19 @@ extern "C" size_t ss_stwo_write_text(const ss_stwo_cfg *c, const uint32_t *recor
 extern "C" int ss_stwo_parse_minimal(const ss_stwo_cfg *c, const char *text, size_t len, uint32_t *minimal_out, size_t cap_words,
                                      size_t *words_out)
 {
+    return ss_stwo_parse_minimal_route(c, text, len, SS_READER_AUTO, minimal_out, cap_words, words_out);
+}
+
+extern "C" int ss_stwo_parse_minimal_route(const ss_stwo_cfg *c, const char *text, size_t len, int reader, uint32_t *minimal_out,
+                                           size_t cap_words, size_t *words_out)
+{
     if (!cfg_ok(c)) return set_err(SS_ERR_ARG, "unsupported stwo config");
-    if (!text || !words_out) return set_err(SS_ERR_ARG, "bad argument");
+    if (!text || !words_out || reader < SS_READER_AUTO || reader > SS_READER_STREAM) return set_err(SS_ERR_ARG, "bad argument");
     *words_out = 0;
     try {
         std::vector<uint32_t> rec;
-        const ParseResult r = stwo_parse_minimal_text(*c, text, len, rec);
+        const ParseResult r = stwo_parse_minimal_text(*c, text, len, rec, reader);
+        if (r == kDeclined) return SS_READER_DECLINED;
         if (r != kParsed) return r == kConfigMismatch ? (int)SS_STATUS_CONFIG_MISMATCH : (int)SS_STATUS_MALFORMED;
         *words_out = rec.size();
         if (!minimal_out || cap_words < rec.size()) return set_err(SS_ERR_ARG, "minimal record needs %zu words", rec.size());

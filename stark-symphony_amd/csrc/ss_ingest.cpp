@@ -10,6 +10,7 @@
 #include "ss_minimal.h"
 #include "ss_shared.h"
 
+#include <emmintrin.h>
 #include <sched.h>
 
 #include <cstdio>
@@ -218,6 +219,62 @@ bool number_node(Tree &t, uint32_t idx, const char *digits, size_t n, int base)
 constexpr int kMaxDepth = 48;
 
 // ------------------------------------------------------------------------------- JSON
+// A hash as both writers print it -- "[b,b,..]" or "[b, b, ..]", 32 byte values; three quarters of a proof.json (nearly
+// all of a minimal one) are such lists.  A digit loop is serial -- where a value starts depends on how long the one before
+// it was -- and mispredicts on most values, so: (1) the digit bytes of the next 64 text bytes as a bit mask (SSE2, the
+// x86-64 baseline), whose rising edges are the 32 starts; (2) every value from one 4-byte read at its start, independent
+// of its neighbours, with the separators checked against the starts.  false = not of that exact shape (p untouched): the
+// caller's general loop decides.
+static inline uint64_t digit_mask64(const char *p)
+{
+    uint64_t m = 0;
+    const __m128i zero = _mm_set1_epi8('0'), nine = _mm_set1_epi8(9);
+    for (int k = 0; k < 4; k++) {
+        const __m128i t = _mm_sub_epi8(_mm_loadu_si128((const __m128i *)(p + 16 * k)), zero);
+        m |= (uint64_t)(uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_min_epu8(t, nine), t)) << (16 * k);
+    }
+    return m;
+}
+
+static inline bool bytes32_fast(const char *&pp, const char *end, uint32_t *w)
+{
+    const char *p = pp;
+    if (end - p < 3 * 64 + 8 || *p != '[') return false;  // room for every read below (a hash is at most 1 + 32 * 5 bytes)
+    uint32_t at[32], n_at = 0;
+    uint64_t carry = 0;
+    for (uint32_t c = 0; c < 3 && n_at < 32; c++) {
+        const uint64_t m = digit_mask64(p + 64 * c);
+        uint64_t st = m & ~((m << 1) | carry);
+        carry = m >> 63;
+        while (st && n_at < 32) {
+            at[n_at++] = 64 * c + (uint32_t)__builtin_ctzll(st);
+            st &= st - 1;
+        }
+    }
+    if (n_at < 32 || at[0] != 1) return false;
+    uint32_t bad = 0, acc = 0, e = 0;
+    for (uint32_t k = 0; k < 32; k++) {
+        uint32_t x;
+        memcpy(&x, p + at[k], 4);
+        const uint32_t t = x ^ 0x30303030u;                                   // digits -> 0..9
+        const uint32_t other = ((t + 0x76767676u) | t) & 0x80808080u;         // bytes that are no digit
+        const uint32_t n = (uint32_t)__builtin_ctz(other | 0x80000000u) >> 3;  // 1..3 digits (4: other == 0, flagged below)
+        const uint32_t u = t << (8 * (3 - n));                                // right-aligned: hundreds, tens, units
+        const uint32_t v = (u & 0xff) * 100 + ((u >> 8) & 0xff) * 10 + ((u >> 16) & 0xff);
+        bad |= (other == 0) | (v > 255) | ((n > 1) & ((t & 0xff) == 0));      // (no leading zeros in JSON)
+        acc = (acc << 8) | v;
+        if ((k & 3) == 3) w[k >> 2] = acc;
+        e = at[k] + n;
+        if (k < 31) {
+            const uint32_t gap = at[k + 1] - e;                               // "," or ", "
+            bad |= (p[e] != ',') | (gap == 2 ? p[e + 1] != ' ' : gap != 1);
+        }
+    }
+    if (bad || p[e] != ']') return false;
+    pp = p + e + 1;
+    return true;
+}
+
 struct Json {
     Tree &t;
     const char *p, *end;
@@ -307,10 +364,12 @@ struct Json {
             // Three quarters of a proof.json are hashes written as lists of 32 byte values: read such a
             // list straight into one node (kind kBig, the 8 stored words) instead of 33.  Anything
             // else -- other lengths, values above 255, nesting -- falls through to the general path.
-            const char *q = p + 1;
+            const char *q = p;
             uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             int k = 0;
             bool ok = true;
+            if (bytes32_fast(q, end, w)) { k = 32; q--; }  // (q on the closing bracket, as the loop below leaves it)
+            else q = p + 1;
             while (ok && k < 32) {
                 while (q < end && (*q == ' ' || *q == '\n' || *q == '\t' || *q == '\r')) q++;
                 uint32_t v = 0;
@@ -1210,11 +1269,181 @@ ParseResult stwo_parse_text(const ss_stwo_cfg &cfg, const char *text, size_t len
     return r;
 }
 
-ParseResult stwo_parse_minimal_text(const ss_stwo_cfg &cfg, const char *text, size_t len, std::vector<uint32_t> &out)
+// ------------------------------------------------------------------ the minimal proof.json, streaming
+// A text in the member order of the writers (csrc/ss_text.cpp json_text = formats.stwo_minimal_to_json; any JSON
+// whitespace between tokens), with the config the caller expects, read in one pass without a tree: numbers go
+// straight into the lists of the record.  It answers "parsed, here is the record" or DECLINES -- every other text
+// (another member order, a mismatching or malformed one) is the general reader's to judge, so a decline is never an
+// outcome.  What it accepts it reads as stwo_min_from_json does (tests/test_minimal.py: equal on every text both take).
+namespace {
+
+struct MinScan {
+    const char *p, *end;
+    void ws() { while (p < end && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++; }
+    bool ch(char c)
+    {
+        ws();
+        if (p >= end || *p != c) return false;
+        p++;
+        return true;
+    }
+    bool peek(char c) { ws(); return p < end && *p == c; }
+    bool key(const char *k)  // "k" :
+    {
+        ws();
+        const size_t n = strlen(k);
+        if ((size_t)(end - p) < n + 2 || p[0] != '"' || memcmp(p + 1, k, n) != 0 || p[n + 1] != '"') return false;
+        p += n + 2;
+        return ch(':');
+    }
+    // a plain JSON integer <= max: digits only, no leading zero, nothing of a fraction or exponent behind it
+    bool num(uint64_t max, uint64_t &v)
+    {
+        ws();
+        const char *s = p;
+        uint64_t x = 0;
+        while (p < end && (unsigned)(*p - '0') < 10u && p - s < 20) { x = x * 10 + (uint64_t)(*p - '0'); p++; }
+        const size_t nd = (size_t)(p - s);
+        if (nd == 0 || (nd > 1 && *s == '0')) return false;
+        if (nd == 20 && (s[0] > '1' || x < 10000000000000000000ull)) return false;  // wrapped past 2^64
+        if (p < end && ((unsigned)(*p - '0') < 10u || *p == '.' || *p == 'e' || *p == 'E')) return false;
+        v = x;
+        return x <= max;
+    }
+    bool u32(uint32_t &w) { uint64_t v; if (!num(0xffffffffull, v)) return false; w = (uint32_t)v; return true; }
+    bool cst(uint64_t want) { uint64_t v; return num(~0ull, v) && v == want; }
+    bool hash(uint32_t *w)  // [b0, .., b31] -> 8 words, most significant byte first
+    {
+        ws();
+        if (bytes32_fast(p, end, w)) return true;
+        if (!ch('[')) return false;
+        for (uint32_t k = 0; k < 32; k++) {
+            if (k && !ch(',')) return false;
+            ws();
+            uint32_t v = 0, nd = 0;
+            const char *s = p;
+            while (p < end && (unsigned)(*p - '0') < 10u && nd < 4) { v = v * 10 + (uint32_t)(*p - '0'); p++; nd++; }
+            if (nd == 0 || nd > 3 || v > 255 || (nd > 1 && *s == '0')) return false;
+            if (p < end && (*p == '.' || *p == 'e' || *p == 'E')) return false;
+            w[k >> 2] = (k & 3) ? (w[k >> 2] << 8) | v : v;
+        }
+        return ch(']');
+    }
+    bool qm31(uint32_t *w)
+    {
+        return ch('[') && ch('[') && u32(w[0]) && ch(',') && u32(w[1]) && ch(']') && ch(',') && ch('[') && u32(w[2]) && ch(',') &&
+               u32(w[3]) && ch(']') && ch(']');
+    }
+};
+
+}  // namespace
+
+bool stwo_min_stream(const ss_stwo_cfg &cfg, const char *text, size_t len, std::vector<uint32_t> &out)
+{
+    uint32_t bits = 0;  // what the text has to declare: the writers' rule (csrc/ss_text.cpp), no text for any other config
+    while (bits < 64 && pow_target_of_bits(bits) != cfg.pow_target) bits++;
+    if (bits == 64 || cfg.hash > SS_HASH_BLAKE2S ||
+        !stwo_cfg_ok(cfg.n_cols, cfg.trace_log, cfg.lde_log, cfg.n_queries, cfg.n_layers, cfg.mode & 1))
+        return false;
+    const MinMap m = min_map(cfg.n_cols, cfg.lde_log, cfg.n_queries, cfg.n_layers);
+    const uint32_t N = m.N, Q = m.Q, K = m.K;
+    MinScan s{text, text + len};
+    // lists in the order of the text; the record wants trace values, composition values, the fri_witness lists, then the
+    // hash lists, so they are collected here and copied behind the head at the end
+    static thread_local std::vector<uint32_t> vals[2], fw[kMaxList + 1], hw[kMaxList + 3];
+    out.assign(m.data, 0);
+    uint32_t *head = out.data();
+    auto hash_witness = [&](uint32_t tree) -> bool {  // "hash_witness": [hashes], "column_witness": []
+        std::vector<uint32_t> &v = hw[tree];
+        v.clear();
+        const size_t cap = (size_t)Q * min_tree_len(m.L, tree);
+        if (!s.key("hash_witness") || !s.ch('[')) return false;
+        if (!s.peek(']')) {
+            do {
+                if (v.size() == 8 * cap) return false;
+                v.resize(v.size() + 8);
+                if (!s.hash(v.data() + v.size() - 8)) return false;
+            } while (s.ch(','));
+        }
+        return s.ch(']') && s.ch(',') && s.key("column_witness") && s.ch('[') && s.ch(']');
+    };
+    auto flat = [&](std::vector<uint32_t> &v, uint32_t per) -> bool {  // [u32, ..]: a multiple of `per`, at most Q rows
+        v.clear();
+        if (!s.ch('[')) return false;
+        if (!s.peek(']')) {
+            do {
+                uint32_t w;
+                if (v.size() == (size_t)Q * per || !s.u32(w)) return false;
+                v.push_back(w);
+            } while (s.ch(','));
+        }
+        return s.ch(']') && v.size() % per == 0;
+    };
+    auto layer = [&](uint32_t l) -> bool {
+        std::vector<uint32_t> &v = fw[l];
+        v.clear();
+        if (!s.ch('{') || !s.key("fri_witness") || !s.ch('[')) return false;
+        if (!s.peek(']')) {
+            do {
+                if (v.size() == 4 * (size_t)Q) return false;
+                v.resize(v.size() + 4);
+                if (!s.qm31(v.data() + v.size() - 4)) return false;
+            } while (s.ch(','));
+        }
+        return s.ch(']') && s.ch(',') && s.key("decommitment") && s.ch('{') && hash_witness(2 + l) && s.ch('}') && s.ch(',') &&
+               s.key("commitment") && s.hash(head + 24 + 4 * N + 64 + 8 * l) && s.ch('}');
+    };
+    bool ok = s.ch('{') && s.key("config") && s.ch('{') && s.key("pow_bits") && s.cst(bits) && s.ch(',') && s.key("fri_config") &&
+              s.ch('{') && s.key("log_blowup_factor") && s.cst(cfg.lde_log - cfg.trace_log) && s.ch(',') &&
+              s.key("log_last_layer_degree_bound") && s.cst(0) && s.ch(',') && s.key("n_queries") && s.cst(Q) && s.ch('}');
+    if (ok && cfg.hash == SS_HASH_BLAKE2S) {
+        s.ws();
+        static const char kB2s[] = "\"blake2s\"";
+        ok = s.ch(',') && s.key("hash") && (s.ws(), (size_t)(s.end - s.p) >= sizeof kB2s - 1) && memcmp(s.p, kB2s, sizeof kB2s - 1) == 0;
+        if (ok) s.p += sizeof kB2s - 1;
+    }
+    ok = ok && s.ch('}') && s.ch(',') && s.key("commitments") && s.ch('[') && s.hash(head) && s.ch(',') && s.hash(head + 8) &&
+         s.ch(',') && s.hash(head + 16) && s.ch(']') && s.ch(',') && s.key("sampled_values") && s.ch('[') && s.ch('[') && s.ch(']') &&
+         s.ch(',') && s.ch('[');
+    for (uint32_t k = 0; ok && k < N; k++) ok = (k == 0 || s.ch(',')) && s.ch('[') && s.qm31(head + 24 + 4 * k) && s.ch(']');
+    ok = ok && s.ch(']') && s.ch(',') && s.ch('[');
+    for (uint32_t k = 0; ok && k < kCp; k++) ok = (k == 0 || s.ch(',')) && s.ch('[') && s.qm31(head + 24 + 4 * N + 4 * k) && s.ch(']');
+    ok = ok && s.ch(']') && s.ch(']') && s.ch(',') && s.key("decommitments") && s.ch('[') && s.ch('{') && s.key("hash_witness") &&
+         s.ch('[') && s.ch(']') && s.ch(',') && s.key("column_witness") && s.ch('[') && s.ch(']') && s.ch('}') && s.ch(',') &&
+         s.ch('{') && hash_witness(0) && s.ch('}') && s.ch(',') && s.ch('{') && hash_witness(1) && s.ch('}') && s.ch(']') && s.ch(',') &&
+         s.key("queried_values") && s.ch('[') && s.ch('[') && s.ch(']') && s.ch(',') && flat(vals[0], N) && s.ch(',') &&
+         flat(vals[1], kCp) && s.ch(']') && s.ch(',') && s.key("proof_of_work");
+    uint64_t nonce = 0;
+    ok = ok && s.num(~0ull, nonce) && s.ch(',') && s.key("fri_proof") && s.ch('{') && s.key("first_layer") && layer(0) && s.ch(',') &&
+         s.key("inner_layers") && s.ch('[');
+    for (uint32_t l = 1; ok && l <= K; l++) ok = (l == 1 || s.ch(',')) && layer(l);
+    ok = ok && s.ch(']') && s.ch(',') && s.key("last_layer_poly") && s.ch('{') && s.key("coeffs") && s.ch('[') &&
+         s.qm31(head + 24 + 4 * N + 64 + 8 * (K + 1)) && s.ch(']') && s.ch(',') && s.key("log_size") && s.cst(0) && s.ch('}') &&
+         s.ch('}') && s.ch('}');
+    if (ok) { s.ws(); ok = s.p == s.end; }
+    if (!ok) { out.clear(); return false; }
+    head[m.head - 2] = (uint32_t)(nonce >> 32);
+    head[m.head - 1] = (uint32_t)nonce;
+    head[m.nv] = (uint32_t)(vals[0].size() / N);
+    head[m.nv + 1] = (uint32_t)(vals[1].size() / kCp);
+    size_t total = m.data + vals[0].size() + vals[1].size();
+    for (uint32_t l = 0; l <= K; l++) { head[m.nfw + l] = (uint32_t)(fw[l].size() / 4); total += fw[l].size(); }
+    for (uint32_t t = 0; t < K + 3; t++) { head[m.nhw + t] = (uint32_t)(hw[t].size() / 8); total += hw[t].size(); }
+    out.reserve(total);
+    out.insert(out.end(), vals[0].begin(), vals[0].end());
+    out.insert(out.end(), vals[1].begin(), vals[1].end());
+    for (uint32_t l = 0; l <= K; l++) out.insert(out.end(), fw[l].begin(), fw[l].end());
+    for (uint32_t t = 0; t < K + 3; t++) out.insert(out.end(), hw[t].begin(), hw[t].end());
+    return true;
+}
+
+ParseResult stwo_parse_minimal_text(const ss_stwo_cfg &cfg, const char *text, size_t len, std::vector<uint32_t> &out, int route)
 {
     static thread_local Tree j;
     out.clear();
     if (len > kMaxTextBytes) return kMalformed;
+    if (route != kRouteGeneral && stwo_min_stream(cfg, text, len, out)) return kParsed;
+    if (route == kRouteStream) return kDeclined;
     ParseResult r = kMalformed;
     if (parse_json(j, text, len) && !j.nodes.empty() && j.nodes[0].kind == kObj) r = stwo_min_from_json(cfg, j, out);
     if (r != kParsed) out.clear();

@@ -22,6 +22,7 @@ enum ParseResult : int {
     kParsed = 0,
     kMalformed = 1,       // not a witness of the reference's types (`simfony run` exits 1 before running)
     kConfigMismatch = 2,  // well formed, but not the shape / declared parameters the verifier expects
+    kDeclined = 3,        // kRouteStream only: the streaming reader does not take this text (no outcome: the general reader judges it)
 };
 
 // fmt: SS_TEXT_AUTO sniffs (a .wit is a JSON object with a "COMMITMENTS" / "P_MT_ROOT" member)
@@ -29,7 +30,12 @@ ParseResult stwo_parse_text(const ss_stwo_cfg &cfg, const char *text, size_t len
 
 // The minimal proof.json (one sorted, deduplicated decommitment per tree; formats.stwo_minimal_from_json): the same
 // schema with lists whose lengths are data.  out receives the minimal record (include/ss_verify.h) when parsed.
-ParseResult stwo_parse_minimal_text(const ss_stwo_cfg &cfg, const char *text, size_t len, std::vector<uint32_t> &out);
+// Two readers: a streaming one for texts in the writers' member order with the expected config (one pass, no tree) and
+// the general one (any member order, judges mismatch / malformed); route picks (tests compare them), kRouteAuto = the
+// streaming reader first and the general one for whatever it declines.
+enum : int { kRouteAuto = 0, kRouteGeneral = 1, kRouteStream = 2 };
+ParseResult stwo_parse_minimal_text(const ss_stwo_cfg &cfg, const char *text, size_t len, std::vector<uint32_t> &out,
+                                    int route = kRouteAuto);
 
 // stark101: a proof's shape is data (List<_, 32>), so parsing yields the shape too
 struct S101Parsed;

@@ -349,15 +349,20 @@ def stwo_minimise_record(cfg: StwoConfig, record: np.ndarray, queries: Sequence[
     return out[:words.value].copy()
 
 
-def parse_stwo_minimal_text(cfg: StwoConfig, text: bytes, mode: int = MODE_FIXTURE):
-    """One minimal proof.json -> (outcome, minimal record or None) with the library's native reader (ss_stwo_parse_minimal;
-    no GPU): outcome 0 = parsed, STATUS_CONFIG_MISMATCH (1), STATUS_MALFORMED (2)."""
+READER_AUTO, READER_GENERAL, READER_STREAM, READER_DECLINED = 0, 1, 2, 3
+
+
+def parse_stwo_minimal_text(cfg: StwoConfig, text: bytes, mode: int = MODE_FIXTURE, reader: int = READER_AUTO):
+    """One minimal proof.json -> (outcome, minimal record or None) with the library's native readers
+    (ss_stwo_parse_minimal_route; no GPU): outcome 0 = parsed, STATUS_CONFIG_MISMATCH (1), STATUS_MALFORMED (2);
+    reader=READER_STREAM asks the streaming reader alone, which answers READER_DECLINED (3) for a text it leaves to the
+    general one."""
     cs = stwo_cfg_struct(cfg, mode)
     L = B.lib()
     text = bytes(text)
     out = np.zeros(L.ss_stwo_minimal_max_words(C.byref(cs)), dtype=np.uint32)
     words = C.c_size_t(0)
-    rc = B.check(L.ss_stwo_parse_minimal(C.byref(cs), text, len(text), out.ctypes.data, out.size, C.byref(words)))
+    rc = B.check(L.ss_stwo_parse_minimal_route(C.byref(cs), text, len(text), reader, out.ctypes.data, out.size, C.byref(words)))
     return rc, (out[:words.value].copy() if rc == 0 else None)
 
 

@@ -277,3 +277,52 @@ def test_minimal_text_native_reader_equals_python(i):
     # a one-query proof: the two forms are the same text
     if cfg.n_queries == 1:
         assert json.dumps(formats.stwo_to_json(p)) == json.dumps(obj)
+
+
+@pytest.mark.parametrize("i", [0, 1, 2, 4])
+def test_minimal_text_streaming_reader_equals_the_general_one(i):
+    """The host has two readers of the minimal proof.json (include/ss_verify.h, ss_stwo_parse_minimal_route): the
+    streaming one takes the writers' member order in any JSON whitespace and DECLINES everything else; what it takes
+    it reads as the general reader does.  On the fixtures' texts in four spellings, on the mutants of the test above
+    and on number spellings inside a hash that only the general reader may judge."""
+    p = fixtures()[i]
+    cfg = p.cfg
+    m = formats.stwo_minimise(p)
+    rec = verifier.stwo_minimal_record(m)
+    obj = formats.stwo_minimal_to_json(m)
+    S, G, DECLINED = verifier.READER_STREAM, verifier.READER_GENERAL, verifier.READER_DECLINED
+
+    def both(text):
+        rs, gs = verifier.parse_stwo_minimal_text(cfg, text, reader=S)
+        rg, gg = verifier.parse_stwo_minimal_text(cfg, text, reader=G)
+        ra, ga = verifier.parse_stwo_minimal_text(cfg, text)
+        assert rs in (0, DECLINED) and ra == rg
+        if rs == 0:
+            assert rg == 0 and np.array_equal(gs, gg)
+        if ra == 0:
+            assert np.array_equal(ga, gg)
+        return rs, rg
+
+    compact = json.dumps(obj, separators=(",", ":")).encode()
+    for text in (compact, json.dumps(obj).encode(), json.dumps(obj, indent=1).encode(),
+                 b" \n" + compact.replace(b",", b" ,\t").replace(b":", b" : ") + b"\r\n "):
+        assert both(text) == (0, 0)
+        assert np.array_equal(verifier.parse_stwo_minimal_text(cfg, text, reader=S)[1], rec)
+    rng = np.random.default_rng(0x5EED2025 + 140 + i)  # the mutants of the test above
+    for mut in _min_text_mutants(json.dumps(obj).encode(), rng):
+        rs, rg = both(mut)
+        assert rs == DECLINED or rg == 0
+    # another member order, an extra member, a declared config that is not the verifier's: not the streaming reader's
+    assert both(json.dumps(dict(reversed(list(obj.items())))).encode()) == (DECLINED, 0)
+    assert both(json.dumps({**obj, "note": 1}).encode()) == (DECLINED, 0)
+    other = json.loads(compact)
+    other["config"]["fri_config"]["n_queries"] += 1
+    assert both(json.dumps(other).encode()) == (DECLINED, 1)
+    # numbers inside a hash: the first hash of the text is the trace root
+    at = compact.index(b'"commitments":[[') + len(b'"commitments":[[')
+    first = compact[at:compact.index(b",", at)]
+    for spelling, general in ((b"0" + first, 2), (b"256", 2), (b"1000", 2), (first + b".0", 2), (first + b"e0", 2), (b"-" + first, 2),
+                              (b" " + first + b" ", 0), (b"\n" + first, 0), (first + b"  ", 0)):
+        assert both(compact[:at] + spelling + compact[at + len(first):])[1] == general
+    # the last hashes of a text sit closer to its end than the fast byte-list path reads ahead: same answers there
+    assert both(compact + b" " * 300) == (0, 0)
