@@ -425,6 +425,12 @@ size_t ss_stwo_write_shared_text(const ss_stwo_cfg *cfg, const uint32_t *shared,
  * fmt is SS_TEXT_JSON, SS_TEXT_WIT or SS_TEXT_JSON_SHARED (record_out: the per-query record it expands to).  Scalar statement of the GPU reader's rule (ss_text.h); when it
  * returns 1 and record_out is not NULL, record_out holds the record.  No GPU involved.              */
 int ss_stwo_text_is_canonical(const ss_stwo_cfg *cfg, const char *text, size_t len, int fmt, uint32_t *record_out);
+/* ... fmt SS_TEXT_JSON_MINIMAL: record_out (ss_stwo_minimal_max_words words) receives the minimal record in CAPACITY form --
+ * the fixed words, then every list at the base it has when all lists have their largest length, the first n entries of
+ * each filled -- which is what the GPU reader writes for such texts (csrc/ss_text.h).  The two forms into each other:  */
+int ss_stwo_minimal_from_capacity(const ss_stwo_cfg *cfg, const uint32_t *capacity, uint32_t *minimal_out, size_t cap_words,
+                                  size_t *words_out);
+int ss_stwo_minimal_to_capacity(const ss_stwo_cfg *cfg, const uint32_t *minimal, size_t words, uint32_t *capacity_out);
 
 /* stark101 twins.  The protocol fixes the shape of a stark101 proof (10 FRI layers, Merkle paths of 13 and
  * 13 - layer siblings: stark101/scripts/fibsquare/prover.py:94-171), so canonical texts exist for that shape only;

@@ -18,6 +18,7 @@
 #include "ss_ingest.h"
 #include "ss_kernels.h"
 #include "ss_layout.h"
+#include "ss_minimal.h"
 #include "ss_sha256.h"
 #include "ss_stwo_checks.h"
 
@@ -952,7 +953,7 @@ extern "C" size_t ss_stwo_write_shared_text(const ss_stwo_cfg *c, const uint32_t
 
 extern "C" int ss_stwo_text_is_canonical(const ss_stwo_cfg *c, const char *text, size_t len, int fmt, uint32_t *record_out)
 {
-    if (!cfg_ok(c) || !text || (fmt != SS_TEXT_JSON && fmt != SS_TEXT_WIT && fmt != SS_TEXT_JSON_SHARED))
+    if (!cfg_ok(c) || !text || (fmt != SS_TEXT_JSON && fmt != SS_TEXT_WIT && fmt != SS_TEXT_JSON_SHARED && fmt != SS_TEXT_JSON_MINIMAL))
         return set_err(SS_ERR_ARG, "bad argument");
     // the template of the last (config, format) asked about is kept per thread: building one walks the whole text
     static thread_local TextTemplateHost h;
@@ -968,7 +969,35 @@ extern "C" int ss_stwo_text_is_canonical(const ss_stwo_cfg *c, const char *text,
     uint32_t *rec = record_out;
     if (!rec) { scratch.resize(std::max<size_t>(h.record_words, ss_stwo_record_words(c))); rec = scratch.data(); }
     if (fmt == SS_TEXT_JSON_SHARED) return shared_text_scan_reference(*c, h, text, len, rec) ? 1 : 0;
+    if (fmt == SS_TEXT_JSON_MINIMAL) return minimal_text_scan_reference(*c, h, text, len, rec) ? 1 : 0;  // (capacity form)
     return text_scan_reference(h.view(), text, len, rec) ? 1 : 0;
+}
+
+extern "C" int ss_stwo_minimal_from_capacity(const ss_stwo_cfg *c, const uint32_t *capacity, uint32_t *minimal_out, size_t cap_words,
+                                             size_t *words_out)
+{
+    if (!cfg_ok(c) || !capacity || !words_out) return set_err(SS_ERR_ARG, "bad argument");
+    const MinMap m = min_map(c->n_cols, c->lde_log, c->n_queries, c->n_layers);
+    bool ok = capacity[m.nv] <= m.Q && capacity[m.nv + 1] <= m.Q;
+    for (uint32_t l = 0; l <= m.K; l++) ok &= capacity[m.nfw + l] <= m.Q;
+    for (uint32_t t = 0; t < m.K + 3; t++) ok &= capacity[m.nhw + t] <= m.Q * min_tree_len(m.L, t);
+    if (!ok) return set_err(SS_ERR_ARG, "list lengths beyond the capacity of the config");
+    try {
+        std::vector<uint32_t> out;
+        minimal_compact(*c, capacity, out);
+        *words_out = out.size();
+        if (!minimal_out || cap_words < out.size()) return set_err(SS_ERR_ARG, "minimal record needs %zu words", out.size());
+        memcpy(minimal_out, out.data(), out.size() * 4);
+        return SS_OK;
+    } catch (const std::exception &) {
+        return set_err(SS_ERR_NOMEM, "out of host memory");
+    }
+}
+
+extern "C" int ss_stwo_minimal_to_capacity(const ss_stwo_cfg *c, const uint32_t *minimal, size_t words, uint32_t *capacity_out)
+{
+    if (!cfg_ok(c) || !minimal || !capacity_out) return set_err(SS_ERR_ARG, "bad argument");
+    return minimal_to_capacity(*c, minimal, words, capacity_out) ? SS_OK : set_err(SS_ERR_ARG, "not a minimal record of this config");
 }
 
 extern "C" size_t ss_s101_write_text(const uint32_t *record, int fmt, int python_separators, char *buf, size_t cap)

@@ -145,6 +145,8 @@ struct TextSink {
     }
     void cst(uint32_t v) { dec(v); }
     void list_begin(uint32_t) {}
+    void vals_begin(uint32_t) {}
+    void fw_begin(uint32_t) {}
     void dec256(uint32_t w)  // 8 words, most significant first, as a decimal integer
     {
         uint32_t limb[8];
@@ -174,6 +176,10 @@ struct SlotSink {
     std::vector<uint32_t> &at;  // byte offset of every number in `out`
     uint32_t list_at[kMaxTrees] = {}, list_tok[kMaxTrees] = {};  // where the first entry of a hash_witness list starts
     void list_begin(uint32_t t) { list_at[t] = (uint32_t)out.size(); list_tok[t] = (uint32_t)slots.size(); }
+    // (the minimal form's other lists: the two flat value lists, the fri_witness list of layer l)
+    uint32_t vals_at[2] = {}, vals_tok[2] = {}, fw_at[kMaxList + 1] = {}, fw_tok[kMaxList + 1] = {};
+    void vals_begin(uint32_t k) { vals_at[k] = (uint32_t)out.size(); vals_tok[k] = (uint32_t)slots.size(); }
+    void fw_begin(uint32_t l) { fw_at[l] = (uint32_t)out.size(); fw_tok[l] = (uint32_t)slots.size(); }
     void lit(const char *s) { out += s; }
     void num(uint32_t dst, uint32_t kind, const char *sample)
     {
@@ -228,15 +234,18 @@ void json_text(const ss_stwo_cfg &cfg, const M &m, uint32_t pow_bits, TextStyle 
     s.lit("{"); hash_witness(0); s.lit("}"); s.lit(cm);
     s.lit("{"); hash_witness(1); s.lit("}]"); s.lit(cm);
     key("queried_values"); s.lit("[[]"); s.lit(cm); s.lit("[");
+    s.vals_begin(0);
     for (uint32_t q = 0, n = m.n_vals(0); q < n; q++)
         for (uint32_t k = 0; k < m.N; k++) { if (q | k) s.lit(cm); s.u32(m.trace_vals(q) + k); }
     s.lit("]"); s.lit(cm); s.lit("[");
+    s.vals_begin(1);
     for (uint32_t q = 0, n = m.n_vals(1); q < n; q++)
         for (uint32_t k = 0; k < kCp; k++) { if (q | k) s.lit(cm); s.u32(m.cp_vals(q) + k); }
     s.lit("]]"); s.lit(cm);
     key("proof_of_work"); s.u64(m.nonce()); s.lit(cm);
     auto layer = [&](uint32_t l) {
         s.lit("{"); key("fri_witness"); s.lit("[");
+        s.fw_begin(l);
         for (uint32_t q = 0, n = m.n_fw(l); q < n; q++) { if (q) s.lit(cm); qm31(m.fri_wit(l, q)); }
         s.lit("]"); s.lit(cm); key("decommitment"); s.lit("{");
         hash_witness(2 + l);
@@ -554,7 +563,7 @@ void stwo_build_template(const ss_stwo_cfg &cfg, int fmt, TextTemplateHost &out)
 {
     out = TextTemplateHost();
     uint32_t bits = 0;
-    if (!cfg_writable(cfg) || (fmt != SS_TEXT_JSON && fmt != SS_TEXT_WIT && fmt != SS_TEXT_JSON_SHARED)) return;
+    if (!cfg_writable(cfg) || (fmt != SS_TEXT_JSON && fmt != SS_TEXT_WIT && fmt != SS_TEXT_JSON_SHARED && fmt != SS_TEXT_JSON_MINIMAL)) return;
     if (fmt != SS_TEXT_WIT && !pow_bits_of(cfg.pow_target, bits)) return;  // no proof.json can declare this target
     std::string sample;
     std::vector<uint32_t> at;
@@ -571,6 +580,45 @@ void stwo_build_template(const ss_stwo_cfg &cfg, int fmt, TextTemplateHost &out)
         I.entry_skel = 32 + 31 + 2 + 1;
         for (uint32_t t = 0; t < I.n_trees; t++) { I.S[t] = mark_skel[t]; I.T[t] = s.list_tok[t]; I.n[t] = sm.count[t]; }
         out.record_words = sm.m.nodes + 8 * sm.m.max_nodes;
+        out.tbase = 0;
+        out.ok = true;
+        return;
+    }
+    if (fmt == SS_TEXT_JSON_MINIMAL) {
+        // the full-length text over a capacity-form minimal record: every list as long as the config allows
+        const MinMap mm = min_map(cfg.n_cols, cfg.lde_log, cfg.n_queries, cfg.n_layers);
+        std::vector<uint32_t> head(mm.data, 0);
+        head[mm.nv] = head[mm.nv + 1] = mm.Q;
+        for (uint32_t l = 0; l <= mm.K; l++) head[mm.nfw + l] = mm.Q;
+        for (uint32_t t = 0; t < mm.K + 3; t++) head[mm.nhw + t] = mm.Q * min_tree_len(mm.L, t);
+        const MRec mr(cfg, head.data());
+        json_text(cfg, mr, bits, kStyleCompact, s);
+        MinTextInfo &I = out.minfo;
+        I.n_lists = 2 * mm.K + 6; I.N = mm.N; I.Q = mm.Q; I.L = mm.L; I.K = mm.K;
+        std::vector<uint32_t> marks, mark_skel;
+        auto list = [&](uint32_t j, uint32_t at_byte, uint32_t tok, uint32_t n, uint32_t es, uint32_t et, uint32_t word, uint32_t per) {
+            marks.push_back(at_byte);
+            I.T[j] = tok; I.n[j] = n; I.es[j] = es; I.et[j] = et; I.word[j] = word; I.per[j] = per;
+        };
+        const uint32_t hash_skel = 32 + 31 + 2 + 1, qm31_skel = 13 + 1;  // "[m,..,m]," and "[[m,m],[m,m]],"
+        list(0, s.list_at[0], s.list_tok[0], mr.nhw[0], hash_skel, 32, mm.nhw + 0, 1);
+        list(1, s.list_at[1], s.list_tok[1], mr.nhw[1], hash_skel, 32, mm.nhw + 1, 1);
+        list(2, s.vals_at[0], s.vals_tok[0], mm.Q * mm.N, 2, 1, mm.nv, mm.N);
+        list(3, s.vals_at[1], s.vals_tok[1], mm.Q * kCp, 2, 1, mm.nv + 1, kCp);
+        for (uint32_t l = 0; l <= mm.K; l++) {
+            list(4 + 2 * l, s.fw_at[l], s.fw_tok[l], mm.Q, qm31_skel, 4, mm.nfw + l, 1);
+            list(5 + 2 * l, s.list_at[2 + l], s.list_tok[2 + l], mr.nhw[2 + l], hash_skel, 32, mm.nhw + 2 + l, 1);
+        }
+        if (!skeleton_of(sample, at, out, &marks, &mark_skel) || mark_skel.size() != I.n_lists) { out = TextTemplateHost(); return; }
+        bool good = true;
+        for (uint32_t j = 0; j < I.n_lists && good; j++) {  // the entry sizes above are what the writer prints
+            I.S[j] = mark_skel[j];
+            const uint32_t end = I.S[j] + I.n[j] * I.es[j] - 1;
+            good = I.n[j] >= 1 && end < out.skel_len && out.skel[end] == ']' && out.skel[I.S[j] - 1] == '[' &&
+                   (I.n[j] == 1 || out.skel[I.S[j] + I.es[j] - 1] == ',') && (j == 0 || I.S[j] > I.S[j - 1]);
+        }
+        if (!good) { out = TextTemplateHost(); return; }
+        out.record_words = (uint32_t)min_max_words(mm);
         out.tbase = 0;
         out.ok = true;
         return;
@@ -744,6 +792,92 @@ bool shared_text_scan_reference(const ss_stwo_cfg &cfg, const TextTemplateHost &
     for (uint32_t q = 0; q < I.Q; q++)
         if (cap[m.qry + q] != h.pos[q]) return false;
     shared_expand_host(m, plan, cap.data(), true, record);
+    return true;
+}
+
+bool minimal_to_capacity(const ss_stwo_cfg &cfg, const uint32_t *rec, size_t words, uint32_t *cap)
+{
+    const MinMap m = min_map(cfg.n_cols, cfg.lde_log, cfg.n_queries, cfg.n_layers);
+    if (words < m.data) return false;
+    if (rec[m.nv] > m.Q || rec[m.nv + 1] > m.Q) return false;
+    size_t o = m.data, c = m.data;
+    memcpy(cap, rec, (size_t)m.data * 4);
+    auto move = [&](size_t have, size_t room) {
+        if (o + have > words) return false;
+        memcpy(cap + c, rec + o, have * 4);
+        o += have;
+        c += room;
+        return true;
+    };
+    if (!move((size_t)rec[m.nv] * m.N, (size_t)m.Q * m.N) || !move((size_t)rec[m.nv + 1] * kCp, (size_t)m.Q * kCp)) return false;
+    for (uint32_t l = 0; l <= m.K; l++)
+        if (rec[m.nfw + l] > m.Q || !move(4 * (size_t)rec[m.nfw + l], 4 * (size_t)m.Q)) return false;
+    for (uint32_t t = 0; t < m.K + 3; t++) {
+        const size_t room = (size_t)m.Q * min_tree_len(m.L, t);
+        if (rec[m.nhw + t] > room || !move(8 * (size_t)rec[m.nhw + t], 8 * room)) return false;
+    }
+    return o == words;
+}
+
+void minimal_compact(const ss_stwo_cfg &cfg, const uint32_t *cap, std::vector<uint32_t> &out)
+{
+    const MinMap m = min_map(cfg.n_cols, cfg.lde_log, cfg.n_queries, cfg.n_layers);
+    out.assign(cap, cap + m.data);
+    size_t c = m.data;
+    auto move = [&](size_t have, size_t room) { out.insert(out.end(), cap + c, cap + c + have); c += room; };
+    move((size_t)cap[m.nv] * m.N, (size_t)m.Q * m.N);
+    move((size_t)cap[m.nv + 1] * kCp, (size_t)m.Q * kCp);
+    for (uint32_t l = 0; l <= m.K; l++) move(4 * (size_t)cap[m.nfw + l], 4 * (size_t)m.Q);
+    for (uint32_t t = 0; t < m.K + 3; t++) move(8 * (size_t)cap[m.nhw + t], 8 * (size_t)m.Q * min_tree_len(m.L, t));
+}
+
+bool minimal_text_scan_reference(const ss_stwo_cfg &cfg, const TextTemplateHost &th, const char *text, size_t len, uint32_t *cap)
+{
+    if (!th.ok || len > 0xffffffffu) return false;
+    const TextTemplate t = th.view();
+    const MinTextInfo &I = th.minfo;
+    const unsigned char *p = reinterpret_cast<const unsigned char *>(text);
+    // pass 1: the numbers in front of every landmark (what the device's scan leaves per window, text_landmark_kernel)
+    std::vector<uint32_t> lm[3];
+    {
+        uint32_t run = kRunNone, in_str = 0, tok = 0;
+        for (size_t i = 0; i < len; i++) {
+            const uint32_t c = p[i];
+            if (txt_is_bad(c)) return false;
+            const int kind = min_text_landmark(p + i, (uint32_t)(len - i));
+            if (kind >= 0) {
+                if (lm[kind].size() >= kMaxLandmarks) return false;
+                lm[kind].push_back(tok);
+            }
+            if (scan_byte(c, run, in_str) & 2) tok++;
+        }
+    }
+    uint32_t counts[kMaxTextLists];
+    if (!min_text_counts(I, lm[kLmHash].data(), (uint32_t)lm[kLmHash].size(), lm[kLmColumn].data(), (uint32_t)lm[kLmColumn].size(),
+                         lm[kLmPow].data(), (uint32_t)lm[kLmPow].size(), counts))
+        return false;
+    MinTextGaps g;
+    min_text_gaps(I, counts, t.skel_len, t.n_slots, g);
+    // pass 2: the scan of text_scan_reference through the gap maps
+    uint32_t run = kRunNone, in_str = 0, sk = 0, tok = 0;
+    for (size_t i = 0; i < len; i++) {
+        const uint32_t c = p[i];
+        const uint32_t r = scan_byte(c, run, in_str);
+        if (r & 2) {
+            if (sk >= g.skel_len || tok >= g.n_slots || t.skel[gap_map(g.G, g.D, I.n_lists, sk)] != kSkelMark) return false;
+            sk++;
+            size_t e = i;
+            while (e < len && e - i <= kMaxTokenBytes && txt_is_alnum(p[e])) e++;
+            if (!place_number(t.slots[gap_map(g.Gk, g.Dk, I.n_lists, tok)], p + i, e - i, cap)) return false;
+            tok++;
+        }
+        if (r & 1) {
+            if (sk >= g.skel_len || t.skel[gap_map(g.G, g.D, I.n_lists, sk)] != c) return false;
+            sk++;
+        }
+    }
+    if (sk != g.skel_len || tok != g.n_slots || in_str) return false;
+    for (uint32_t j = 0; j < I.n_lists; j++) cap[I.word[j]] = counts[j] / I.per[j];
     return true;
 }
 

@@ -147,6 +147,89 @@ SS_HD inline uint32_t gap_map(const uint32_t *G, const uint32_t *D, uint32_t n_t
     return p + d;
 }
 
+// ---- minimal proof.json (one sorted, deduplicated decommitment per tree: csrc/ss_minimal.h, formats.stwo_minimal_to_json)
+// The same idea with more lists and nothing in the text that says how long they are.  2 K + 6 lists have lengths that are
+// data -- in text order: the hash_witness of the trace and of the composition tree, the two flat queried_values lists, then
+// per FRI layer its fri_witness and its hash_witness -- and every entry of a list looks the same (a hash: 66 skeleton bytes
+// and 32 numbers; a value: 2 and 1; a QM31 evaluation: 14 and 4).  The template is the FULL-LENGTH text (every list at the
+// capacity the config allows: csrc/ss_minimal.h min_max_words) over a minimal record in CAPACITY form (every list at a fixed
+// base with room for that many entries).  The lengths of one text are FOUND first: three member names are landmarks --
+// "hash_witness", "column_witness", "proof_of_work" sit right behind / in front of the lists -- and the number of NUMBERS in
+// front of each landmark (a by-product of the tokenizer's scan) gives every list length by subtraction.  That is only a
+// guess: the place pass compares the whole text with the template those lengths imply, so a text whose landmarks lie (a
+// member name inside a string value, another member order) simply fails the comparison and goes to the host reader.
+constexpr uint32_t kMaxTextLists = 68;  // 2 K + 6, K <= 30
+constexpr uint32_t kMaxLandmarks = 36;  // K + 4 of a kind
+enum : uint32_t { kLmHash = 0, kLmColumn = 1, kLmPow = 2 };  // "hash_w.. , "colu.. , "proof_..
+struct MinTextInfo {
+    uint32_t n_lists, N, Q, L, K;
+    uint32_t S[kMaxTextLists];   // skeleton position of the first entry of list j in the full-length text (text order)
+    uint32_t T[kMaxTextLists];   // index of its first number
+    uint32_t n[kMaxTextLists];   // entries of the full-length list
+    uint32_t es[kMaxTextLists];  // skeleton bytes from one entry to the next
+    uint32_t et[kMaxTextLists];  // numbers per entry
+    uint32_t word[kMaxTextLists];  // the record word that holds this list's length, as the record counts it (rows / witnesses / hashes)
+    uint32_t per[kMaxTextLists];   // text entries per counted unit (a trace row is N flat values, a composition row 16)
+};
+struct MinTextGaps {
+    uint32_t skel_len, n_slots;
+    uint32_t G[kMaxTextLists], D[kMaxTextLists], Gk[kMaxTextLists], Dk[kMaxTextLists];
+};
+// text-order list index: 0 / 1 = hash_witness of the trace / composition tree, 2 / 3 = their queried values,
+// 4 + 2 l = fri_witness of layer l, 5 + 2 l = its hash_witness
+SS_HD inline void min_text_gaps(const MinTextInfo &I, const uint32_t *counts, uint32_t full_skel, uint32_t full_slots,
+                                MinTextGaps &g)
+{
+    uint32_t d = 0, dk = 0;
+    for (uint32_t j = 0; j < I.n_lists; j++) {
+        // c entries occupy c * es - 1 skeleton bytes (no comma behind the last one), an empty list none
+        const uint32_t c = counts[j], kept = c ? c * I.es[j] - 1 : 0, full = I.n[j] * I.es[j] - 1;
+        g.G[j] = I.S[j] + kept - d;
+        g.Gk[j] = I.T[j] + c * I.et[j] - dk;
+        d += full - kept;
+        dk += (I.n[j] - c) * I.et[j];
+        g.D[j] = d;
+        g.Dk[j] = dk;
+    }
+    g.skel_len = full_skel - d;
+    g.n_slots = full_slots - dk;
+}
+// Landmarks -> list lengths (entries, text order).  h / c / p: the numbers in front of every "hash_w.. / "colu.. / "proof_..
+// of the text, ascending.  false = not the landmarks of a minimal proof.json of this config.
+SS_HD inline bool min_text_counts(const MinTextInfo &I, const uint32_t *h, uint32_t nh, const uint32_t *c, uint32_t nc,
+                                  const uint32_t *p, uint32_t np, uint32_t *counts)
+{
+    if (nh != I.K + 4 || nc != I.K + 4 || np != 1) return false;
+    auto div = [](uint32_t hi, uint32_t lo, uint32_t by, uint32_t cap, uint32_t &out) {
+        if (hi < lo || (hi - lo) % by || (hi - lo) / by > cap) return false;
+        out = (hi - lo) / by;
+        return true;
+    };
+    // the preprocessed tree's empty lists, then the two trees of the proof
+    if (h[0] != I.T[0] || c[0] != I.T[0] || h[1] != I.T[0] || h[2] != c[1]) return false;
+    if (!div(c[1], h[1], 32, I.n[0], counts[0]) || !div(c[2], h[2], 32, I.n[1], counts[1])) return false;
+    uint32_t rows;  // the two flat value lists together: rows x (N + 16) numbers (they must describe the same positions)
+    if (!div(p[0], c[2], I.N + 16, I.Q, rows)) return false;
+    counts[2] = rows * I.N;
+    counts[3] = rows * 16;
+    uint32_t prev = p[0] + 1;  // the nonce
+    for (uint32_t l = 0; l <= I.K; l++) {
+        if (!div(h[3 + l], prev, 4, I.n[4 + 2 * l], counts[4 + 2 * l])) return false;
+        if (!div(c[3 + l], h[3 + l], 32, I.n[5 + 2 * l], counts[5 + 2 * l])) return false;
+        prev = c[3 + l] + 32;  // the layer's commitment
+    }
+    return true;
+}
+// is a landmark's name at text[i ..)?  (avail = bytes of the text from i on)
+SS_HD inline int min_text_landmark(const uint8_t *t, uint32_t avail)
+{
+    if (avail < 7 || t[0] != '"') return -1;
+    if (t[1] == 'h') return (t[2] == 'a' && t[3] == 's' && t[4] == 'h' && t[5] == '_' && t[6] == 'w') ? (int)kLmHash : -1;
+    if (t[1] == 'c') return (t[2] == 'o' && t[3] == 'l' && t[4] == 'u') ? (int)kLmColumn : -1;
+    if (t[1] == 'p') return (t[2] == 'r' && t[3] == 'o' && t[4] == 'o' && t[5] == 'f' && t[6] == '_') ? (int)kLmPow : -1;
+    return -1;
+}
+
 // The positions a shared-path text names, read BACKWARDS from its end: `... [p0, p1, .., pQ-1] }` with JSON whitespace
 // anywhere between the tokens.  tail[0 .. n) are the last n bytes of the text.  Only a first guess: the place pass
 // compares the whole text with the template these positions imply and stores the numbers it finds, and the two
@@ -190,6 +273,7 @@ bool stwo_write_wit(const ss_stwo_cfg &cfg, const uint32_t *record, std::string 
 // Host-side owner of a template.
 struct TextTemplateHost {
     SharedTextInfo sinfo{};        // format 3 only
+    MinTextInfo minfo{};           // format 4 only
     std::vector<uint8_t> skel;     // skel_len bytes + kSkelSlack zeros
     uint32_t skel_len = 0;
     std::vector<TextSlot> slots;
@@ -199,7 +283,8 @@ struct TextTemplateHost {
     bool ok = false;               // false: no canonical text exists for this config / format (fast path off)
     TextTemplate view() const;
 };
-// fmt: SS_TEXT_JSON, SS_TEXT_WIT or SS_TEXT_JSON_SHARED (the full-length text over a capacity-form shared record)
+// fmt: SS_TEXT_JSON, SS_TEXT_WIT, SS_TEXT_JSON_SHARED (the full-length text over a capacity-form shared record) or
+// SS_TEXT_JSON_MINIMAL (the full-length text over a capacity-form minimal record)
 void stwo_build_template(const ss_stwo_cfg &cfg, int fmt, TextTemplateHost &out);
 // shared record (include/ss_verify.h) -> the shared-path proof.json, byte for byte json.dumps(formats.stwo_to_json(p,
 // shared=True)); false when `shared` is no shared record of the config
@@ -211,6 +296,16 @@ bool stwo_write_json_minimal(const ss_stwo_cfg &cfg, const uint32_t *minimal, si
 // rule) into `record` (the per-query record).  scratch: shared_capacity_words(cfg) words.
 bool shared_text_scan_reference(const ss_stwo_cfg &cfg, const TextTemplateHost &t, const char *text, size_t len,
                                 uint32_t *record);
+
+// Scalar statement of the fast path for format 4 (the minimal proof.json): landmarks, list lengths, gaps, the scan of
+// text_scan_reference through the gap maps into a capacity-form minimal record, which `capacity` receives
+// (min_max_words words).  minimal_compact turns that into the minimal record of include/ss_verify.h.
+bool minimal_text_scan_reference(const ss_stwo_cfg &cfg, const TextTemplateHost &t, const char *text, size_t len,
+                                 uint32_t *capacity);
+// minimal record <-> its capacity form (every list at a fixed base: the layout of a minimal record whose lists all have
+// their largest length).  to_capacity: false when `minimal` is no minimal record of the config (sizes, counts).
+bool minimal_to_capacity(const ss_stwo_cfg &cfg, const uint32_t *minimal, size_t words, uint32_t *capacity);
+void minimal_compact(const ss_stwo_cfg &cfg, const uint32_t *capacity, std::vector<uint32_t> &minimal);
 
 // stark101 (stark101/scripts/fibsquare/prover.py:108,143-167 writes proof.json, stark101/scripts/generate_wit.py:13-30
 // the .wit).  The protocol fixes the proof's shape: an LDE domain of 2^13 points, so Merkle paths of 13 siblings for the
