@@ -342,7 +342,7 @@ int ss_stwo_verify_shared_records(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n,
 /* The minimal proof.json: proof.json with one decommitment per tree (minimal record above; formats.stwo_minimal_to_json,
  * `cli convert --to json-minimal`) -- the lists as upstream stwo's prover fills them before the reference's adapter cuts them
  * per query (scripts/generate_wit.py:36-42).  Nothing in the text names its form; with two or more queries its lists are
- * shorter than n_queries equal shares, with one query the two forms are the same bytes.  Read by the host reader.  */
+ * shorter than n_queries equal shares, with one query the two forms are the same bytes.                                   */
 #define SS_TEXT_JSON_MINIMAL 4
 /* text -> minimal record (0 / SS_STATUS_CONFIG_MISMATCH / SS_STATUS_MALFORMED; *words_out = its size, written when it fits
  * cap_words, SS_ERR_ARG otherwise) and back (the text's length, 0 = no minimal record of the config).  No GPU involved. */
@@ -401,9 +401,14 @@ int ss_stwo_verify_files(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const ch
  * it and ignored); non-canonical texts are read by the host reader from the same buffer.  Same verdicts as ss_stwo_verify_texts. */
 int ss_stwo_verify_texts_pinned(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const char *blob, const uint64_t *offs,
                                 const size_t *lens, int fmt, uint32_t *status_host, ss_ingest_stats *stats);
-/* minimal proof.json texts -> verdicts (host reader on the library's worker threads, then ss_stwo_verify_minimal_records) */
+/* minimal proof.json texts -> verdicts through the same pipeline: the GPU reader finds each text's list lengths from the
+ * member names next to the lists, compares the text with the template those lengths imply and fills a minimal record in
+ * capacity form (csrc/ss_text.h, ss_textdev.hip); ss_minimal.hip verifies from there (no per-query record is ever made); texts
+ * the GPU reader does not take go to the host readers above.  _pinned: as ss_stwo_verify_texts_pinned.                    */
 int ss_stwo_verify_minimal_texts(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const char *const *texts,
                                  const size_t *lens, uint32_t *status_host, ss_ingest_stats *stats);
+int ss_stwo_verify_minimal_texts_pinned(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const void *blob, const uint64_t *offs,
+                                        const size_t *lens, uint32_t *status_host, ss_ingest_stats *stats);
 int ss_s101_verify_texts(ss_ctx *ctx, size_t n, const char *const *texts, const size_t *lens, int fmt,
                          uint32_t *status_host, ss_ingest_stats *stats);
 int ss_s101_verify_files(ss_ctx *ctx, size_t n, const char *const *paths, int fmt, uint32_t *status_host,
@@ -442,7 +447,8 @@ int ss_s101_text_is_canonical(const char *text, size_t len, int fmt, uint32_t *r
 /* The GPU reader alone (diagnostic): n texts of format fmt (SS_TEXT_JSON / SS_TEXT_WIT / SS_TEXT_JSON_SHARED: read
  * into shared records and expanded, all on the GPU) -> records_host
  * (n * ss_stwo_record_words words) and outcome_host[i] = 0 (canonical: record i written by the GPU) or 1
- * (left to the host reader; record i unspecified).  Synchronous; outcome equals ss_stwo_text_is_canonical. */
+ * (left to the host reader; record i unspecified).  Synchronous; outcome equals ss_stwo_text_is_canonical.
+ * SS_TEXT_JSON_MINIMAL: records_host holds n * ss_stwo_minimal_max_words words and receives capacity-form minimal records. */
 int ss_stwo_read_texts(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const char *const *texts, const size_t *lens,
                        int fmt, uint32_t *records_host, uint32_t *outcome_host);
 

@@ -315,9 +315,19 @@ extern "C" int ss_stwo_verify_minimal_dev(ss_ctx *ctx, const ss_stwo_cfg *c, siz
                                           const uint64_t *offs_dev, uint32_t *batch_dev, void *workspace, size_t workspace_bytes,
                                           uint32_t *status, uint32_t *accept_count, int phases, void *stream_)
 {
+    if (!offs_dev) return set_err(SS_ERR_ARG, "null/empty argument");
+    return stwo_verify_minimal_any(ctx, c, n, min_dev, offs_dev, batch_dev, workspace, workspace_bytes, status, accept_count, phases,
+                                   (hipStream_t)stream_);
+}
+
+// offs_dev == nullptr: capacity-form records at a fixed stride (the GPU reader's output, csrc/ss_minimal.hip MinArgs)
+int ss::stwo_verify_minimal_any(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const uint32_t *min_dev, const uint64_t *offs_dev,
+                                uint32_t *batch_dev, void *workspace, size_t workspace_bytes, uint32_t *status,
+                                uint32_t *accept_count, int phases, hipStream_t stream_)
+{
     SS_DEVICE_GUARD(ctx);
     if (!cfg_ok(c)) return set_err(SS_ERR_ARG, "unsupported stwo config");
-    if (!n || !min_dev || !offs_dev || !batch_dev || !workspace || !status) return set_err(SS_ERR_ARG, "null/empty argument");
+    if (!n || !min_dev || !batch_dev || !workspace || !status) return set_err(SS_ERR_ARG, "null/empty argument");
     if (n * (size_t)kMaxQueries > 0x7fffffffu) return set_err(SS_ERR_ARG, "batch too large");
     if (!(phases & SS_PHASE_ALL)) return set_err(SS_ERR_ARG, "no phase selected");
     const StwoLayout y = lay_of(c, n, true);
@@ -876,58 +886,21 @@ extern "C" size_t ss_stwo_write_minimal_text(const ss_stwo_cfg *c, const uint32_
 extern "C" int ss_stwo_verify_minimal_texts(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *const *texts,
                                             const size_t *lens, uint32_t *status_host, ss_ingest_stats *stats)
 {
-    if (!ctx || !texts || !lens || !status_host) return set_err(SS_ERR_ARG, "null argument");
-    if (!cfg_ok(c)) return set_err(SS_ERR_ARG, "unsupported stwo config");
-    if (!n) return set_err(SS_ERR_ARG, "empty batch");
+    if (!texts) return set_err(SS_ERR_ARG, "null argument");
     try {
-        const double t0 = now_s();
-        const size_t threads = std::max<size_t>(1, effective_cpus());
-        double parse_s = 0;
-        uint64_t text_bytes = 0, rec_bytes = 0;
-        // blocks of 2 048 texts: the parsed records of one block are all that is held at a time
-        const size_t kBlock = 2048;
-        std::vector<std::vector<uint32_t>> recs(std::min(n, kBlock));
-        std::vector<uint32_t> outcome(recs.size());
-        std::vector<int> failed(recs.size());
-        for (size_t lo = 0; lo < n; lo += kBlock) {
-            const size_t cnt = std::min(kBlock, n - lo);
-            const double tp0 = now_s();
-            std::fill(failed.begin(), failed.end(), 0);
-            parallel_for(cnt, [&](size_t i) {
-                try {
-                    const ParseResult r = texts[lo + i] ? stwo_parse_minimal_text(*c, texts[lo + i], lens[lo + i], recs[i]) : kMalformed;
-                    outcome[i] = r == kParsed ? 0 : r == kConfigMismatch ? SS_STATUS_CONFIG_MISMATCH : SS_STATUS_MALFORMED;
-                } catch (const std::exception &) {
-                    failed[i] = 1;
-                }
-            }, threads);
-            for (size_t i = 0; i < cnt; i++)
-                if (failed[i]) return set_err(SS_ERR_NOMEM, "host reader: out of memory");
-            parse_s += now_s() - tp0;
-            std::vector<const uint32_t *> ptrs;
-            std::vector<size_t> words, where;
-            for (size_t i = 0; i < cnt; i++) {
-                text_bytes += lens[lo + i];
-                status_host[lo + i] = outcome[i];
-                if (!outcome[i]) { ptrs.push_back(recs[i].data()); words.push_back(recs[i].size()); where.push_back(lo + i); rec_bytes += recs[i].size() * 4; }
-            }
-            if (!ptrs.empty()) {
-                std::vector<uint32_t> st(ptrs.size());
-                const int rc = ss_stwo_verify_minimal_records(ctx, c, ptrs.size(), ptrs.data(), words.data(), st.data());
-                if (rc) return rc;
-                for (size_t k = 0; k < where.size(); k++) status_host[where[k]] = st[k];
-            }
-        }
-        if (stats) {
-            memset(stats, 0, sizeof *stats);
-            stats->parse_s = parse_s;
-            stats->total_s = now_s() - t0;
-            stats->text_bytes = text_bytes;
-            stats->record_bytes = rec_bytes;
-            stats->threads = (uint32_t)threads;
-            stats->host_parsed = (uint32_t)std::min<size_t>(n, 0xffffffffu);
-        }
-        return SS_OK;
+        return stwo_minimal_ingest_dev(ctx, c, n, texts, lens, status_host, stats);
+    } catch (const std::exception &) {
+        return set_err(SS_ERR_NOMEM, "out of host memory");
+    }
+}
+
+extern "C" int ss_stwo_verify_minimal_texts_pinned(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const void *blob,
+                                                   const uint64_t *offs, const size_t *lens, uint32_t *status_host,
+                                                   ss_ingest_stats *stats)
+{
+    if (!blob || !offs) return set_err(SS_ERR_ARG, "null argument");
+    try {
+        return stwo_minimal_ingest_dev(ctx, c, n, nullptr, lens, status_host, stats, (const uint8_t *)blob, offs);
     } catch (const std::exception &) {
         return set_err(SS_ERR_NOMEM, "out of host memory");
     }

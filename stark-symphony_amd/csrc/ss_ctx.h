@@ -72,6 +72,7 @@ struct DevTemplate {
     int fmt;
     bool ok;            // false: no fast path for this config / format
     SharedTextInfo sinfo;  // format SS_TEXT_JSON_SHARED
+    MinTextInfo minfo;     // format SS_TEXT_JSON_MINIMAL
     void *skel = nullptr, *slots = nullptr, *trailer = nullptr;
     TextTemplate view;  // device pointers
 };
@@ -140,6 +141,11 @@ int shared_expand_launch(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const uint
 int stwo_minimal_head(ss_ctx *ctx, const ss_stwo_cfg *c, const StwoLayout &y, const uint32_t *recs_dev, const uint64_t *offs_dev,
                       uint32_t *batch, uint32_t *ws, uint32_t *status, hipStream_t s);
 
+// ss_stwo_verify_minimal_dev with offs_dev == nullptr allowed: capacity-form records at a stride of ss_stwo_minimal_max_words
+int stwo_verify_minimal_any(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const uint32_t *min_dev, const uint64_t *offs_dev,
+                            uint32_t *batch_dev, void *workspace, size_t workspace_bytes, uint32_t *status, uint32_t *accept_count,
+                            int phases, hipStream_t stream);
+
 int grow(GrowBuf &b, size_t bytes, bool pinned);  // (re)allocates when too small; contents are not kept
 void release(GrowBuf &b);
 
@@ -150,6 +156,10 @@ bool read_file(const char *path, std::string &out);
 int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *const *texts, const size_t *lens,
                     const char *const *paths, int fmt, uint32_t *status_host, ss_ingest_stats *stats,
                     const uint8_t *blob = nullptr, const uint64_t *blob_offs = nullptr);  // blob: the texts in one caller-pinned buffer
+// the minimal proof.json (SS_TEXT_JSON_MINIMAL): read into capacity-form minimal records on the GPU, verified from there
+int stwo_minimal_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *const *texts, const size_t *lens,
+                            uint32_t *status_host, ss_ingest_stats *stats, const uint8_t *blob = nullptr,
+                            const uint64_t *blob_offs = nullptr);
 int s101_ingest_dev(ss_ctx *ctx, size_t n, const char *const *texts, const size_t *lens, const char *const *paths, int fmt,
                     uint32_t *status_host, ss_ingest_stats *stats);
 // ss_s101_verify_records for a caller that already holds ctx->mu

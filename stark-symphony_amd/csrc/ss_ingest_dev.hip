@@ -86,7 +86,8 @@ bool same_text_cfg(const ss_stwo_cfg &a, const ss_stwo_cfg &b)
 }
 
 // the device copy of (cfg, fmt)'s template, built on first use
-int template_of(ss_ctx *ctx, const ss_stwo_cfg &cfg, int fmt, hipStream_t s, TextTemplate &view, SharedTextInfo *sinfo = nullptr)
+int template_of(ss_ctx *ctx, const ss_stwo_cfg &cfg, int fmt, hipStream_t s, TextTemplate &view, SharedTextInfo *sinfo = nullptr,
+                MinTextInfo *minfo = nullptr)
 {
     TextPath &tp = ctx->tp;
     for (size_t i = 0; i < tp.templates.size(); i++) {
@@ -96,6 +97,7 @@ int template_of(ss_ctx *ctx, const ss_stwo_cfg &cfg, int fmt, hipStream_t s, Tex
         tp.templates.push_back(t);
         view = t.ok ? t.view : TextTemplate();
         if (sinfo) *sinfo = t.sinfo;
+        if (minfo) *minfo = t.minfo;
         return SS_OK;
     }
     if (tp.templates.size() >= 12) {  // a caller that cycles through many configs: drop the least recently used one
@@ -115,8 +117,9 @@ int template_of(ss_ctx *ctx, const ss_stwo_cfg &cfg, int fmt, hipStream_t s, Tex
     if (cfg.n_cols == 0) s101_build_template(fmt, h);  // the key s101_ingest_dev uses
     else stwo_build_template(cfg, fmt, h);
     DevTemplate d{};
-    d.cfg = cfg; d.fmt = fmt; d.ok = h.ok; d.sinfo = h.sinfo;
+    d.cfg = cfg; d.fmt = fmt; d.ok = h.ok; d.sinfo = h.sinfo; d.minfo = h.minfo;
     if (sinfo) *sinfo = h.sinfo;
+    if (minfo) *minfo = h.minfo;
     if (h.ok) {
         HIP_TRY(hipMalloc(&d.skel, h.skel.size()));
         HIP_TRY(hipMalloc(&d.slots, h.slots.size() * sizeof(TextSlot)));
@@ -191,8 +194,10 @@ long read_into(const char *path, uint8_t *dst, size_t cap)
 // What differs between the proof families behind the one pipeline.
 struct Family {
     size_t W = 0;                 // words of a record on the device
-    TextTemplate tmpl[3];         // device views: proof.json, proof.wit, shared-path proof.json (stwo only)
+    TextTemplate tmpl[4];         // device views: proof.json, proof.wit, shared-path proof.json (stwo only), minimal proof.json
     SharedTextInfo sinfo{};       // of tmpl[2]
+    MinTextInfo minfo{};          // of tmpl[3]
+    bool minimal = false;         // every text is a minimal proof.json (format 3): records are capacity-form minimal records
     const ss_stwo_cfg *shared_cfg = nullptr;  // not null: shared-path texts are read and expanded on the GPU
     const char *wit_key = "";     // the member name a .wit starts with (format sniffing for the GPU reader's first guess)
     bool zero_records = false;    // records have padding words the GPU reader does not write
@@ -220,7 +225,10 @@ static int ingest_pipeline(ss_ctx *ctx, const Family &F, size_t n, const char *c
     args.tmpl[0] = F.tmpl[0];
     args.tmpl[1] = F.tmpl[1];
     args.tmpl[2] = F.tmpl[2];
+    args.tmpl[3] = F.tmpl[3];
     args.sinfo = F.sinfo;
+    args.minfo = F.minfo;
+    const bool min_ok = F.minimal && F.tmpl[3].skel;
     args.record_words = (uint32_t)W;
     const bool shared_ok = F.shared_cfg && F.tmpl[2].skel;
     const size_t SW = shared_ok ? F.tmpl[2].record_words : 0;  // words of a capacity-form shared record
@@ -296,6 +304,7 @@ static int ingest_pipeline(ss_ctx *ctx, const Family &F, size_t n, const char *c
         if ((rc = grow(tp.win_dev[b], max_windows * (4 + sizeof(WinSum) + sizeof(WinIn)), false))) return rc;
         if (shared_ok && ((rc = grow(tp.shrec_dev[b], max_cnt * SW * 4, false)) || (rc = grow(tp.hint_dev[b], max_cnt * sizeof(TextHint), false))))
             return rc;
+        if (min_ok && (rc = grow(tp.hint_dev[b], max_cnt * sizeof(MinHint), false))) return rc;
     }
     if ((rc = grow(tp.batch_dev, words * 4, false))) return rc;
     if ((rc = grow(tp.ws_dev, wsb, false))) return rc;
@@ -355,7 +364,7 @@ static int ingest_pipeline(ss_ctx *ctx, const Family &F, size_t n, const char *c
                     if (look >= 9 && memmem(dst + (len - look), look, "\"queries\"", 9)) f = 2;
                 }
             }
-            fmts[i] = f;
+            fmts[i] = F.minimal ? 3 : f;
         }, stage_threads);
         uint32_t n_windows = 0;  // (after the reads: a file may have shrunk since its stat)
         for (size_t i = 0; i < ch.cnt; i++) {
@@ -475,6 +484,7 @@ static int ingest_pipeline(ss_ctx *ctx, const Family &F, size_t n, const char *c
             args.records = (uint32_t *)tp.rec_dev[b].p;
             args.outcome = (uint32_t *)tp.out_dev[b].p;
             args.hints = shared_ok ? (TextHint *)tp.hint_dev[b].p : nullptr;
+            args.mhints = min_ok ? (MinHint *)tp.hint_dev[b].p : nullptr;
             args.shared_records = shared_ok ? (uint32_t *)tp.shrec_dev[b].p : nullptr;
             args.n = (uint32_t)ch.cnt;
             args.n_windows = chunk_windows[k];
@@ -576,6 +586,64 @@ int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *con
     return ingest_pipeline(ctx, F, n, texts, lens, paths, fmt, status_host, outcome, stats, t0, blob, blob_offs);
 }
 
+// The minimal proof.json.  Same pipeline, another record: the GPU reader fills minimal records in capacity form (the list
+// lengths found in the text, csrc/ss_text.h), the host readers' records are spread into that form, and the verification is
+// ss_minimal.hip's on records at a fixed stride -- no per-query records anywhere.
+int stwo_minimal_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *const *texts, const size_t *lens,
+                            uint32_t *status_host, ss_ingest_stats *stats, const uint8_t *blob, const uint64_t *blob_offs)
+{
+    if (!ctx || !status_host || (!texts && !blob) || !lens || (blob && !blob_offs)) return set_err(SS_ERR_ARG, "null argument");
+    if (blob) {
+        hipPointerAttribute_t a;
+        for (size_t i = 0; i < n; i++)
+            if ((blob_offs[i] & 15) || blob_offs[i + 1] < blob_offs[i] + lens[i])
+                return set_err(SS_ERR_ARG, "text %zu: offsets are multiples of 16, ascending, at least a text's length apart", i);
+        if ((blob_offs[n] & 15)) return set_err(SS_ERR_ARG, "the end offset is a multiple of 16 too (room for 16-byte reads)");
+        if (hipPointerGetAttributes(&a, blob) != hipSuccess || a.type != hipMemoryTypeHost ||
+            (blob_offs[n] && (hipPointerGetAttributes(&a, blob + blob_offs[n] - 1) != hipSuccess || a.type != hipMemoryTypeHost))) {
+            (void)hipGetLastError();
+            return set_err(SS_ERR_ARG, "the buffer is not page-locked host memory (hipHostMalloc / ss_host_register)");
+        }
+    }
+    if (!cfg_ok(c)) return set_err(SS_ERR_ARG, "unsupported stwo config");
+    if (!n) return set_err(SS_ERR_ARG, "empty batch");
+    if (n * (size_t)kMaxQueries > 0x7fffffffu) return set_err(SS_ERR_ARG, "batch too large");
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    const double t0 = now_s();
+    SS_DEVICE_GUARD(ctx);
+    int rc;
+    if ((rc = ensure_streams(ctx->tp))) return rc;
+    Family F;
+    F.minimal = true;
+    F.W = ss_stwo_minimal_max_words(c);
+    {
+        SharedTextInfo unused;
+        if ((rc = template_of(ctx, *c, SS_TEXT_JSON_MINIMAL, ctx->tp.cx, F.tmpl[3], &unused, &F.minfo))) return rc;
+    }
+    const ss_stwo_cfg cv = *c;
+    const size_t W = F.W;
+    F.host_read = [&cv, W](size_t, const char *text, size_t len, uint32_t *dst) {
+        static thread_local std::vector<uint32_t> rec;
+        const ParseResult r = stwo_parse_minimal_text(cv, text, len, rec);
+        if (r != kParsed) return r == kConfigMismatch ? (int)SS_STATUS_CONFIG_MISMATCH : (int)SS_STATUS_MALFORMED;
+        memset(dst, 0, W * 4);
+        return minimal_to_capacity(cv, rec.data(), rec.size(), dst) ? 0 : (int)SS_STATUS_MALFORMED;
+    };
+    F.batch_words = [&cv](size_t cnt) { return ss_stwo_minimal_batch_words(&cv, cnt); };
+    F.ws_bytes = [&cv](size_t cnt) { return ss_stwo_minimal_workspace_bytes(&cv, cnt); };
+    F.verify = [ctx, &cv](size_t cnt, const uint32_t *rec, uint32_t *batch, void *ws, size_t wsb, uint32_t *status, hipStream_t s) {
+        return stwo_verify_minimal_any(ctx, &cv, cnt, rec, nullptr, batch, ws, wsb, status, nullptr, SS_PHASE_ALL, s);
+    };
+    std::vector<uint8_t> outcome;
+    std::vector<const char *> ptrs;
+    if (blob) {
+        ptrs.resize(n);
+        for (size_t i = 0; i < n; i++) ptrs[i] = (const char *)blob + blob_offs[i];
+        texts = ptrs.data();
+    }
+    return ingest_pipeline(ctx, F, n, texts, lens, nullptr, SS_TEXT_JSON, status_host, outcome, stats, t0, blob, blob_offs);
+}
+
 // stark101: the protocol's shape has a template (ss_text.h); a proof of another shape is parsed by the host reader
 // and, when it does not fit the {10, 13} records of the pipeline, verified afterwards in a batch of its own shape.
 int s101_ingest_dev(ss_ctx *ctx, size_t n, const char *const *texts, const size_t *lens, const char *const *paths, int fmt,
@@ -655,8 +723,8 @@ int stwo_read_texts_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char 
                         int fmt, uint32_t *records_host, uint32_t *outcome_host)
 {
     if (!ctx || !texts || !lens || !records_host || !outcome_host) return set_err(SS_ERR_ARG, "null argument");
-    const bool sh_fmt = c && fmt == SS_TEXT_JSON_SHARED;
-    if ((c && !cfg_ok(c)) || !n || (fmt != SS_TEXT_JSON && fmt != SS_TEXT_WIT && !sh_fmt)) return set_err(SS_ERR_ARG, "bad argument");
+    const bool sh_fmt = c && fmt == SS_TEXT_JSON_SHARED, min_fmt = c && fmt == SS_TEXT_JSON_MINIMAL;
+    if ((c && !cfg_ok(c)) || !n || (fmt != SS_TEXT_JSON && fmt != SS_TEXT_WIT && !sh_fmt && !min_fmt)) return set_err(SS_ERR_ARG, "bad argument");
     std::lock_guard<std::mutex> lock(ctx->mu);
     SS_DEVICE_GUARD(ctx);
     TextPath &tp = ctx->tp;
@@ -665,12 +733,17 @@ int stwo_read_texts_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char 
     ss_stwo_cfg key{};
     key.lde_log = kS101Path; key.n_layers = kS101Layers;  // n_cols 0: the stark101 template (s101_ingest_dev)
     const ss_s101_shape sh = {kS101Layers, kS101Path};
-    const size_t W = c ? ss_stwo_record_words(c) : ss_s101_record_words(&sh);
+    const size_t W = min_fmt ? ss_stwo_minimal_max_words(c) : c ? ss_stwo_record_words(c) : ss_s101_record_words(&sh);
     TextParseArgs args{};
     if ((rc = template_of(ctx, c ? *c : key, SS_TEXT_JSON, tp.cx, args.tmpl[0]))) return rc;
     if ((rc = template_of(ctx, c ? *c : key, SS_TEXT_WIT, tp.cx, args.tmpl[1]))) return rc;
     if (sh_fmt && (rc = template_of(ctx, *c, SS_TEXT_JSON_SHARED, tp.cx, args.tmpl[2], &args.sinfo))) return rc;
     if (sh_fmt && !args.tmpl[2].skel) return set_err(SS_ERR_ARG, "no shared-path text exists for this config");
+    if (min_fmt) {
+        SharedTextInfo unused;
+        if ((rc = template_of(ctx, *c, SS_TEXT_JSON_MINIMAL, tp.cx, args.tmpl[3], &unused, &args.minfo))) return rc;
+        if (!args.tmpl[3].skel) return set_err(SS_ERR_ARG, "no minimal proof.json exists for this config");
+    }
     args.record_words = (uint32_t)W;
     auto aligned = [](size_t v) { return (v + 15) & ~(size_t)15; };
     size_t total = 0;
@@ -693,7 +766,7 @@ int stwo_read_texts_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char 
         l32[i] = (uint32_t)lens[i];
         wb[i] = n_windows;
         n_windows += (uint32_t)((lens[i] + 1023) >> 10);
-        f8[i] = sh_fmt ? 2 : fmt == SS_TEXT_WIT;
+        f8[i] = min_fmt ? 3 : sh_fmt ? 2 : fmt == SS_TEXT_WIT;
     }
     wb[n] = n_windows;
     GrowBuf text, rec, out, win, shrec, hint;
@@ -703,7 +776,9 @@ int stwo_read_texts_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char 
         return done(rc);
     if (sh_fmt && ((rc = grow(shrec, n * (size_t)args.tmpl[2].record_words * 4, false)) || (rc = grow(hint, n * sizeof(TextHint), false))))
         return done(rc);
-    args.hints = (TextHint *)hint.p;
+    if (min_fmt && (rc = grow(hint, n * sizeof(MinHint), false))) return done(rc);
+    args.hints = sh_fmt ? (TextHint *)hint.p : nullptr;
+    args.mhints = min_fmt ? (MinHint *)hint.p : nullptr;
     args.shared_records = (uint32_t *)shrec.p;
     const size_t wcap = ((size_t)n_windows + 4) & ~(size_t)3;
     if (hipMemcpy(text.p, host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess ||

@@ -34,7 +34,9 @@ namespace ss {
 struct MinArgs {
     MinMap m;
     const uint32_t *recs;  // minimal records, record p at word offset offs[p], offs[p + 1] - offs[p] words
-    const uint64_t *offs;
+    const uint64_t *offs;  // nullptr: CAPACITY form -- record p at p * stride, every list at the base it has when all lists
+                           // have their largest length (what the GPU reader of the minimal proof.json writes: ss_text.h)
+    uint64_t stride;
     uint32_t n;
 };
 
@@ -46,8 +48,8 @@ __global__ void stwo_min_head_kernel(StwoLayout y, MinArgs a, uint32_t *__restri
     const uint32_t w = (uint32_t)(d / y.np), p = (uint32_t)(d - (uint64_t)w * y.np);
     uint32_t v = 0;
     if (p < a.n) {
-        const uint64_t off = a.offs[p];
-        if (a.offs[p + 1] - off >= a.m.data) v = a.recs[off + w];  // (shorter than the fixed words: nothing of it is read)
+        const uint64_t off = a.offs ? a.offs[p] : p * a.stride;
+        if (!a.offs || a.offs[p + 1] - off >= a.m.data) v = a.recs[off + w];  // (shorter than the fixed words: nothing of it is read)
     }
     batch[y.off_head + d] = v;
 }
@@ -66,8 +68,9 @@ stwo_min_expand_kernel(StwoLayout y, MinArgs a, uint32_t *__restrict__ batch, ui
     if (p >= a.n) return;
     const MinMap &m = a.m;
     const uint32_t N = y.N, L = y.L, Q = y.Q, Qd = y.Qd, K = y.K, np = y.np, nip = y.nip;
-    const uint64_t off = a.offs[p];
-    const uint64_t words = a.offs[p + 1] - off;
+    const bool capacity = a.offs == nullptr;
+    const uint64_t off = capacity ? p * a.stride : a.offs[p];
+    const uint64_t words = capacity ? a.stride : a.offs[p + 1] - off;
     const uint32_t *rec = a.recs + off;
     const uint32_t inst0 = p * Q;
 
@@ -117,19 +120,19 @@ stwo_min_expand_kernel(StwoLayout y, MinArgs a, uint32_t *__restrict__ batch, ui
         if (!malformed) {
             const uint32_t Qr = m.Q;  // the config's query count bounds every list
             malformed |= rec[m.nv] > Qr || rec[m.nv + 1] > Qr;
-            s_tv = (uint32_t)o; o += (uint64_t)(malformed ? 0 : rec[m.nv]) * N;
-            s_cv = (uint32_t)o; o += (uint64_t)(malformed ? 0 : rec[m.nv + 1]) * kCp;
+            s_tv = (uint32_t)o; o += (uint64_t)(capacity ? Qr : malformed ? 0 : rec[m.nv]) * N;
+            s_cv = (uint32_t)o; o += (uint64_t)(capacity ? Qr : malformed ? 0 : rec[m.nv + 1]) * kCp;
             for (uint32_t l = 0; l <= K && !malformed; l++) {
                 malformed |= rec[m.nfw + l] > Qr;
                 s_fw[l] = (uint32_t)o;
-                o += 4ull * (malformed ? 0 : rec[m.nfw + l]);
+                o += 4ull * (capacity ? Qr : malformed ? 0 : rec[m.nfw + l]);
             }
             for (uint32_t t = 0; t < K + 3 && !malformed; t++) {
                 malformed |= rec[m.nhw + t] > Qr * min_tree_len(L, t);
                 s_hw[t] = (uint32_t)o;
-                o += 8ull * (malformed ? 0 : rec[m.nhw + t]);
+                o += 8ull * (capacity ? Qr * min_tree_len(L, t) : malformed ? 0 : rec[m.nhw + t]);
             }
-            malformed |= o != words;
+            malformed |= !capacity && o != words;
         }
         for (uint32_t t = 0; t < K + 3; t++) {
             bool ok = !malformed;
@@ -193,6 +196,7 @@ static MinArgs min_args(const ss_stwo_cfg *c, size_t n, const uint32_t *recs, co
     a.m = min_map(c->n_cols, c->lde_log, c->n_queries, c->n_layers);
     a.recs = recs;
     a.offs = offs;
+    a.stride = min_max_words(a.m);
     a.n = (uint32_t)n;
     return a;
 }

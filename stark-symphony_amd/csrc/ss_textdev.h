@@ -20,18 +20,31 @@ struct WinIn {
     uint32_t state;              // bit 0: inside a JSON string; bits 1-2: run state entering the window
 };
 
+// per text of format 3 (the minimal proof.json; ss_text.h): the landmarks its windows found, the totals the scan saw, the
+// gaps the list lengths imply
+struct MinHint {
+    MinTextGaps g;
+    uint32_t n_lm[3];                  // landmarks of each kind found (zeroed by text_index_kernel)
+    uint32_t seen_skel, seen_tok;      // skeleton bytes / numbers of the whole text (text_scan_kernel)
+    uint32_t lm[3][kMaxLandmarks];     // numbers in front of each landmark, in any order
+};
+
 struct TextParseArgs {
     const uint8_t *texts;      // the chunk's texts, each starting at a 16-byte aligned offset; >= kTextSlack readable bytes behind the last
     const uint64_t *offs;      // [n] byte offset of text i in `texts`
     const uint32_t *lens;      // [n] its length
     const uint32_t *win_base;  // [n + 1] windows (ceil(len / 1024)) of the texts before text i
-    const uint8_t *fmt;        // [n] 0 = tmpl[0] (proof.json), 1 = tmpl[1] (proof.wit), 2 = tmpl[2] (shared-path proof.json)
-    TextTemplate tmpl[3];      // device pointers inside; skel == nullptr: no fast path for that format
+    const uint8_t *fmt;        // [n] 0 = tmpl[0] (proof.json), 1 = tmpl[1] (proof.wit), 2 = tmpl[2] (shared-path proof.json),
+                               //     3 = tmpl[3] (minimal proof.json: `records` are capacity-form minimal records then)
+    TextTemplate tmpl[4];      // device pointers inside; skel == nullptr: no fast path for that format
     // format 2 (ss_text.h, "shared-path proof.json"): where the hash lists sit in tmpl[2]; per text the positions read
     // from its tail and the gaps they imply; the capacity-form shared records the place pass writes for such texts
     SharedTextInfo sinfo;
     TextHint *hints;           // [n] scratch
     uint32_t *shared_records;  // [n][tmpl[2].record_words]
+    // format 3: where the 2 K + 6 lists sit in tmpl[3]; per text the landmarks and what they imply
+    MinTextInfo minfo;
+    MinHint *mhints;           // [n] scratch (nullptr: no text of format 3)
     uint32_t *win_text;        // [n_windows] scratch: the text a window belongs to
     WinSum *win_sum;           // [n_windows] scratch
     WinIn *win_in;             // [n_windows] scratch

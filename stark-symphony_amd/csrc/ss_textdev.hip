@@ -16,7 +16,8 @@
 //   positions      prefix sums of the skeleton bytes / numbers each position contributes -- which depend on
 //                  the entering states only through the window's leading alnum run and through whether its
 //                  whitespace sits inside a string, so a window can count both cases without knowing them.
-// Three kernels per chunk:
+// Three kernels per chunk (plus, for the minimal proof.json, text_landmark_kernel and text_minhint_kernel between the scan
+// and the place pass: its list lengths are found in the text, ss_text.h):
 //   text_summary_kernel  wave = window: WinSum (counts for either string state, leading run, flags);
 //   text_scan_kernel     wave = text:   scans its windows' summaries -> WinIn (entering states and positions),
 //                        checks the totals against the template (skeleton length, number count, string closed);
@@ -123,6 +124,7 @@ __global__ void __launch_bounds__(64) text_index_kernel(TextParseArgs a)
     const uint32_t t = blockIdx.x;
     if (t >= a.n) return;
     for (uint32_t w = a.win_base[t] + threadIdx.x; w < a.win_base[t + 1]; w += 64) a.win_text[w] = t;
+    if (a.mhints && a.fmt[t] == 3 && threadIdx.x < 3) a.mhints[t].n_lm[threadIdx.x] = 0;
 }
 
 // Format 2 only: the positions a shared-path text names (read backwards from its last KiB by one lane: <= 64 short
@@ -251,7 +253,7 @@ __global__ void __launch_bounds__(64) text_scan_kernel(TextParseArgs a)
     const uint32_t skel_len = f == 2 ? a.hints[t].g.skel_len : a.tmpl[f].skel_len;
     const uint32_t n_slots = f == 2 ? a.hints[t].g.n_slots : a.tmpl[f].n_slots;
     uint32_t carry_run = kRunNone, carry_str = 0, skel_pos = 0, tok_pos = 0;
-    bool bad = skel == nullptr || nwin == 0 || skel_len == 0xffffffffu;
+    bool bad = skel == nullptr || nwin == 0 || skel_len == 0xffffffffu || (f == 3 && !a.mhints);
     const uint64_t below = (1ull << lane) - 1;
     for (uint32_t g = 0; g < nwin && !bad; g += 64) {
         const uint32_t w = g + lane;
@@ -286,14 +288,113 @@ __global__ void __launch_bounds__(64) text_scan_kernel(TextParseArgs a)
         tok_pos += __shfl(ik, 63);
         bad = __ballot(s.flags & 1) != 0 || skel_pos > skel_len || tok_pos > n_slots;
     }
-    const bool good = !bad && skel_pos == skel_len && tok_pos == n_slots && carry_str == 0;
-    if (good && f != 2) {  // the path-length trailer of a canonical text is the config's (format 2: written by the expansion)
+    // (a minimal proof.json has the totals its list lengths imply, and those are found next: text_minhint_kernel compares;
+    // here the full-length template's totals are upper bounds)
+    const bool good = !bad && (f == 3 || (skel_pos == skel_len && tok_pos == n_slots)) && carry_str == 0;
+    if (f == 3 && lane == 0 && a.mhints) { a.mhints[t].seen_skel = skel_pos; a.mhints[t].seen_tok = tok_pos; }
+    if (good && f < 2) {  // the path-length trailer of a canonical text is the config's (format 2: written by the expansion)
         const TextTemplate &T = wit ? a.tmpl[1] : a.tmpl[0];
         uint32_t *rec = a.records + (size_t)t * a.record_words;
         for (uint32_t i = lane; i < T.n_trailer; i += 64) rec[T.tbase + i] = T.trailer[i];
         for (uint32_t i = lane; i < T.n_fixed; i += 64) rec[T.fixed[2 * i]] = T.fixed[2 * i + 1];
     }
     if (lane == 0) a.outcome[t] = good ? 0u : 1u;
+}
+
+// Format 3 only, wave = window: the member names that stand next to the lists of a minimal proof.json (ss_text.h,
+// min_text_landmark) and, for each, the numbers in front of it -- the replay of the place kernel up to the marks.
+__global__ void __launch_bounds__(64) text_landmark_kernel(TextParseArgs a)
+{
+    __shared__ uint4 s_text4[64 + 1];  // this window and the first 16 bytes of the next
+    const uint8_t *s_text = reinterpret_cast<const uint8_t *>(s_text4);
+    const uint32_t gw = blockIdx.x, lane = threadIdx.x;
+    if (gw >= a.n_windows) return;
+    const uint32_t t = a.win_text[gw];
+    if (a.fmt[t] != 3 || a.outcome[t] != 0) return;
+    const uint32_t w = gw - a.win_base[t], nwin = a.win_base[t + 1] - a.win_base[t], len = a.lens[t];
+    const uint4 *text4 = reinterpret_cast<const uint4 *>(a.texts + a.offs[t]);
+    const WinIn in = a.win_in[gw];
+    const uint4 cur = text4[(size_t)w * 64 + lane];
+    s_text4[lane] = cur;
+    if (lane == 0) s_text4[64] = w + 1 < nwin ? text4[(size_t)(w + 1) * 64] : make_uint4(0, 0, 0, 0);
+    const uint32_t win0 = w << 10, pos0 = win0 + lane * 16;
+    const uint32_t nvalid = pos0 >= len ? 0 : (len - pos0 < 16 ? len - pos0 : 16);
+    const LaneLocal L = lane_local(cur, nvalid);
+    const uint64_t det_mask = __ballot(L.det), q_mask = __ballot(L.qpar);
+    const uint64_t below = (1ull << lane) - 1;
+    uint32_t r_str = (in.state & 1) ^ ((uint32_t)__popcll(q_mask & below) & 1);
+    uint32_t r_run = entering_run(det_mask, L.rout, L.ftype, in.state >> 1, lane);
+    uint32_t mark_mask = 0, quote_mask = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 16; j++) {
+        if (j < nvalid) {
+            const uint32_t c = byte_of(cur, j);
+            mark_mask |= (scan_byte(c, r_run, r_str) >> 1) << j;
+            quote_mask |= (uint32_t)(c == '"') << j;
+        }
+    }
+    const uint32_t mine = __popc(mark_mask);
+    uint32_t incl = mine;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(incl, d);
+        if (lane >= d) incl += y;
+    }
+    const uint32_t tok0 = in.tok_pos + incl - mine;
+    __syncthreads();
+    MinHint *h = a.mhints + t;
+    while (quote_mask) {
+        const uint32_t j = __ffs(quote_mask) - 1;
+        quote_mask &= quote_mask - 1;
+        const int kind = min_text_landmark(s_text + lane * 16 + j, len - (pos0 + j));
+        if (kind >= 0) {
+            const uint32_t slot = atomicAdd(&h->n_lm[kind], 1u);
+            if (slot < kMaxLandmarks) h->lm[kind][slot] = tok0 + __popc(mark_mask & ((1u << j) - 1));
+        }
+    }
+}
+
+// Format 3 only, wave = text: the landmarks in order, the list lengths they give, the gaps those cut out of the full-length
+// template, and the lengths into the record.  A text whose landmarks are not a minimal proof.json's, or whose totals are not
+// the ones its lengths imply, goes to the host reader.
+__global__ void __launch_bounds__(64) text_minhint_kernel(TextParseArgs a)
+{
+    __shared__ uint32_t s_lm[3][kMaxLandmarks], s_sorted[3][kMaxLandmarks], s_counts[kMaxTextLists], s_ok;
+    const uint32_t t = blockIdx.x, lane = threadIdx.x;
+    if (t >= a.n || a.fmt[t] != 3 || a.outcome[t] != 0) return;
+    MinHint *h = a.mhints + t;
+    const MinTextInfo &I = a.minfo;
+    const uint32_t n_lm[3] = {h->n_lm[0], h->n_lm[1], h->n_lm[2]};
+    bool ok = n_lm[kLmHash] == I.K + 4 && n_lm[kLmColumn] == I.K + 4 && n_lm[kLmPow] == 1;  // (<= kMaxLandmarks: all stored)
+    if (ok) {
+        for (uint32_t k = 0; k < 3; k++)
+            if (lane < n_lm[k]) s_lm[k][lane] = h->lm[k][lane];
+        __syncthreads();
+        for (uint32_t k = 0; k < 3; k++)
+            if (lane < n_lm[k]) {
+                const uint32_t v = s_lm[k][lane];
+                uint32_t rank = 0;
+                for (uint32_t e = 0; e < n_lm[k]; e++) rank += s_lm[k][e] < v || (s_lm[k][e] == v && e < lane);
+                s_sorted[k][rank] = v;
+            }
+        __syncthreads();
+        if (lane == 0) {
+            bool good = min_text_counts(I, s_sorted[kLmHash], n_lm[kLmHash], s_sorted[kLmColumn], n_lm[kLmColumn], s_sorted[kLmPow],
+                                        n_lm[kLmPow], s_counts);
+            if (good) {
+                min_text_gaps(I, s_counts, a.tmpl[3].skel_len, a.tmpl[3].n_slots, h->g);
+                good = h->g.skel_len == h->seen_skel && h->g.n_slots == h->seen_tok;
+            }
+            s_ok = good;
+        }
+        __syncthreads();
+        ok = s_ok != 0;
+        if (ok) {
+            uint32_t *rec = a.records + (size_t)t * a.record_words;
+            for (uint32_t j = lane; j < I.n_lists; j += 64) rec[I.word[j]] = s_counts[j] / I.per[j];
+        }
+    }
+    if (!ok && lane == 0) a.outcome[t] = 1;
 }
 
 __global__ void __launch_bounds__(64) text_place_kernel(TextParseArgs a)
@@ -310,19 +411,18 @@ __global__ void __launch_bounds__(64) text_place_kernel(TextParseArgs a)
     if (a.outcome[t] != 0) return;  // the scan (or another window) has already sent this text to the host reader
     const uint32_t w = gw - a.win_base[t], nwin = a.win_base[t + 1] - a.win_base[t], len = a.lens[t];
     const uint32_t f = a.fmt[t];
-    const bool shared = f == 2;
+    const bool shared = f >= 2;  // a text whose lists are shorter than the template's: shared-path (2) or minimal (3) proof.json
     const uint8_t *skel = a.tmpl[f].skel;
     const TextSlot *slots = a.tmpl[f].slots;
-    const uint32_t n_slots = shared ? a.hints[t].g.n_slots : a.tmpl[f].n_slots;
-    uint32_t *rec = shared ? a.shared_records + (size_t)t * a.tmpl[2].record_words : a.records + (size_t)t * a.record_words;
-    // format 2: positions in this text -> positions in the full-length template (ss_text.h, TextGaps)
-    __shared__ uint32_t s_G[kMaxTrees], s_D[kMaxTrees], s_Gk[kMaxTrees], s_Dk[kMaxTrees];
-    const uint32_t n_trees = a.sinfo.n_trees;
+    const uint32_t n_slots = f == 2 ? a.hints[t].g.n_slots : f == 3 ? a.mhints[t].g.n_slots : a.tmpl[f].n_slots;
+    uint32_t *rec = f == 2 ? a.shared_records + (size_t)t * a.tmpl[2].record_words : a.records + (size_t)t * a.record_words;
+    // formats 2 and 3: positions in this text -> positions in the full-length template (ss_text.h, TextGaps / MinTextGaps)
+    __shared__ uint32_t s_G[kMaxTextLists], s_D[kMaxTextLists], s_Gk[kMaxTextLists], s_Dk[kMaxTextLists];
+    const uint32_t n_trees = f == 3 ? a.minfo.n_lists : a.sinfo.n_trees;  // (gaps)
     if (shared) {
-        if (lane < n_trees) {
-            const TextGaps &g = a.hints[t].g;
-            s_G[lane] = g.G[lane]; s_D[lane] = g.D[lane]; s_Gk[lane] = g.Gk[lane]; s_Dk[lane] = g.Dk[lane];
-        }
+        const uint32_t *gG = f == 2 ? a.hints[t].g.G : a.mhints[t].g.G, *gD = f == 2 ? a.hints[t].g.D : a.mhints[t].g.D;
+        const uint32_t *gGk = f == 2 ? a.hints[t].g.Gk : a.mhints[t].g.Gk, *gDk = f == 2 ? a.hints[t].g.Dk : a.mhints[t].g.Dk;
+        for (uint32_t i = lane; i < n_trees; i += 64) { s_G[i] = gG[i]; s_D[i] = gD[i]; s_Gk[i] = gGk[i]; s_Dk[i] = gDk[i]; }
         __syncthreads();
     }
     const uint4 *text4 = reinterpret_cast<const uint4 *>(a.texts + a.offs[t]);  // 16-byte aligned by the host
@@ -523,6 +623,10 @@ void launch_text_parse(const TextParseArgs &a, hipStream_t s)
     if (a.hints) hipLaunchKernelGGL(text_hint_kernel, dim3(a.n), dim3(64), 0, s, a);
     if (a.n_windows) hipLaunchKernelGGL(text_summary_kernel, dim3(a.n_windows), dim3(64), 0, s, a);
     hipLaunchKernelGGL(text_scan_kernel, dim3(a.n), dim3(64), 0, s, a);
+    if (a.mhints) {
+        if (a.n_windows) hipLaunchKernelGGL(text_landmark_kernel, dim3(a.n_windows), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(text_minhint_kernel, dim3(a.n), dim3(64), 0, s, a);
+    }
     if (a.n_windows) hipLaunchKernelGGL(text_place_kernel, dim3(a.n_windows), dim3(64), 0, s, a);
 }
 

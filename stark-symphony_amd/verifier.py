@@ -366,6 +366,28 @@ def parse_stwo_minimal_text(cfg: StwoConfig, text: bytes, mode: int = MODE_FIXTU
     return rc, (out[:words.value].copy() if rc == 0 else None)
 
 
+def stwo_minimal_from_capacity(cfg: StwoConfig, capacity: np.ndarray, mode: int = MODE_FIXTURE) -> np.ndarray:
+    """Capacity-form minimal record (every list at a fixed base: what the GPU reader of the minimal proof.json writes and
+    ss_stwo_text_is_canonical returns for SS_TEXT_JSON_MINIMAL) -> the minimal record of include/ss_verify.h."""
+    cs = stwo_cfg_struct(cfg, mode)
+    cap = np.ascontiguousarray(capacity, dtype=np.uint32)
+    out = np.zeros(cap.size, dtype=np.uint32)
+    words = C.c_size_t(0)
+    B.check(B.lib().ss_stwo_minimal_from_capacity(C.byref(cs), cap.ctypes.data, out.ctypes.data, out.size, C.byref(words)))
+    return out[:words.value].copy()
+
+
+def stwo_minimal_text_is_canonical(cfg: StwoConfig, text: bytes, mode: int = MODE_FIXTURE):
+    """Would the GPU reader take this minimal proof.json?  -> (taken, minimal record or None): the scalar statement of its rule
+    (ss_stwo_text_is_canonical with SS_TEXT_JSON_MINIMAL; no GPU)."""
+    cs = stwo_cfg_struct(cfg, mode)
+    L = B.lib()
+    text = bytes(text)
+    cap = np.zeros(L.ss_stwo_minimal_max_words(C.byref(cs)), dtype=np.uint32)
+    r = B.check(L.ss_stwo_text_is_canonical(C.byref(cs), text, len(text), B.TEXT_JSON_MINIMAL, cap.ctypes.data))
+    return bool(r), (stwo_minimal_from_capacity(cfg, cap, mode) if r else None)
+
+
 def write_stwo_minimal_text(cfg: StwoConfig, minimal: np.ndarray, python_separators: bool = True, mode: int = MODE_FIXTURE) -> bytes:
     """Minimal record -> the minimal proof.json, byte for byte what json.dumps prints for formats.stwo_minimal_to_json
     (ss_stwo_write_minimal_text).  ValueError when `minimal` is no minimal record of the config."""
@@ -942,9 +964,27 @@ class Verifier:
                                                     status.ctypes.data, C.byref(stats)))
         return status, {k: getattr(stats, k) for k, _ in B.IngestStats._fields_}
 
+    def verify_stwo_minimal_texts_pinned(self, cfg: StwoConfig, blob: np.ndarray, offsets, lengths, mode: int = MODE_FIXTURE):
+        """ss_stwo_verify_minimal_texts_pinned: minimal proof.json texts lying in one page-locked uint8 array (pinned_text_blob)
+        -> (status, stats)."""
+        cs = stwo_cfg_struct(cfg, mode, self.stwo_flags)
+        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        lens = np.ascontiguousarray(lengths, dtype=np.uint64)
+        n = lens.size
+        if blob.dtype != np.uint8 or not blob.flags["C_CONTIGUOUS"] or offs.size != n + 1 or (n and int(offs[-1]) > blob.size):
+            raise ValueError("a contiguous uint8 array, n + 1 byte offsets inside it and n lengths expected")
+        status = np.full(n, 0xFFFFFFFF, dtype=np.uint32)
+        stats = B.IngestStats()
+        if n == 0:
+            return status, {k: 0 for k, _ in B.IngestStats._fields_}
+        clens = (C.c_size_t * n).from_buffer(lens)
+        B.check(B.lib().ss_stwo_verify_minimal_texts_pinned(self.ctx, C.byref(cs), n, blob.ctypes.data, offs.ctypes.data, clens,
+                                                            status.ctypes.data, C.byref(stats)))
+        return status, {k: getattr(stats, k) for k, _ in B.IngestStats._fields_}
+
     def verify_stwo_minimal_texts(self, cfg: StwoConfig, texts: Sequence[bytes], mode: int = MODE_FIXTURE):
-        """Minimal proof.json texts -> (status, stats) (ss_stwo_verify_minimal_texts: the library's host reader on its
-        worker threads, then the minimal-record path)."""
+        """Minimal proof.json texts -> (status, stats) (ss_stwo_verify_minimal_texts: read into capacity-form minimal records
+        by the GPU reader -- texts it does not take by the library's host readers --, then the minimal-record path)."""
         cs = stwo_cfg_struct(cfg, mode, self.stwo_flags)
         n = len(texts)
         status = np.full(n, 0xFFFFFFFF, dtype=np.uint32)
@@ -1024,7 +1064,8 @@ class Verifier:
         outcome 0 = canonical text, record written by the GPU; 1 = left to the host reader."""
         cs = stwo_cfg_struct(cfg, mode, self.stwo_flags)
         n = len(texts)
-        W = B.lib().ss_stwo_record_words(C.byref(cs))
+        # (the minimal proof.json is read into minimal records in capacity form: stwo_minimal_from_capacity)
+        W = B.lib().ss_stwo_minimal_max_words(C.byref(cs)) if fmt == B.TEXT_JSON_MINIMAL else B.lib().ss_stwo_record_words(C.byref(cs))
         recs = np.zeros((n, W), dtype=np.uint32)
         outcome = np.full(n, 0xFFFFFFFF, dtype=np.uint32)
         bufs = [bytes(t) for t in texts]

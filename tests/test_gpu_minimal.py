@@ -148,7 +148,7 @@ def test_resident_minimal_batch_and_phases(ver):
 
 
 def test_minimal_texts_and_cli(ver, tmp_path):
-    """The minimal proof.json as text: ss_stwo_verify_minimal_texts (host reader, then the minimal-record path) gives the
+    """The minimal proof.json as text: ss_stwo_verify_minimal_texts (GPU reader / host readers, then the minimal-record path) gives the
     records' verdicts and the stage-0 codes for texts that are no witness / of another config; `cli verify
     --minimal-proof` keeps the exit-status contract of simfony-cli/src/main.rs:254-257; `cli convert --to json-minimal`
     writes the text the library's writer writes."""
@@ -164,7 +164,7 @@ def test_minimal_texts_and_cli(ver, tmp_path):
     texts += [b"not a witness", json.dumps(other).encode()]
     got, stats = ver.verify_stwo_minimal_texts(cfg, texts)
     want = [O.stwo_verify_minimal(cfg, r, 1) for r in recs] + [2, 1]
-    assert got.tolist() == want and got[0] == 0 and stats["host_parsed"] == len(texts)
+    assert got.tolist() == want and got[0] == 0 and stats["host_parsed"] == 2  # (the canonical texts are read on the GPU)
     good, bad = tmp_path / "good.json", tmp_path / "bad.json"
     good.write_bytes(texts[0])
     bad.write_bytes(texts[1])
@@ -256,3 +256,90 @@ def test_pinned_texts_give_the_staged_verdicts(ver):
     pageable = np.array(blob)
     with pytest.raises(B.SsError):
         ver.verify_stwo_texts_pinned(cfg, pageable, offs, lens)
+
+
+@pytest.mark.parametrize("i", [0, 1, 2, 3, 5])
+def test_gpu_reader_of_the_minimal_text_equals_its_scalar_rule(ver, i):
+    """ss_stwo_read_texts with SS_TEXT_JSON_MINIMAL (csrc/ss_textdev.hip: summary, scan, text_landmark_kernel,
+    text_minhint_kernel, place through the gap maps): outcome == the scalar rule (csrc/ss_text.cpp
+    minimal_text_scan_reference, itself held to the host reader in tests/test_minimal.py) for every text, and the same
+    minimal record where taken -- fixtures in three spellings, texts of corrupted records (list lengths that are data),
+    empty lists, byte-level mutants, another member order."""
+    import json
+    from stark_symphony_amd import binding as B
+    from test_minimal import _min_text_mutants
+    p = fixtures()[i]
+    cfg = p.cfg
+    m = minimal_of(p)
+    obj = formats.stwo_minimal_to_json(formats.stwo_minimise(p))
+    rng = np.random.default_rng(0x5EED2025 + 180 + i)
+    texts = [json.dumps(obj).encode(), json.dumps(obj, separators=(",", ":")).encode(), json.dumps(obj, indent=1).encode()]
+    for k in range(24):
+        r = corrupt_minimal(m, cfg, rng)[0]
+        try:
+            texts.append(verifier.write_stwo_minimal_text(cfg, r, python_separators=bool(k & 1)))
+        except ValueError:  # (no minimal record of the config any more: no text)
+            pass
+    texts += [t for t in _min_text_mutants(json.dumps(obj).encode(), rng) if len(t)]
+    K = cfg.n_layers
+    def variant(edit):
+        o = json.loads(json.dumps(obj))
+        edit(o)
+        return json.dumps(o, separators=(",", ":")).encode()
+    layer = lambda o, l: o["fri_proof"]["first_layer"] if l == 0 else o["fri_proof"]["inner_layers"][l - 1]
+    def all_empty(o):
+        o["queried_values"][1] = []
+        o["queried_values"][2] = []
+        o["decommitments"][1]["hash_witness"] = []
+        o["decommitments"][2]["hash_witness"] = []
+        for l in range(K + 1):
+            layer(o, l)["fri_witness"] = []
+            layer(o, l)["decommitment"]["hash_witness"] = []
+    texts += [variant(lambda o: layer(o, 0).__setitem__("fri_witness", [])),
+              variant(lambda o: layer(o, K)["decommitment"].__setitem__("hash_witness", [])),
+              variant(lambda o: o["decommitments"][2]["hash_witness"].pop()), variant(all_empty),
+              variant(lambda o: [o["queried_values"][1].pop() for _ in range(cfg.n_cols)]),
+              variant(lambda o: o.__setitem__("hash_witness", [])), json.dumps(dict(reversed(list(obj.items())))).encode()]
+    recs, outcome = ver.read_stwo_texts(cfg, texts, B.TEXT_JSON_MINIMAL)
+    taken = 0
+    for k, text in enumerate(texts):
+        want_taken, want = verifier.stwo_minimal_text_is_canonical(cfg, text)
+        assert (outcome[k] == 0) == want_taken, (k, int(outcome[k]), want_taken, text[:60])
+        if want_taken:
+            taken += 1
+            assert np.array_equal(verifier.stwo_minimal_from_capacity(cfg, recs[k]), want), k
+    assert outcome[0] == outcome[1] == outcome[2] == 0 and 8 <= taken < len(texts)
+
+
+def test_minimal_texts_through_the_gpu_reader_give_the_records_verdicts(ver):
+    """ss_stwo_verify_minimal_texts end to end at the metric shape (2^20 rows: 0.43-0.54 MB a text, several chunks of the
+    pipeline): texts of the fixture and of corrupted records in both spellings go through the GPU reader, texts in another
+    member order through the host readers, garbage and another config get the stage-0 codes; every verdict is the oracle's
+    for the record; the caller-pinned variant gives the same verdicts."""
+    import json
+    p = fixtures()[5]
+    cfg = p.cfg
+    m = minimal_of(p)
+    rng = np.random.default_rng(0x5EED2025 + 190)
+    recs, texts = [], []
+    for r in [m] + [corrupt_minimal(m, cfg, rng)[0] for _ in range(60)]:
+        st = O.stwo_verify_minimal(cfg, r, 1)
+        if st == 2:
+            continue
+        recs.append((r, st))
+    want = []
+    for k in range(360):
+        r, st = recs[k % len(recs)]
+        texts.append(verifier.write_stwo_minimal_text(cfg, r, python_separators=bool(k % 3 == 0)))
+        want.append(st)
+    obj = formats.stwo_minimal_to_json(formats.stwo_minimise(p))
+    other = formats.stwo_minimal_to_json(formats.stwo_minimise(fixtures()[0]))
+    texts += [json.dumps(dict(reversed(list(obj.items())))).encode(), b"not a witness", b"", json.dumps(other).encode(),
+              json.dumps(obj, indent=1).encode()]
+    want += [0, 2, 2, 1, 0]
+    got, stats = ver.verify_stwo_minimal_texts(cfg, texts)
+    assert got.tolist() == want, [(k, int(g), w) for k, (g, w) in enumerate(zip(got, want)) if g != w][:8]
+    assert stats["host_parsed"] == 4 and len(set(want)) >= 4
+    blob, offs, lens = ver.pinned_text_blob(texts)
+    got2, stats2 = ver.verify_stwo_minimal_texts_pinned(cfg, blob, offs, lens)
+    assert got2.tolist() == want and stats2["host_parsed"] == 4

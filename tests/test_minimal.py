@@ -326,3 +326,57 @@ def test_minimal_text_streaming_reader_equals_the_general_one(i):
         assert both(compact[:at] + spelling + compact[at + len(first):])[1] == general
     # the last hashes of a text sit closer to its end than the fast byte-list path reads ahead: same answers there
     assert both(compact + b" " * 300) == (0, 0)
+
+
+@pytest.mark.parametrize("i", [0, 1, 2, 3])
+def test_minimal_text_gpu_rule_equals_the_host_reader(i):
+    """The scalar statement of the GPU reader's rule for the minimal proof.json (csrc/ss_text.cpp
+    minimal_text_scan_reference: landmarks -> list lengths -> gaps -> the scan through the gap maps): takes the writers'
+    texts in every whitespace spelling, and whatever it takes the general host reader parses to the same record --
+    on the fixtures, their mutants, and texts whose lists are empty or shortened."""
+    p = fixtures()[i]
+    cfg = p.cfg
+    m = formats.stwo_minimise(p)
+    rec = verifier.stwo_minimal_record(m)
+    obj = formats.stwo_minimal_to_json(m)
+
+    def check(text):
+        taken, got = verifier.stwo_minimal_text_is_canonical(cfg, text)
+        rc, want = verifier.parse_stwo_minimal_text(cfg, text, reader=verifier.READER_GENERAL)
+        if taken:
+            assert rc == 0 and np.array_equal(got, want), text[:80]
+        return taken
+
+    for text in (json.dumps(obj).encode(), json.dumps(obj, separators=(",", ":")).encode(), json.dumps(obj, indent=1).encode()):
+        assert check(text)
+        assert np.array_equal(verifier.stwo_minimal_text_is_canonical(cfg, text)[1], rec)
+    rng = np.random.default_rng(0x5EED2025 + 170 + i)
+    taken = sum(check(mut) for mut in _min_text_mutants(json.dumps(obj).encode(), rng))
+    assert taken >= 1  # (byte damage inside a number keeps the structure)
+    # list lengths are data: empty and shortened lists are still this form (the verifier refuses them, not the reader)
+    def variant(edit):
+        o = json.loads(json.dumps(obj))
+        edit(o)
+        return json.dumps(o).encode()
+    K = cfg.n_layers
+    layer = lambda o, l: o["fri_proof"]["first_layer"] if l == 0 else o["fri_proof"]["inner_layers"][l - 1]
+    assert check(variant(lambda o: layer(o, 0).__setitem__("fri_witness", [])))
+    assert check(variant(lambda o: layer(o, K)["decommitment"].__setitem__("hash_witness", [])))
+    assert check(variant(lambda o: o["decommitments"][1].__setitem__("hash_witness", [])))
+    assert check(variant(lambda o: o["decommitments"][2]["hash_witness"].pop()))
+    assert check(variant(lambda o: (o["queried_values"].__setitem__(1, []), o["queried_values"].__setitem__(2, []))))
+    def all_empty(o):
+        o["queried_values"][1] = []
+        o["queried_values"][2] = []
+        o["decommitments"][1]["hash_witness"] = []
+        o["decommitments"][2]["hash_witness"] = []
+        for l in range(K + 1):
+            layer(o, l)["fri_witness"] = []
+            layer(o, l)["decommitment"]["hash_witness"] = []
+    assert check(variant(all_empty))
+    # ... but the two value lists describe the same positions, and no list is longer than the config allows
+    assert not check(variant(lambda o: [o["queried_values"][1].pop() for _ in range(cfg.n_cols)]))
+    assert not check(variant(lambda o: layer(o, 0)["fri_witness"].extend([[[1, 2], [3, 4]]] * (cfg.n_queries + 1))))
+    # a landmark's name somewhere else, another member order: the host reader's
+    assert not check(variant(lambda o: o.__setitem__("hash_witness", [])))
+    assert not check(json.dumps(dict(reversed(list(obj.items())))).encode())
