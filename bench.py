@@ -338,8 +338,9 @@ def end_to_end(ver, proofs, n: int, rank: int = 0, world: int = 1, dist=None):
         except Exception as e:  # noqa: BLE001
             errors.append("rank %d pinned %s: %r" % (rank, kind, e))
         del batch
-    # the minimal proof.json (one decommitment per tree, 68 % of the per-query text): read by the library's HOST reader -- its
-    # list lengths depend on the queries, so the GPU reader has no template for it -- then verified as minimal records
+    # the minimal proof.json (one decommitment per tree, 30 % of the per-query text): the GPU reader finds each text's list
+    # lengths from the member names next to the lists, reads it into a capacity-form minimal record and ss_minimal.hip
+    # verifies from there (csrc/ss_text.h, ss_textdev.hip); host readers only for texts it does not take
     try:
         from stark_symphony_amd import formats as _f
         mtexts = [json.dumps(_f.stwo_minimal_to_json(_f.stwo_minimise(p)), separators=(",", ":")).encode() for p in distinct]
@@ -351,11 +352,25 @@ def end_to_end(ver, proofs, n: int, rank: int = 0, world: int = 1, dist=None):
         st = st or {"parse_s": 0.0, "total_s": 1.0, "threads": 0}
         row = {"proofs_per_s": n / slowest, "total_s": None if slowest == float("inf") else slowest,
                "text_GB_per_s": text_bytes * (n / max(n_local, 1)) / slowest / 1e9, "host_reader_s": st["parse_s"],
-               "parse_share": st["parse_s"] / st["total_s"], "host_parsed_texts": n_local, "host_threads": st["threads"],
-               "text_bytes_per_proof": text_bytes // max(n_local, 1), "reader": "host (no GPU template for this form)"}
+               "parse_share": st["parse_s"] / st["total_s"], "host_parsed_texts": st.get("host_parsed", -1), "host_threads": st["threads"],
+               "text_bytes_per_proof": text_bytes // max(n_local, 1)}
         if world > 1:
             row["per_rank_link_GB_s"] = links
         out["json_minimal"] = row
+        try:
+            blob, boffs, blens = ver.pinned_text_blob(batch)
+            ver.verify_stwo_minimal_texts_pinned(cfg, blob, boffs, blens)
+            dt, st = timed(lambda: ver.verify_stwo_minimal_texts_pinned(cfg, blob, boffs, blens))
+            slowest, links = across_ranks(dt, text_bytes)
+            prow = {"proofs_per_s": n / slowest, "total_s": None if slowest == float("inf") else slowest,
+                    "text_GB_per_s": text_bytes * (n / max(n_local, 1)) / slowest / 1e9,
+                    "host_parsed_texts": (st or {}).get("host_parsed", -1), "stage_threads": 0}
+            if world > 1:
+                prow["per_rank_link_GB_s"] = links
+            out["json_minimal_pinned"] = prow
+            del blob
+        except Exception as e:  # noqa: BLE001
+            errors.append("rank %d pinned minimal texts: %r" % (rank, e))
         del batch
     except Exception as e:  # noqa: BLE001
         errors.append("rank %d minimal texts: %r" % (rank, e))

@@ -339,7 +339,10 @@ def test_minimal_texts_through_the_gpu_reader_give_the_records_verdicts(ver):
     want += [0, 2, 2, 1, 0]
     got, stats = ver.verify_stwo_minimal_texts(cfg, texts)
     assert got.tolist() == want, [(k, int(g), w) for k, (g, w) in enumerate(zip(got, want)) if g != w][:8]
-    assert stats["host_parsed"] == 4 and len(set(want)) >= 4
+    # the host readers' share: exactly the texts the GPU reader's rule does not take (the last five but the indented one,
+    # and corrupted records whose two value lists no longer describe the same positions)
+    host = sum(1 for t in texts if not verifier.stwo_minimal_text_is_canonical(cfg, t)[0])
+    assert stats["host_parsed"] == host and 4 <= host < 40 and len(set(want)) >= 4
     blob, offs, lens = ver.pinned_text_blob(texts)
     got2, stats2 = ver.verify_stwo_minimal_texts_pinned(cfg, blob, offs, lens)
-    assert got2.tolist() == want and stats2["host_parsed"] == 4
+    assert got2.tolist() == want and stats2["host_parsed"] == host
