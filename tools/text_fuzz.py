@@ -8,7 +8,9 @@ truncations, injected digits / brackets / escapes, numbers replaced by other spe
 against the window grid) and requires, for every mutant:
     GPU outcome == scalar rule (ss_stwo_text_is_canonical);
     where taken: GPU record == scalar rule's record == host reader's record (and the host reader parses it);
-and, through the whole entry point, status words == host reader + record path on a sample.
+and, through the whole entry point, status words == host reader + record path on a sample.  The minimal proof.json gets
+the same treatment plus mutants whose lists have other lengths (its lengths are data), and the streaming host reader is held
+to the general one on every mutant it takes.
 Exit status 0 = no disagreement."""
 import json
 import os
@@ -40,6 +42,91 @@ def cases():
     yield "reference production", ss.stwo_from_json(json.load(open(os.path.join(GOLDEN, "stwo_proof.json"))))
     for npz in ("stwo_trace16.npz", "stwo_trace16_blake2s.npz", "stwo_wide256.npz"):
         yield npz, records.load_stwo_npz(os.path.join(GOLDEN, npz))[0]
+
+
+def minimal_leg(ver, rnd, name, p):
+    from stark_symphony_amd import formats
+    MIN = binding.TEXT_JSON_MINIMAL
+    cfg = p.cfg
+    m = formats.stwo_minimise(p)
+    rec = verifier.stwo_minimal_record(m)
+    obj = formats.stwo_minimal_to_json(m)
+    base = (json.dumps(obj) if rnd.randrange(2) else json.dumps(obj, separators=(",", ":"))).encode()
+    n = N if len(base) < 300000 else max(200, N // 8)
+    K = cfg.n_layers
+
+    def lists(o):
+        out = [o["decommitments"][1]["hash_witness"], o["decommitments"][2]["hash_witness"]]
+        for l in range(K + 1):
+            lay = o["fri_proof"]["first_layer"] if l == 0 else o["fri_proof"]["inner_layers"][l - 1]
+            out += [lay["fri_witness"], lay["decommitment"]["hash_witness"]]
+        return out
+
+    texts = []
+    for i in range(n):
+        if i % 4 == 0:  # another length of some lists (entries removed / repeated; both value lists by whole rows or not)
+            o = json.loads(base)
+            for _ in range(rnd.randrange(1, 4)):
+                lst = rnd.choice(lists(o))
+                k = rnd.randrange(4)
+                if k == 0 and lst:
+                    del lst[rnd.randrange(len(lst))]
+                elif k == 1 and lst:
+                    lst.insert(rnd.randrange(len(lst) + 1), lst[rnd.randrange(len(lst))])
+                elif k == 2:
+                    del lst[:]
+                else:
+                    rows = rnd.randrange(0, 3)
+                    for which, per in ((1, cfg.n_cols), (2, 16)):
+                        if rnd.randrange(8):
+                            del o["queried_values"][which][:rows * per]
+            t = json.dumps(o, separators=(",", ":") if i % 8 else None).encode()
+        else:
+            t = _text_mutant(rnd, base) if i % 3 == 0 else _number_mutant(rnd, base)
+        if i % 7 == 0:
+            t = b" " * rnd.randrange(1, 1100) + t
+        texts.append(t)
+    texts = [t for t in texts if len(t)]
+    bad = taken = changed = 0
+    recs, outcome = ver.read_stwo_texts(cfg, texts, MIN)
+    for i, t in enumerate(texts):
+        want, srec = verifier.stwo_minimal_text_is_canonical(cfg, t)
+        if (outcome[i] == 0) != want:
+            bad += 1
+            print("OUTCOME", name, "json-minimal", i, int(outcome[i]), want, t[:100])
+            continue
+        if want:
+            taken += 1
+            got, hrec = verifier.parse_stwo_minimal_text(cfg, t, reader=verifier.READER_GENERAL)
+            if got != 0 or not np.array_equal(verifier.stwo_minimal_from_capacity(cfg, recs[i]), srec) or not np.array_equal(hrec, srec):
+                bad += 1
+                print("RECORD", name, "json-minimal", i, got, t[:100])
+            changed += not np.array_equal(srec, rec)
+        s_rc, s_rec = verifier.parse_stwo_minimal_text(cfg, t, reader=verifier.READER_STREAM)
+        if s_rc == 0:  # the streaming host reader against the general one
+            g_rc, g_rec = verifier.parse_stwo_minimal_text(cfg, t, reader=verifier.READER_GENERAL)
+            if g_rc != 0 or not np.array_equal(s_rec, g_rec):
+                bad += 1
+                print("STREAM", name, i, g_rc, t[:100])
+    # the entry point on a sample: status words of the text path == of the record path for what parses
+    sample = texts[:300]
+    status, stats = ver.verify_stwo_minimal_texts(cfg, sample)
+    ok_recs, ok_idx = [], []
+    for i, t in enumerate(sample):
+        got, hrec = verifier.parse_stwo_minimal_text(cfg, t)
+        if got == 0:
+            ok_recs.append(hrec); ok_idx.append(i)
+        elif status[i] != got:
+            bad += 1
+            print("STAGE0", name, "json-minimal", i, int(status[i]), got)
+    if ok_recs:
+        st2 = ver.verify_stwo_minimal_records(cfg, ok_recs)
+        if status[ok_idx].tolist() != st2.tolist():
+            bad += 1
+            print("STATUS", name, "json-minimal")
+    print("%-24s %-4s: %6d mutants, %5d taken by the GPU reader (%5d with a changed record), disagreements %d"
+          % (name, "json-minimal", len(texts), taken, changed, bad), flush=True)
+    return bad
 
 
 def main():
@@ -103,6 +190,9 @@ def main():
                     print("STATUS", name, kind)
             print("%-24s %-4s: %6d mutants, %5d taken by the GPU reader (%5d with a changed record), disagreements so far %d"
                   % (name, kind, n, taken, changed, bad), flush=True)
+        # the minimal proof.json (round 5): its list lengths are found in the text (landmarks), so the mutants also delete and
+        # duplicate whole list entries -- still this form, another length
+        bad += minimal_leg(ver, rnd, name, p)
     # stark101
     for fn, fmt in (("stark101_proof.json", JSON), (os.path.join("formats", "stark101_proof.wit"), WIT)):
         base = open(os.path.join(GOLDEN, fn), "rb").read()
