@@ -235,7 +235,7 @@ int main(int argc, char **argv)
     // ---- minimal records (csrc/ss_minimalrec.cpp, ss_text.cpp, ss_ingest.cpp): minimise through exact-size buffers on random
     // shapes and positions (uniform, clustered, equal), the minimal text writer, the host reader on the text and on mutants
     // of it, the writer on structure mutants of the record
-    size_t minimal_read = 0;
+    size_t minimal_read = 0, minimal_taken = 0;
     for (const auto &sh : shapes) {
         const ss_stwo_cfg c = make_cfg(sh[0], sh[1], sh[2], sh[3], sh[4], 0, 0);
         const size_t Wc = ss_stwo_record_words(&c), cap = ss_stwo_minimal_max_words(&c), fixed = ss_stwo_minimal_fixed_words(&c);
@@ -278,14 +278,34 @@ int main(int argc, char **argv)
             if (!ss::stwo_write_json_minimal(c, mr, words, rep & 1 ? ss::kStylePython : ss::kStyleCompact, text)) { fprintf(stderr, "no minimal text\n"); return 1; }
             std::vector<uint32_t> back;
             if (ss::stwo_parse_minimal_text(c, text.data(), text.size(), back) != ss::kParsed || back.size() != words || memcmp(back.data(), mr, words * 4) != 0) { fprintf(stderr, "minimal text does not read back\n"); return 1; }
+            // the GPU reader's rule for this form, scalar (template of the full-length text, landmarks, gaps): the text reads
+            // back through it, into the capacity form, and compacts to the record; the two forms into each other
+            ss::TextTemplateHost t4;
+            ss::stwo_build_template(c, SS_TEXT_JSON_MINIMAL, t4);
+            uint32_t *capr = new uint32_t[cap];  // exact size
+            if (!t4.ok || t4.record_words != cap || !ss::minimal_text_scan_reference(c, t4, text.data(), text.size(), capr)) { fprintf(stderr, "minimal text not taken by the scalar rule\n"); return 1; }
+            ss::minimal_compact(c, capr, back);
+            if (back.size() != words || memcmp(back.data(), mr, words * 4) != 0) { fprintf(stderr, "scalar rule reads another record\n"); return 1; }
+            if (!ss::minimal_to_capacity(c, mr, words, capr)) { fprintf(stderr, "no capacity form\n"); return 1; }
+            ss::minimal_compact(c, capr, back);
+            if (back.size() != words || memcmp(back.data(), mr, words * 4) != 0) { fprintf(stderr, "capacity form does not compact back\n"); return 1; }
+            if (words > fixed && ss::minimal_to_capacity(c, mr, words - 1, capr)) { fprintf(stderr, "short record spread\n"); return 1; }
             for (int i = 0; i < mutants / 20; i++) {
                 const std::string mt = mutate(text);
                 char *exact = new char[mt.size() ? mt.size() : 1];
                 memcpy(exact, mt.data(), mt.size());
-                minimal_read += ss::stwo_parse_minimal_text(c, exact, mt.size(), back) == ss::kParsed;
+                const bool host = ss::stwo_parse_minimal_text(c, exact, mt.size(), back) == ss::kParsed;
+                minimal_read += host;
+                if (ss::minimal_text_scan_reference(c, t4, exact, mt.size(), capr)) {  // whatever the rule takes, the host reader reads the same
+                    std::vector<uint32_t> got;
+                    ss::minimal_compact(c, capr, got);
+                    if (!host || got != back) { fprintf(stderr, "scalar rule and host reader differ on a mutant\n"); return 1; }
+                    minimal_taken++;
+                }
                 delete[] exact;
                 checks++;
             }
+            delete[] capr;
             for (int m = 0; m < 40; m++) {  // structure mutants of the record into the writer: any size, any counts
                 size_t mw = words;
                 std::vector<uint32_t> mut(mr, mr + words);
@@ -334,6 +354,6 @@ int main(int argc, char **argv)
         if (waitpid(child, &st, 0) != child || !WIFEXITED(st) || WEXITSTATUS(st) != 0) { fprintf(stderr, "pool: forked child failed (%d)\n", st); return 1; }
         checks += 3;
     }
-    printf("host_san: %zu checks, %zu mutants taken by the scalar rule, %zu shared-text mutants, %zu minimal-text mutants read\n", checks, taken, shared_taken, minimal_read);
+    printf("host_san: %zu checks, %zu mutants taken by the scalar rule, %zu shared-text mutants, %zu minimal-text mutants read (%zu taken by the scalar rule)\n", checks, taken, shared_taken, minimal_read, minimal_taken);
     return 0;
 }
