@@ -405,6 +405,8 @@ int ss_stwo_verify_texts_pinned(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, c
  * member names next to the lists, compares the text with the template those lengths imply and fills a minimal record in
  * capacity form (csrc/ss_text.h, ss_textdev.hip); ss_minimal.hip verifies from there (no per-query record is ever made); texts
  * the GPU reader does not take go to the host readers above.  _pinned: as ss_stwo_verify_texts_pinned.                    */
+/* (the same as ss_stwo_verify_texts / _texts_pinned with fmt = SS_TEXT_JSON_MINIMAL; ss_stwo_verify_files takes that fmt too.
+ * SS_TEXT_AUTO never picks this form: nothing in such a text names it.)                                                  */
 int ss_stwo_verify_minimal_texts(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const char *const *texts,
                                  const size_t *lens, uint32_t *status_host, ss_ingest_stats *stats);
 int ss_stwo_verify_minimal_texts_pinned(ss_ctx *ctx, const ss_stwo_cfg *cfg, size_t n, const void *blob, const uint64_t *offs,

@@ -173,13 +173,8 @@ def main(argv=None) -> int:
             status += st.tolist()
         if args.minimal_proof:
             mode = verifier.MODE_FIXTURE if args.mode == "fixture" else verifier.MODE_LITERAL
-            texts = []
-            for path in args.minimal_proof:
-                try:
-                    texts.append(open(path, "rb").read())
-                except OSError:
-                    texts.append(b"")  # unreadable = not a witness: malformed, exit 1 (main.rs:77-81)
-            st, _ = ver.verify_stwo_minimal_texts(expected, texts, mode)
+            # (files the library reads itself, like the other forms; unreadable = not a witness: malformed, exit 1, main.rs:77-81)
+            st, _ = ver.verify_stwo_files(expected, args.minimal_proof, mode, binding.TEXT_JSON_MINIMAL)
             names += list(args.minimal_proof)
             status += st.tolist()
     except binding.SsError as e:  # no GPU / unsupported config: an error, never a verdict

@@ -888,7 +888,7 @@ extern "C" int ss_stwo_verify_minimal_texts(ss_ctx *ctx, const ss_stwo_cfg *c, s
 {
     if (!texts) return set_err(SS_ERR_ARG, "null argument");
     try {
-        return stwo_minimal_ingest_dev(ctx, c, n, texts, lens, status_host, stats);
+        return stwo_minimal_ingest_dev(ctx, c, n, texts, lens, nullptr, status_host, stats);
     } catch (const std::exception &) {
         return set_err(SS_ERR_NOMEM, "out of host memory");
     }
@@ -900,7 +900,7 @@ extern "C" int ss_stwo_verify_minimal_texts_pinned(ss_ctx *ctx, const ss_stwo_cf
 {
     if (!blob || !offs) return set_err(SS_ERR_ARG, "null argument");
     try {
-        return stwo_minimal_ingest_dev(ctx, c, n, nullptr, lens, status_host, stats, (const uint8_t *)blob, offs);
+        return stwo_minimal_ingest_dev(ctx, c, n, nullptr, lens, nullptr, status_host, stats, (const uint8_t *)blob, offs);
     } catch (const std::exception &) {
         return set_err(SS_ERR_NOMEM, "out of host memory");
     }

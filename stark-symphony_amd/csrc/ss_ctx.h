@@ -158,7 +158,7 @@ int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *con
                     const uint8_t *blob = nullptr, const uint64_t *blob_offs = nullptr);  // blob: the texts in one caller-pinned buffer
 // the minimal proof.json (SS_TEXT_JSON_MINIMAL): read into capacity-form minimal records on the GPU, verified from there
 int stwo_minimal_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *const *texts, const size_t *lens,
-                            uint32_t *status_host, ss_ingest_stats *stats, const uint8_t *blob = nullptr,
+                            const char *const *paths, uint32_t *status_host, ss_ingest_stats *stats, const uint8_t *blob = nullptr,
                             const uint64_t *blob_offs = nullptr);
 int s101_ingest_dev(ss_ctx *ctx, size_t n, const char *const *texts, const size_t *lens, const char *const *paths, int fmt,
                     uint32_t *status_host, ss_ingest_stats *stats);

@@ -534,6 +534,8 @@ int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *con
                     const char *const *paths, int fmt, uint32_t *status_host, ss_ingest_stats *stats, const uint8_t *blob,
                     const uint64_t *blob_offs)
 {
+    if (fmt == SS_TEXT_JSON_MINIMAL)  // (nothing in such a text names its form: the caller does)
+        return stwo_minimal_ingest_dev(ctx, c, n, texts, lens, paths, status_host, stats, blob, blob_offs);
     if (!ctx || !status_host || (!texts && !paths && !blob) || ((texts || blob) && !lens) || (blob && !blob_offs))
         return set_err(SS_ERR_ARG, "null argument");
     if (blob) {
@@ -590,9 +592,11 @@ int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *con
 // lengths found in the text, csrc/ss_text.h), the host readers' records are spread into that form, and the verification is
 // ss_minimal.hip's on records at a fixed stride -- no per-query records anywhere.
 int stwo_minimal_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *const *texts, const size_t *lens,
-                            uint32_t *status_host, ss_ingest_stats *stats, const uint8_t *blob, const uint64_t *blob_offs)
+                            const char *const *paths, uint32_t *status_host, ss_ingest_stats *stats, const uint8_t *blob,
+                            const uint64_t *blob_offs)
 {
-    if (!ctx || !status_host || (!texts && !blob) || !lens || (blob && !blob_offs)) return set_err(SS_ERR_ARG, "null argument");
+    if (!ctx || !status_host || (!texts && !paths && !blob) || ((texts || blob) && !lens) || (blob && !blob_offs))
+        return set_err(SS_ERR_ARG, "null argument");
     if (blob) {
         hipPointerAttribute_t a;
         for (size_t i = 0; i < n; i++)
@@ -641,7 +645,7 @@ int stwo_minimal_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const c
         for (size_t i = 0; i < n; i++) ptrs[i] = (const char *)blob + blob_offs[i];
         texts = ptrs.data();
     }
-    return ingest_pipeline(ctx, F, n, texts, lens, nullptr, SS_TEXT_JSON, status_host, outcome, stats, t0, blob, blob_offs);
+    return ingest_pipeline(ctx, F, n, texts, lens, paths, SS_TEXT_JSON, status_host, outcome, stats, t0, blob, blob_offs);
 }
 
 // stark101: the protocol's shape has a template (ss_text.h); a proof of another shape is parsed by the host reader

@@ -311,7 +311,7 @@ def test_gpu_reader_of_the_minimal_text_equals_its_scalar_rule(ver, i):
     assert outcome[0] == outcome[1] == outcome[2] == 0 and 8 <= taken < len(texts)
 
 
-def test_minimal_texts_through_the_gpu_reader_give_the_records_verdicts(ver):
+def test_minimal_texts_through_the_gpu_reader_give_the_records_verdicts(ver, tmp_path):
     """ss_stwo_verify_minimal_texts end to end at the metric shape (2^20 rows: 0.43-0.54 MB a text, several chunks of the
     pipeline): texts of the fixture and of corrupted records in both spellings go through the GPU reader, texts in another
     member order through the host readers, garbage and another config get the stage-0 codes; every verdict is the oracle's
@@ -346,3 +346,16 @@ def test_minimal_texts_through_the_gpu_reader_give_the_records_verdicts(ver):
     blob, offs, lens = ver.pinned_text_blob(texts)
     got2, stats2 = ver.verify_stwo_minimal_texts_pinned(cfg, blob, offs, lens)
     assert got2.tolist() == want and stats2["host_parsed"] == host
+    # the general text entry points take the form by name (never by SS_TEXT_AUTO), files included
+    from stark_symphony_amd import binding as B
+    got3, _ = ver.verify_stwo_texts(cfg, texts[-40:], fmt=B.TEXT_JSON_MINIMAL)
+    assert got3.tolist() == want[-40:]
+    paths = []
+    for k, t in enumerate(texts[-12:]):
+        paths.append(str(tmp_path / ("m%02d.json" % k)))
+        open(paths[-1], "wb").write(t)
+    paths.append(str(tmp_path / "absent.json"))
+    got4, stats4 = ver.verify_stwo_files(cfg, paths, fmt=B.TEXT_JSON_MINIMAL)
+    assert got4.tolist() == want[-12:] + [2]
+    auto, _ = ver.verify_stwo_texts(cfg, texts[:2])  # (read as a per-query proof.json: its lists are too short for that form)
+    assert (auto != 0).all()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Text -> verdict rate of ss_stwo_verify_texts on the metric shape (2^20-row proofs), alone.
 
-    python tools/e2e_bench.py [--n 1536] [--reps 5] [--fmt json|wit|shared|both|all] [--workload stwo_trace20.npz]
+    python tools/e2e_bench.py [--n 1536] [--reps 5] [--fmt json|wit|shared|minimal|both|all] [--workload stwo_trace20.npz]
 
 Prints one JSON object: proofs/s and text GB/s (best and median of --reps), the host staging time,
 texts that needed the host reader, and the GPU reader's kernel times per chunk (HIP events)."""
@@ -34,7 +34,7 @@ def main():
     cfg = p.cfg
     ver = verifier.Verifier(0)
     out = {"n": args.n, "workload": args.workload}
-    kinds = ["json", "wit"] if args.fmt == "both" else ["json", "wit", "shared"] if args.fmt == "all" else [args.fmt]
+    kinds = ["json", "wit"] if args.fmt == "both" else ["json", "wit", "shared", "minimal"] if args.fmt == "all" else [args.fmt]
     for kind in kinds:
         if kind == "json":
             text = (json.dumps(ss.stwo_to_json(p)) if args.python_separators else
@@ -46,6 +46,12 @@ def main():
             text = (json.dumps(obj) if args.python_separators else json.dumps(obj, separators=(",", ":"))).encode()
             odd = json.dumps(dict(reversed(list(obj.items())))).encode()
             fmt = binding.TEXT_AUTO
+        elif kind == "minimal":  # one sorted, deduplicated decommitment per tree (its list lengths are found by the GPU reader)
+            from stark_symphony_amd import formats
+            obj = formats.stwo_minimal_to_json(formats.stwo_minimise(p))
+            text = (json.dumps(obj) if args.python_separators else json.dumps(obj, separators=(",", ":"))).encode()
+            odd = json.dumps(dict(reversed(list(obj.items())))).encode()
+            fmt = binding.TEXT_JSON_MINIMAL
         else:
             text = ss.stwo_to_wit(p).encode()
             odd = text.replace(b'"type": "u64"', b'"type":  "u64"')
