@@ -413,6 +413,8 @@ int ss_stwo_verify_minimal_texts_pinned(ss_ctx *ctx, const ss_stwo_cfg *cfg, siz
                                         const size_t *lens, uint32_t *status_host, ss_ingest_stats *stats);
 int ss_s101_verify_texts(ss_ctx *ctx, size_t n, const char *const *texts, const size_t *lens, int fmt,
                          uint32_t *status_host, ss_ingest_stats *stats);
+int ss_s101_verify_texts_pinned(ss_ctx *ctx, size_t n, const char *blob, const uint64_t *offs, const size_t *lens, int fmt,
+                                uint32_t *status_host, ss_ingest_stats *stats);  /* as ss_stwo_verify_texts_pinned */
 int ss_s101_verify_files(ss_ctx *ctx, size_t n, const char *const *paths, int fmt, uint32_t *status_host,
                          ss_ingest_stats *stats);
 

@@ -68,7 +68,7 @@ EXPORTS = [
     "ss_stwo_minimal_fixed_words", "ss_stwo_minimal_max_words", "ss_stwo_minimal_counts", "ss_stwo_minimise_record",
     "ss_stwo_minimal_batch_words", "ss_stwo_minimal_workspace_bytes", "ss_stwo_verify_minimal_dev",
     "ss_host_register", "ss_host_unregister", "ss_stwo_verify_texts_pinned", "ss_stwo_verify_records_pinned", "ss_stwo_verify_shared_records_pinned",
-    "ss_stwo_verify_minimal_records_pinned", "ss_s101_read_intermediates", "ss_kat", "ss_stwo_verify_minimal_records", "ss_stwo_parse_minimal", "ss_stwo_parse_minimal_route", "ss_stwo_minimal_from_capacity", "ss_stwo_minimal_to_capacity", "ss_stwo_write_minimal_text", "ss_stwo_verify_minimal_texts", "ss_stwo_verify_minimal_texts_pinned",
+    "ss_stwo_verify_minimal_records_pinned", "ss_s101_read_intermediates", "ss_kat", "ss_stwo_verify_minimal_records", "ss_stwo_parse_minimal", "ss_stwo_parse_minimal_route", "ss_stwo_minimal_from_capacity", "ss_stwo_minimal_to_capacity", "ss_stwo_write_minimal_text", "ss_stwo_verify_minimal_texts", "ss_stwo_verify_minimal_texts_pinned", "ss_s101_verify_texts_pinned",
 ]
 
 _lib = None
@@ -138,6 +138,7 @@ def lib() -> C.CDLL:
     sig("ss_selftest", C.c_int, vp, C.c_int, sz, vp, vp)
     sig("ss_kat", C.c_int, vp, C.c_int, sz, vp, sz, vp, sz)
     sig("ss_stwo_verify_texts_pinned", C.c_int, vp, cp, sz, vp, vp, szp, C.c_int, vp, stp)
+    sig("ss_s101_verify_texts_pinned", C.c_int, vp, sz, vp, vp, szp, C.c_int, vp, stp)
     sig("ss_host_register", C.c_int, vp, vp, sz)
     sig("ss_host_unregister", C.c_int, vp, vp)
     sig("ss_stwo_verify_records_pinned", C.c_int, vp, cp, sz, vp, vp)

@@ -1060,6 +1060,17 @@ extern "C" int ss_s101_verify_texts(ss_ctx *ctx, size_t n, const char *const *te
     return s101_ingest_dev(ctx, n, texts, lens, nullptr, fmt, status_host, stats);
 }
 
+extern "C" int ss_s101_verify_texts_pinned(ss_ctx *ctx, size_t n, const char *blob, const uint64_t *offs, const size_t *lens, int fmt,
+                                           uint32_t *status_host, ss_ingest_stats *stats)
+{
+    if (!blob || !offs) return set_err(SS_ERR_ARG, "null argument");
+    try {
+        return s101_ingest_dev(ctx, n, nullptr, lens, nullptr, fmt, status_host, stats, (const uint8_t *)blob, offs);
+    } catch (const std::exception &) {
+        return set_err(SS_ERR_NOMEM, "out of host memory");
+    }
+}
+
 extern "C" int ss_s101_verify_files(ss_ctx *ctx, size_t n, const char *const *paths, int fmt, uint32_t *status_host,
                                     ss_ingest_stats *stats)
 {

@@ -161,7 +161,7 @@ int stwo_minimal_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const c
                             const char *const *paths, uint32_t *status_host, ss_ingest_stats *stats, const uint8_t *blob = nullptr,
                             const uint64_t *blob_offs = nullptr);
 int s101_ingest_dev(ss_ctx *ctx, size_t n, const char *const *texts, const size_t *lens, const char *const *paths, int fmt,
-                    uint32_t *status_host, ss_ingest_stats *stats);
+                    uint32_t *status_host, ss_ingest_stats *stats, const uint8_t *blob = nullptr, const uint64_t *blob_offs = nullptr);
 // ss_s101_verify_records for a caller that already holds ctx->mu
 int s101_verify_records_locked(ss_ctx *ctx, const ss_s101_shape *sh, size_t n, const uint32_t *const *records,
                                uint32_t *status_host);

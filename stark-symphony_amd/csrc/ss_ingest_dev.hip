@@ -211,6 +211,22 @@ struct Family {
 };
 constexpr int kDeferred = 3;
 
+// a caller-pinned text buffer: offsets that leave room for 16-byte reads, memory the DMA engine can read
+static int blob_ok(size_t n, const size_t *lens, const uint8_t *blob, const uint64_t *blob_offs)
+{
+    hipPointerAttribute_t a;
+    for (size_t i = 0; i < n; i++)
+        if ((blob_offs[i] & 15) || blob_offs[i + 1] < blob_offs[i] + lens[i])
+            return set_err(SS_ERR_ARG, "text %zu: offsets are multiples of 16, ascending, at least a text's length apart", i);
+    if ((blob_offs[n] & 15)) return set_err(SS_ERR_ARG, "the end offset is a multiple of 16 too (room for 16-byte reads)");
+    if (hipPointerGetAttributes(&a, blob) != hipSuccess || a.type != hipMemoryTypeHost ||
+        (blob_offs[n] && (hipPointerGetAttributes(&a, blob + blob_offs[n] - 1) != hipSuccess || a.type != hipMemoryTypeHost))) {
+        (void)hipGetLastError();
+        return set_err(SS_ERR_ARG, "the buffer is not page-locked host memory (hipHostMalloc / ss_host_register)");
+    }
+    return SS_OK;
+}
+
 // blob / blob_offs (optional): the texts lie in ONE page-locked buffer of the caller's, text i at byte blob_offs[i] (a
 // multiple of 16, ascending, blob_offs[n] = the end): nothing is staged -- the DMA engine reads the chunk's bytes where they
 // are, the stager only writes the chunk's small tables, and the host reader (non-canonical texts) reads the caller's copy.
@@ -539,16 +555,8 @@ int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *con
     if (!ctx || !status_host || (!texts && !paths && !blob) || ((texts || blob) && !lens) || (blob && !blob_offs))
         return set_err(SS_ERR_ARG, "null argument");
     if (blob) {
-        hipPointerAttribute_t a;
-        for (size_t i = 0; i < n; i++)
-            if ((blob_offs[i] & 15) || blob_offs[i + 1] < blob_offs[i] + lens[i])
-                return set_err(SS_ERR_ARG, "text %zu: offsets are multiples of 16, ascending, at least a text's length apart", i);
-        if ((blob_offs[n] & 15)) return set_err(SS_ERR_ARG, "the end offset is a multiple of 16 too (room for 16-byte reads)");
-        if (hipPointerGetAttributes(&a, blob) != hipSuccess || a.type != hipMemoryTypeHost ||
-            (blob_offs[n] && (hipPointerGetAttributes(&a, blob + blob_offs[n] - 1) != hipSuccess || a.type != hipMemoryTypeHost))) {
-            (void)hipGetLastError();
-            return set_err(SS_ERR_ARG, "the buffer is not page-locked host memory (hipHostMalloc / ss_host_register)");
-        }
+        const int bad = blob_ok(n, lens, blob, blob_offs);
+        if (bad) return bad;
     }
     if (!cfg_ok(c)) return set_err(SS_ERR_ARG, "unsupported stwo config");
     if (!n) return set_err(SS_ERR_ARG, "empty batch");
@@ -598,16 +606,8 @@ int stwo_minimal_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const c
     if (!ctx || !status_host || (!texts && !paths && !blob) || ((texts || blob) && !lens) || (blob && !blob_offs))
         return set_err(SS_ERR_ARG, "null argument");
     if (blob) {
-        hipPointerAttribute_t a;
-        for (size_t i = 0; i < n; i++)
-            if ((blob_offs[i] & 15) || blob_offs[i + 1] < blob_offs[i] + lens[i])
-                return set_err(SS_ERR_ARG, "text %zu: offsets are multiples of 16, ascending, at least a text's length apart", i);
-        if ((blob_offs[n] & 15)) return set_err(SS_ERR_ARG, "the end offset is a multiple of 16 too (room for 16-byte reads)");
-        if (hipPointerGetAttributes(&a, blob) != hipSuccess || a.type != hipMemoryTypeHost ||
-            (blob_offs[n] && (hipPointerGetAttributes(&a, blob + blob_offs[n] - 1) != hipSuccess || a.type != hipMemoryTypeHost))) {
-            (void)hipGetLastError();
-            return set_err(SS_ERR_ARG, "the buffer is not page-locked host memory (hipHostMalloc / ss_host_register)");
-        }
+        const int bad = blob_ok(n, lens, blob, blob_offs);
+        if (bad) return bad;
     }
     if (!cfg_ok(c)) return set_err(SS_ERR_ARG, "unsupported stwo config");
     if (!n) return set_err(SS_ERR_ARG, "empty batch");
@@ -651,10 +651,15 @@ int stwo_minimal_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const c
 // stark101: the protocol's shape has a template (ss_text.h); a proof of another shape is parsed by the host reader
 // and, when it does not fit the {10, 13} records of the pipeline, verified afterwards in a batch of its own shape.
 int s101_ingest_dev(ss_ctx *ctx, size_t n, const char *const *texts, const size_t *lens, const char *const *paths, int fmt,
-                    uint32_t *status_host, ss_ingest_stats *stats)
+                    uint32_t *status_host, ss_ingest_stats *stats, const uint8_t *blob, const uint64_t *blob_offs)
 {
-    if (!ctx || !status_host || (!texts && !paths) || (texts && !lens)) return set_err(SS_ERR_ARG, "null argument");
+    if (!ctx || !status_host || (!texts && !paths && !blob) || ((texts || blob) && !lens) || (blob && !blob_offs))
+        return set_err(SS_ERR_ARG, "null argument");
     if (!n) return set_err(SS_ERR_ARG, "empty batch");
+    if (blob) {
+        const int bad = blob_ok(n, lens, blob, blob_offs);
+        if (bad) return bad;
+    }
     if (fmt < SS_TEXT_AUTO || fmt > SS_TEXT_WIT) return set_err(SS_ERR_ARG, "unknown text format");
     if (n > 0x7fffffffu) return set_err(SS_ERR_ARG, "batch too large");
     std::lock_guard<std::mutex> lock(ctx->mu);
@@ -692,7 +697,13 @@ int s101_ingest_dev(ss_ctx *ctx, size_t n, const char *const *texts, const size_
         return r ? r : ss_s101_verify_batch_dev(ctx, &sh, cnt, batch, ws, wsb, status, nullptr, s);
     };
     std::vector<uint8_t> outcome;
-    rc = ingest_pipeline(ctx, F, n, texts, lens, paths, fmt, status_host, outcome, stats, t0);
+    std::vector<const char *> ptrs0;
+    if (blob) {  // (the pipeline's size / readability rules look at texts[i] and lens[i])
+        ptrs0.resize(n);
+        for (size_t i = 0; i < n; i++) ptrs0[i] = (const char *)blob + blob_offs[i];
+        texts = ptrs0.data();
+    }
+    rc = ingest_pipeline(ctx, F, n, texts, lens, paths, fmt, status_host, outcome, stats, t0, blob, blob_offs);
     // ---- proofs of a larger shape than the protocol's: one more batch, of their own shape
     std::vector<size_t> late;
     ss_s101_shape big = {0, 0};

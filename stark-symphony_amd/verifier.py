@@ -964,6 +964,22 @@ class Verifier:
                                                     status.ctypes.data, C.byref(stats)))
         return status, {k: getattr(stats, k) for k, _ in B.IngestStats._fields_}
 
+    def verify_stark101_texts_pinned(self, blob: np.ndarray, offsets, lengths, fmt: int = B.TEXT_AUTO):
+        """ss_s101_verify_texts_pinned: stark101 proof.json / proof.wit texts lying in one page-locked uint8 array."""
+        offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+        lens = np.ascontiguousarray(lengths, dtype=np.uint64)
+        n = lens.size
+        if blob.dtype != np.uint8 or not blob.flags["C_CONTIGUOUS"] or offs.size != n + 1 or (n and int(offs[-1]) > blob.size):
+            raise ValueError("a contiguous uint8 array, n + 1 byte offsets inside it and n lengths expected")
+        status = np.full(n, 0xFFFFFFFF, dtype=np.uint32)
+        stats = B.IngestStats()
+        if n == 0:
+            return status, {k: 0 for k, _ in B.IngestStats._fields_}
+        clens = (C.c_size_t * n).from_buffer(lens)
+        B.check(B.lib().ss_s101_verify_texts_pinned(self.ctx, n, blob.ctypes.data, offs.ctypes.data, clens, fmt, status.ctypes.data,
+                                                    C.byref(stats)))
+        return status, {k: getattr(stats, k) for k, _ in B.IngestStats._fields_}
+
     def verify_stwo_minimal_texts_pinned(self, cfg: StwoConfig, blob: np.ndarray, offsets, lengths, mode: int = MODE_FIXTURE):
         """ss_stwo_verify_minimal_texts_pinned: minimal proof.json texts lying in one page-locked uint8 array (pinned_text_blob)
         -> (status, stats)."""

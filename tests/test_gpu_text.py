@@ -249,6 +249,14 @@ def test_stark101_verify_texts_mixed_shapes(ver, tmp_path):
         paths.append(str(f))
     status, _ = ver.verify_stark101_files(paths + [str(tmp_path / "absent")])
     assert status.tolist() == want + [2]
+    # the same texts in one caller-pinned buffer (ss_s101_verify_texts_pinned): the staged verdicts, the same host share
+    batch = [texts[i % len(texts)] for i in range(3000)]
+    blob, offs, lens = ver.pinned_text_blob(batch)
+    status, stats = ver.verify_stark101_texts_pinned(blob, offs, lens)
+    assert status.tolist() == [want[i % len(texts)] for i in range(3000)]
+    assert stats["host_parsed"] == sum(1 for i in range(3000) if i % len(texts) >= canonical_n)
+    with pytest.raises(binding.SsError):
+        ver.verify_stark101_texts_pinned(np.array(blob), offs, lens)  # pageable memory
 
 
 def test_stark101_device_pack_equals_host_pack(ver):
