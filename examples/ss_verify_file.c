@@ -9,6 +9,10 @@
  *                  <mode 0|1> records.bin
  *   ss_verify_file stwo-shared <the same nine numbers> shared.bin      (ABI 2.2: SHARED records back to back -- every
  *                  distinct Merkle sibling once; a record says how long it is: fixed words + 8 * sum of its counts)
+ *   ss_verify_file stwo-minimal <the same nine numbers> minimal.bin    (ABI 2.3: MINIMAL records back to back -- one sorted,
+ *                  deduplicated decommitment per tree; the record's count words say how long its lists are)
+ *   ss_verify_file stwo-text <the same nine numbers> <fmt 0..4> file...      (texts: the library reads the files itself and
+ *                  parses them on the GPU; fmt = SS_TEXT_AUTO / _JSON / _WIT / _JSON_SHARED / _JSON_MINIMAL)
  *   ss_verify_file stark101 <max_layers> <max_path> records.bin
  *
  * records.bin = the records back to back, little-endian u32 words (include/ss_verify.h; written by
@@ -41,9 +45,10 @@ static uint32_t *read_words(const char *path, size_t *n_words)
 int main(int argc, char **argv)
 {
     if (argc < 2) { fprintf(stderr, "usage: see the header of examples/ss_verify_file.c\n"); return 2; }
-    const int shared = strcmp(argv[1], "stwo-shared") == 0;
-    const int stwo = shared || strcmp(argv[1], "stwo") == 0;
-    if ((stwo && argc != 11) || (!stwo && (strcmp(argv[1], "stark101") != 0 || argc != 5))) {
+    const int shared = strcmp(argv[1], "stwo-shared") == 0, minimal = strcmp(argv[1], "stwo-minimal") == 0;
+    const int text = strcmp(argv[1], "stwo-text") == 0;
+    const int stwo = shared || minimal || text || strcmp(argv[1], "stwo") == 0;
+    if ((stwo && !text && argc != 11) || (text && argc < 12) || (!stwo && (strcmp(argv[1], "stark101") != 0 || argc != 5))) {
         fprintf(stderr, "usage: see the header of examples/ss_verify_file.c\n");
         return 2;
     }
@@ -72,6 +77,24 @@ int main(int argc, char **argv)
         path = argv[4];
     }
     if (!rec_words) { fprintf(stderr, "unsupported configuration\n"); return 2; }
+    if (text) {  /* files of text: nothing is read or parsed here */
+        const size_t nf = (size_t)argc - 11;
+        uint32_t *st = (uint32_t *)malloc(nf * sizeof *st);
+        ss_ingest_stats stats;
+        ss_ctx *tctx = NULL;
+        int trc = ss_ctx_create(0, &tctx);
+        if (trc == SS_OK) trc = ss_stwo_verify_files(tctx, &cfg, nf, (const char *const *)(argv + 11), atoi(argv[10]), st, &stats);
+        if (trc != SS_OK) { fprintf(stderr, "libss_verify: %s (code %d)\n", ss_last_error(), trc); return 2; }
+        size_t bad = 0;
+        for (size_t i = 0; i < nf; i++) {
+            if (st[i]) { bad++; printf("%s: REJECT (0x%08x)\n", argv[11 + i], st[i]); }
+            else printf("%s: ACCEPT\n", argv[11 + i]);
+        }
+        printf("%u of %zu texts went through the host reader\n", stats.host_parsed, nf);
+        ss_ctx_destroy(tctx);
+        free(st);
+        return bad ? 1 : 0;
+    }
     size_t n_words = 0;
     uint32_t *words = read_words(path, &n_words);
     if (!words) return 2;
@@ -97,6 +120,28 @@ int main(int argc, char **argv)
             lens[n++] = len;
             o += len;
         }
+    } else if (minimal) {
+        /* a minimal record: ss_stwo_minimal_fixed_words words, the last 2 + (n_layers + 1) + (n_layers + 3) of them its list
+         * lengths -- value rows of the two trees, fri_witness entries per layer, hashes per tree -- then the lists */
+        const size_t fixed = ss_stwo_minimal_fixed_words(&cfg), K = cfg.n_layers, nc = 2 + (K + 1) + (K + 3);
+        const size_t max_words = ss_stwo_minimal_max_words(&cfg);
+        if (fixed == 0) { fprintf(stderr, "unsupported stwo config\n"); return 2; }
+        recs = (const uint32_t **)malloc((n_words / fixed + 1) * sizeof *recs);
+        lens = (size_t *)malloc((n_words / fixed + 1) * sizeof *lens);
+        for (size_t o = 0; o < n_words;) {
+            size_t len = fixed;
+            if (o + fixed > n_words) len = n_words - o;
+            else {
+                const uint32_t *c = words + o + fixed - nc;
+                len += (size_t)c[0] * cfg.n_cols + (size_t)c[1] * 16;
+                for (size_t l = 0; l <= K; l++) len += 4 * (size_t)c[2 + l];
+                for (size_t t = 0; t < K + 3; t++) len += 8 * (size_t)c[3 + K + t];
+                if (len > max_words || o + len > n_words) len = n_words - o;
+            }
+            recs[n] = words + o;
+            lens[n++] = len;
+            o += len;
+        }
     } else {
         if (n_words % rec_words) { fprintf(stderr, "%s: %zu words is not a multiple of the %zu-word record\n", path, n_words, rec_words); return 2; }
         n = n_words / rec_words;
@@ -109,6 +154,7 @@ int main(int argc, char **argv)
     int rc = ss_ctx_create(0, &ctx);
     if (rc == SS_OK)
         rc = shared ? ss_stwo_verify_shared_records(ctx, &cfg, n, recs, lens, status)
+             : minimal ? ss_stwo_verify_minimal_records(ctx, &cfg, n, recs, lens, status)
              : stwo ? ss_stwo_verify_records(ctx, &cfg, n, recs, status)
                     : ss_s101_verify_records(ctx, &shape, n, recs, status);
     if (rc != SS_OK) {  /* no CPU fallback: a missing GPU is an error, never a verdict */

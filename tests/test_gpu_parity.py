@@ -490,6 +490,33 @@ def test_c_abi_consumer_program(ver, tmp_path, s101_proof, stwo_prod):
     for i, w in enumerate(sh_want):
         assert lines[i] == ("proof %d: ACCEPT" % i if w == 0 else "proof %d: REJECT (first failing assert 0x%08x)" % (i, w))
     assert r.returncode == (1 if any(sh_want) else 0)
+    # ... from MINIMAL records (ABI 2.3), and from text files in three forms (the library reads and parses them)
+    mins, min_want = [], []
+    for p, w in zip(proofs, want.tolist()):
+        try:
+            mins.append(verifier.stwo_minimise_record(c, verifier.stwo_record(p), qs))
+            min_want.append(O.stwo_verify_minimal(c, mins[-1], 1))
+        except ValueError:
+            pass
+    assert len(mins) >= 3 and min_want[0] == 0
+    mpath = tmp_path / "minimal.bin"
+    np.concatenate(mins).astype("<u4").tofile(mpath)
+    r = subprocess.run([exe, "stwo-minimal"] + args[2:-1] + [str(mpath)], capture_output=True, text=True)
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == len(mins), r.stderr
+    for i, w in enumerate(min_want):
+        assert lines[i] == ("proof %d: ACCEPT" % i if w == 0 else "proof %d: REJECT (first failing assert 0x%08x)" % (i, w))
+    assert r.returncode == (1 if any(min_want) else 0)
+    import json
+    files = {"a.json": (json.dumps(ss.stwo_to_json(stwo_prod)).encode(), 1), "a.wit": (ss.stwo_to_wit(stwo_prod).encode(), 2),
+             "a.min.json": (verifier.write_stwo_minimal_text(c, mins[0]), 4)}
+    for name, (text, fmt) in files.items():
+        (tmp_path / name).write_bytes(text)
+        r = subprocess.run([exe, "stwo-text"] + args[2:-1] + [str(fmt), str(tmp_path / name)], capture_output=True, text=True)
+        assert r.returncode == 0 and "ACCEPT" in r.stdout and "0 of 1 texts went through the host reader" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([exe, "stwo-text"] + args[2:-1] + ["4", str(tmp_path / "a.min.json"), str(tmp_path / "absent")],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "REJECT (0x00000002)" in r.stdout
     ml, pm = verifier.s101_shape_of([s101_proof])
     p101 = tmp_path / "s101.bin"
     verifier.s101_record(s101_proof, ml, pm).astype("<u4").tofile(p101)
