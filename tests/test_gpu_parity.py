@@ -508,7 +508,7 @@ def test_c_abi_consumer_program(ver, tmp_path, s101_proof, stwo_prod):
         assert lines[i] == ("proof %d: ACCEPT" % i if w == 0 else "proof %d: REJECT (first failing assert 0x%08x)" % (i, w))
     assert r.returncode == (1 if any(min_want) else 0)
     import json
-    files = {"a.json": (json.dumps(ss.stwo_to_json(stwo_prod)).encode(), 1), "a.wit": (ss.stwo_to_wit(stwo_prod).encode(), 2),
+    files = {"a.json": (json.dumps(formats.stwo_to_json(stwo_prod)).encode(), 1), "a.wit": (formats.stwo_to_wit(stwo_prod).encode(), 2),
              "a.min.json": (verifier.write_stwo_minimal_text(c, mins[0]), 4)}
     for name, (text, fmt) in files.items():
         (tmp_path / name).write_bytes(text)
