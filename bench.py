@@ -422,6 +422,29 @@ def end_to_end(ver, proofs, n: int, rank: int = 0, world: int = 1, dist=None):
         except Exception as e:  # noqa: BLE001
             errors.append("rank %d pinned %s: %r" % (rank, kind, e))
         del batch
+    # ONE input -> verdict, the reference's calling convention (`simfony run` takes one witness): median of 21 calls, rank 0.
+    # Dominated by the transcript kernel's dependent hash chain and the launches, not by bytes.
+    if rank == 0:
+        try:
+            one = {}
+            cases = (("json", lambda: ver.verify_stwo_texts(cfg, [texts["json"][0]], fmt=binding.TEXT_JSON)[0]),
+                     ("wit", lambda: ver.verify_stwo_texts(cfg, [texts["wit"][0]], fmt=binding.TEXT_WIT)[0]),
+                     ("json_minimal", lambda: ver.verify_stwo_minimal_texts(cfg, [mtexts[0]])[0]),
+                     ("record", lambda: ver.verify_stwo_records(cfg, recs[:1])),
+                     ("minimal_record", lambda: ver.verify_stwo_minimal_records(cfg, minimal[:1])))
+            for name, call in cases:
+                st = call()
+                if not (np.asarray(st) == 0).all():
+                    raise AssertionError("single %s: not accepted" % name)
+                ts = []
+                for _ in range(21):
+                    t0 = time.perf_counter()
+                    call()
+                    ts.append(time.perf_counter() - t0)
+                one[name + "_ms"] = sorted(ts)[10] * 1e3
+            out["single_input_latency"] = one
+        except Exception as e:  # noqa: BLE001
+            errors.append("single-input latency: %r" % (e,))
     if errors:
         out["errors"] = errors
     return out
