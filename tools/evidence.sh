@@ -90,7 +90,7 @@ for f in sorted(glob.glob(O + '/bench_*.json')):
     print(os.path.basename(f)[6:-5], round(d['value']), round(d['ms_per_step'], 3), 'roof', round(d['roofline']['frac'], 4), 'alu',
           round(d['alu_roofline']['frac'], 4), 'issue', d['alu_roofline'].get('issue_frac'),
           {k: round(v, 3) for k, v in d['kernels_ms_per_step'].items() if k in ('stwo_merkle', 'stwo_top', 's101_merkle')},
-          'e2e', {k: round(v['proofs_per_s']) for k, v in d.get('e2e', {}).items() if isinstance(v, dict)})
+          'e2e', {k: round(v['proofs_per_s']) for k, v in d.get('e2e', {}).items() if isinstance(v, dict) and 'proofs_per_s' in v})
 for f in sorted(glob.glob(O + '/e2e_*.json')):
     try:
         d = json.load(open(f))
