@@ -928,22 +928,27 @@ extern "C" int ss_stwo_text_is_canonical(const ss_stwo_cfg *c, const char *text,
 {
     if (!cfg_ok(c) || !text || (fmt != SS_TEXT_JSON && fmt != SS_TEXT_WIT && fmt != SS_TEXT_JSON_SHARED && fmt != SS_TEXT_JSON_MINIMAL))
         return set_err(SS_ERR_ARG, "bad argument");
-    // the template of the last (config, format) asked about is kept per thread: building one walks the whole text
-    static thread_local TextTemplateHost h;
-    static thread_local ss_stwo_cfg h_cfg;
-    static thread_local int h_fmt = -1;
-    if (h_fmt != fmt || memcmp(&h_cfg, c, sizeof h_cfg) != 0) {
-        stwo_build_template(*c, fmt, h);
-        memcpy(&h_cfg, c, sizeof h_cfg);  // (ctypes / C callers zero the struct's padding; a mismatch only rebuilds)
-        h_fmt = fmt;
+    try {
+        // the template of the last (config, format) asked about is kept per thread: building one walks the whole text
+        static thread_local TextTemplateHost h;
+        static thread_local ss_stwo_cfg h_cfg;
+        static thread_local int h_fmt = -1;
+        if (h_fmt != fmt || memcmp(&h_cfg, c, sizeof h_cfg) != 0) {
+            h_fmt = -1;  // (nothing is cached if building throws)
+            stwo_build_template(*c, fmt, h);
+            memcpy(&h_cfg, c, sizeof h_cfg);  // (ctypes / C callers zero the struct's padding; a mismatch only rebuilds)
+            h_fmt = fmt;
+        }
+        if (!h.ok) return 0;
+        std::vector<uint32_t> scratch;
+        uint32_t *rec = record_out;
+        if (!rec) { scratch.resize(std::max<size_t>(h.record_words, ss_stwo_record_words(c))); rec = scratch.data(); }
+        if (fmt == SS_TEXT_JSON_SHARED) return shared_text_scan_reference(*c, h, text, len, rec) ? 1 : 0;
+        if (fmt == SS_TEXT_JSON_MINIMAL) return minimal_text_scan_reference(*c, h, text, len, rec) ? 1 : 0;  // (capacity form)
+        return text_scan_reference(h.view(), text, len, rec) ? 1 : 0;
+    } catch (const std::exception &) {
+        return set_err(SS_ERR_NOMEM, "out of host memory");
     }
-    if (!h.ok) return 0;
-    std::vector<uint32_t> scratch;
-    uint32_t *rec = record_out;
-    if (!rec) { scratch.resize(std::max<size_t>(h.record_words, ss_stwo_record_words(c))); rec = scratch.data(); }
-    if (fmt == SS_TEXT_JSON_SHARED) return shared_text_scan_reference(*c, h, text, len, rec) ? 1 : 0;
-    if (fmt == SS_TEXT_JSON_MINIMAL) return minimal_text_scan_reference(*c, h, text, len, rec) ? 1 : 0;  // (capacity form)
-    return text_scan_reference(h.view(), text, len, rec) ? 1 : 0;
 }
 
 extern "C" int ss_stwo_minimal_from_capacity(const ss_stwo_cfg *c, const uint32_t *capacity, uint32_t *minimal_out, size_t cap_words,
@@ -1021,7 +1026,11 @@ bool ss::read_file(const char *path, std::string &out)
 extern "C" int ss_stwo_verify_texts(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *const *texts,
                                     const size_t *lens, int fmt, uint32_t *status_host, ss_ingest_stats *stats)
 {
-    return stwo_ingest_dev(ctx, c, n, texts, lens, nullptr, fmt, status_host, stats);
+    try {
+        return stwo_ingest_dev(ctx, c, n, texts, lens, nullptr, fmt, status_host, stats);
+    } catch (const std::exception &) {
+        return set_err(SS_ERR_NOMEM, "out of host memory");
+    }
 }
 
 // the same with the texts in ONE page-locked buffer of the caller's (text i at byte offs[i], a multiple of 16): no staging copy
@@ -1051,13 +1060,21 @@ extern "C" int ss_s101_read_texts(ss_ctx *ctx, size_t n, const char *const *text
 extern "C" int ss_stwo_verify_files(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *const *paths, int fmt,
                                     uint32_t *status_host, ss_ingest_stats *stats)
 {
-    return stwo_ingest_dev(ctx, c, n, nullptr, nullptr, paths, fmt, status_host, stats);
+    try {
+        return stwo_ingest_dev(ctx, c, n, nullptr, nullptr, paths, fmt, status_host, stats);
+    } catch (const std::exception &) {
+        return set_err(SS_ERR_NOMEM, "out of host memory");
+    }
 }
 
 extern "C" int ss_s101_verify_texts(ss_ctx *ctx, size_t n, const char *const *texts, const size_t *lens, int fmt,
                                     uint32_t *status_host, ss_ingest_stats *stats)
 {
-    return s101_ingest_dev(ctx, n, texts, lens, nullptr, fmt, status_host, stats);
+    try {
+        return s101_ingest_dev(ctx, n, texts, lens, nullptr, fmt, status_host, stats);
+    } catch (const std::exception &) {
+        return set_err(SS_ERR_NOMEM, "out of host memory");
+    }
 }
 
 extern "C" int ss_s101_verify_texts_pinned(ss_ctx *ctx, size_t n, const char *blob, const uint64_t *offs, const size_t *lens, int fmt,
@@ -1074,7 +1091,11 @@ extern "C" int ss_s101_verify_texts_pinned(ss_ctx *ctx, size_t n, const char *bl
 extern "C" int ss_s101_verify_files(ss_ctx *ctx, size_t n, const char *const *paths, int fmt, uint32_t *status_host,
                                     ss_ingest_stats *stats)
 {
-    return s101_ingest_dev(ctx, n, nullptr, nullptr, paths, fmt, status_host, stats);
+    try {
+        return s101_ingest_dev(ctx, n, nullptr, nullptr, paths, fmt, status_host, stats);
+    } catch (const std::exception &) {
+        return set_err(SS_ERR_NOMEM, "out of host memory");
+    }
 }
 
 // =========================================================================== self-test
