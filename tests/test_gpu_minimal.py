@@ -300,6 +300,11 @@ def test_gpu_reader_of_the_minimal_text_equals_its_scalar_rule(ver, i):
               variant(lambda o: o["decommitments"][2]["hash_witness"].pop()), variant(all_empty),
               variant(lambda o: [o["queried_values"][1].pop() for _ in range(cfg.n_cols)]),
               variant(lambda o: o.__setitem__("hash_witness", [])), json.dumps(dict(reversed(list(obj.items())))).encode()]
+    # more landmarks than the per-text table holds (member names in a trailing object, in one window and spread over many)
+    many = {"hash_witness_%d" % k: k for k in range(50)}
+    texts += [variant(lambda o: o.__setitem__("x", many)), variant(lambda o: o.__setitem__("x", {k + " " * 900: v for k, v in many.items()})),
+              variant(lambda o: o.__setitem__("x", {"column_witness_%d" % k: [k] * 40 for k in range(45)})),
+              variant(lambda o: o.__setitem__("x", {"proof_of_work_%d" % k: k for k in range(3)}))]
     recs, outcome = ver.read_stwo_texts(cfg, texts, B.TEXT_JSON_MINIMAL)
     taken = 0
     for k, text in enumerate(texts):

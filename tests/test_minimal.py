@@ -380,3 +380,4 @@ def test_minimal_text_gpu_rule_equals_the_host_reader(i):
     # a landmark's name somewhere else, another member order: the host reader's
     assert not check(variant(lambda o: o.__setitem__("hash_witness", [])))
     assert not check(json.dumps(dict(reversed(list(obj.items())))).encode())
+    assert not check(variant(lambda o: o.__setitem__("x", {"hash_witness_%d" % k: k for k in range(50)})))  # more than the table holds
