@@ -8,7 +8,8 @@ PoW bits, hash family) the GPU prover makes a proof; the valid proof and seeded 
 (tools/fuzz_parity.mutate_stwo) must get the oracle's status word from the GPU verifier in both
 modes, with the pair memoisation on and off.  Since round 4 the same batch also goes through the SHARED forms (every
 distinct Merkle sibling once): as shared records through ss_stwo_verify_shared_records and, the honest proof, as
-shared-path proof.json through the GPU reader -- the status words of the per-query form."""
+shared-path proof.json through the GPU reader -- the status words of the per-query form.  Since round 5 also through the
+MINIMAL forms: minimal records against the oracle's walk, and their minimal proof.json texts through the GPU reader."""
 import json
 import os
 import sys
@@ -72,6 +73,27 @@ for i in range(shapes):
         m += 1
     if m:
         print("MISMATCH (shared forms)", kw, m, flush=True)
+        bad += m
+    # the MINIMAL forms (round 5): the batch's records that have one through ss_stwo_verify_minimal_records against the
+    # oracle's walk, and as minimal proof.json through the GPU reader (template of the full-length text, landmarks, gaps:
+    # every shape has its own) -- the same status words, none of the writers' texts left to the host readers
+    minimal, mwant = [], []
+    for p in batch:
+        try:
+            minimal.append(verifier.stwo_minimise_record(proof.cfg, verifier.stwo_record(p), qs))
+            mwant.append(O.stwo_verify_minimal(proof.cfg, minimal[-1], verifier.MODE_FIXTURE))
+        except ValueError:
+            pass
+    got = ver.verify_stwo_minimal_records(proof.cfg, minimal, verifier.MODE_FIXTURE)
+    m = int((got != np.array(mwant, dtype=np.uint32)).sum())
+    texts = [verifier.write_stwo_minimal_text(proof.cfg, r, python_separators=bool(k & 1)) for k, r in enumerate(minimal)]
+    st, stats = ver.verify_stwo_minimal_texts(proof.cfg, texts)
+    host = sum(1 for t in texts if not verifier.stwo_minimal_text_is_canonical(proof.cfg, t)[0])
+    if st.tolist() != mwant or stats["host_parsed"] != host or mwant[0] != 0 or host > len(texts) // 2:
+        print("MINIMAL TEXT", kw, int((st != np.array(mwant, dtype=np.uint32)).sum()), stats["host_parsed"], host, flush=True)
+        m += 1
+    if m:
+        print("MISMATCH (minimal forms)", kw, m, flush=True)
         bad += m
     if mode == verifier.MODE_LITERAL and i % 10 == 9:
         print("%d shapes done, last %s" % (i + 1, kw), flush=True)
