@@ -554,6 +554,9 @@ def main() -> None:
                          "'on' = hipGraph replay of independent slots; kernel durations for the roofline then "
                          "come from a separate pipelined pass.  'off' = the HEAD/TAIL pipeline")
     ap.add_argument("--streams", type=int, default=16, help="independent streams of --graph streams")
+    ap.add_argument("--top-checks", action="store_true",
+                    help="SS_FLAG_TOP_CHECKS: the pair memoisation's byte compares run in the top kernel (the round-3 split); "
+                         "less HBM traffic, 2.5 %% more time (DESIGN.md 5)")
     ap.add_argument("--no-dedup", action="store_true",
                     help="SS_FLAG_NO_DEDUP: hash every query's Merkle path in full (A/B of the pair memoisation)")
     args = ap.parse_args()
@@ -608,6 +611,8 @@ def main() -> None:
     ver = verifier.Verifier(dev_index)
     if args.no_dedup:
         ver.stwo_flags = verifier.FLAG_NO_DEDUP
+    if args.top_checks:  # the memoisation's byte compares in the top kernel instead of lane against lane in the merkle kernel
+        ver.stwo_flags = verifier.FLAG_TOP_CHECKS
 
     if family == "stwo" and args.distinct > len(proofs) and wname != "stwo_fixture":
         # More distinct valid proofs of the same configuration, made on this GPU by the prover
