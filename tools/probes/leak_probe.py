@@ -1,6 +1,7 @@
 """Do repeated calls of the host-buffer entry points leak?  Device memory (hipMemGetInfo through torch) and the
 process's resident set after every 50 calls of each of: ss_stwo_verify_texts (json, wit, shared json, mixed with
-non-canonical texts), ss_stwo_verify_records, ss_stwo_verify_shared_records, across three configs (template cache).
+non-canonical texts; since round 5 the minimal proof.json too), ss_stwo_verify_records, ss_stwo_verify_shared_records,
+ss_stwo_verify_minimal_records, across three configs (template cache).
     python tools/probes/leak_probe.py [rounds]     (run on a GPU box)"""
 import json
 import os
@@ -33,18 +34,27 @@ def main() -> None:
         cfg = proofs[0].cfg
         js = [json.dumps(ss.stwo_to_json(p), separators=(",", ":")).encode() for p in proofs]
         nc = [json.dumps(dict(reversed(list(ss.stwo_to_json(p).items())))).encode() for p in proofs[:1]]  # other member order: host reader
+        from stark_symphony_amd import formats
+        mins = [verifier.stwo_minimise_record(cfg, verifier.stwo_record(p), formats.stwo_queries(p)) for p in proofs]
+        mtexts = [verifier.write_stwo_minimal_text(cfg, m, python_separators=False) for m in mins]
+        mobj = formats.stwo_minimal_to_json(formats.stwo_minimise(proofs[0]))
+        mtexts = mtexts * 8 + [json.dumps(dict(reversed(list(mobj.items())))).encode()]  # (one for the host readers)
         sets.append((cfg, {"json": js * 8 + nc, "wit": [ss.stwo_to_wit(p).encode() for p in proofs] * 8,
-                           "shared": [json.dumps(ss.stwo_to_json(p, shared=True), separators=(",", ":")).encode() for p in proofs] * 8},
-                     np.stack([verifier.stwo_record(p) for p in proofs] * 16), [verifier.stwo_shared_record(p) for p in proofs] * 16))
+                           "shared": [json.dumps(ss.stwo_to_json(p, shared=True), separators=(",", ":")).encode() for p in proofs] * 8,
+                           "minimal": mtexts},
+                     np.stack([verifier.stwo_record(p) for p in proofs] * 16), [verifier.stwo_shared_record(p) for p in proofs] * 16,
+                     mins * 16))
     base = None
     for r in range(rounds):
-        for cfg, texts, recs, shared in sets:
+        for cfg, texts, recs, shared, mins in sets:
             for _ in range(50 // len(sets) + 1):
-                for kind, fmt in (("json", binding.TEXT_AUTO), ("wit", binding.TEXT_WIT), ("shared", binding.TEXT_AUTO)):
+                for kind, fmt in (("json", binding.TEXT_AUTO), ("wit", binding.TEXT_WIT), ("shared", binding.TEXT_AUTO),
+                                  ("minimal", binding.TEXT_JSON_MINIMAL)):
                     st, _ = ver.verify_stwo_texts(cfg, texts[kind], fmt=fmt)
                     assert (st == 0).all(), (kind, st)
                 assert (ver.verify_stwo_records(cfg, recs) == 0).all()
                 assert (ver.verify_stwo_shared_records(cfg, shared) == 0).all()
+                assert (ver.verify_stwo_minimal_records(cfg, mins) == 0).all()
         torch.cuda.synchronize()
         free, total = torch.cuda.mem_get_info()
         used = (total - free) / 2**20
