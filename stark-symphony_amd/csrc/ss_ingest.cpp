@@ -1288,14 +1288,15 @@ struct MinScan {
         return true;
     }
     bool peek(char c) { ws(); return p < end && *p == c; }
-    bool key(const char *k)  // "k" :
+    bool str(const char *v)  // "v"
     {
         ws();
-        const size_t n = strlen(k);
-        if ((size_t)(end - p) < n + 2 || p[0] != '"' || memcmp(p + 1, k, n) != 0 || p[n + 1] != '"') return false;
+        const size_t n = strlen(v);
+        if ((size_t)(end - p) < n + 2 || p[0] != '"' || memcmp(p + 1, v, n) != 0 || p[n + 1] != '"') return false;
         p += n + 2;
-        return ch(':');
+        return true;
     }
+    bool key(const char *k) { return str(k) && ch(':'); }  // "k" :
     // a plain JSON integer <= max: digits only, no leading zero, nothing of a fraction or exponent behind it
     bool num(uint64_t max, uint64_t &v)
     {
@@ -1396,12 +1397,7 @@ bool stwo_min_stream(const ss_stwo_cfg &cfg, const char *text, size_t len, std::
     bool ok = s.ch('{') && s.key("config") && s.ch('{') && s.key("pow_bits") && s.cst(bits) && s.ch(',') && s.key("fri_config") &&
               s.ch('{') && s.key("log_blowup_factor") && s.cst(cfg.lde_log - cfg.trace_log) && s.ch(',') &&
               s.key("log_last_layer_degree_bound") && s.cst(0) && s.ch(',') && s.key("n_queries") && s.cst(Q) && s.ch('}');
-    if (ok && cfg.hash == SS_HASH_BLAKE2S) {
-        s.ws();
-        static const char kB2s[] = "\"blake2s\"";
-        ok = s.ch(',') && s.key("hash") && (s.ws(), (size_t)(s.end - s.p) >= sizeof kB2s - 1) && memcmp(s.p, kB2s, sizeof kB2s - 1) == 0;
-        if (ok) s.p += sizeof kB2s - 1;
-    }
+    if (ok && cfg.hash == SS_HASH_BLAKE2S) ok = s.ch(',') && s.key("hash") && s.str("blake2s");  // (the extension member)
     ok = ok && s.ch('}') && s.ch(',') && s.key("commitments") && s.ch('[') && s.hash(head) && s.ch(',') && s.hash(head + 8) &&
          s.ch(',') && s.hash(head + 16) && s.ch(']') && s.ch(',') && s.key("sampled_values") && s.ch('[') && s.ch('[') && s.ch(']') &&
          s.ch(',') && s.ch('[');
