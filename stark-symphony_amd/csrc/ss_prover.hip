@@ -544,11 +544,35 @@ __global__ void p_hash_qm31_kernel(size_t n, const uint32_t *__restrict__ vals, 
 }
 
 template <int HF>
+__device__ __forceinline__ void merkle_parent(size_t i, const uint32_t *children, uint32_t *parents);
+
+template <int HF>
 __global__ void p_merkle_level_kernel(size_t n_parents, const uint32_t *__restrict__ children,
                                       uint32_t *__restrict__ parents)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_parents) return;
+    merkle_parent<HF>(i, children, parents);
+}
+
+// The last levels of a tree (n <= 512 nodes -> the root) by ONE block: a level with at most 256 parents is one wavefront per
+// SIMD of a CU, i.e. one pair hash of latency, which is what a launch of its own takes too -- minus the launch.  Levels above
+// stay launches: a single CU hashes them slower than the chip does.  levels: the n nodes, then their parents...
+template <int HF>
+__global__ void __launch_bounds__(256) p_merkle_tail_kernel(uint32_t n, uint32_t *levels)
+{
+    uint32_t off = 0;
+    for (uint32_t cur = n; cur > 1; cur >>= 1) {
+        if (threadIdx.x < (cur >> 1)) merkle_parent<HF>(threadIdx.x, levels + (size_t)off * 8, levels + (size_t)(off + cur) * 8);
+        off += cur;
+        __threadfence_block();
+        __syncthreads();  // (the level just written is read by other wavefronts of this block next)
+    }
+}
+
+template <int HF>
+__device__ __forceinline__ void merkle_parent(size_t i, const uint32_t *children, uint32_t *parents)
+{
     const uint4 *c = reinterpret_cast<const uint4 *>(children + i * 16);
     const uint4 a0 = c[0], a1 = c[1], b0 = c[2], b1 = c[3];
     const uint32_t l[8] = {Hasher<HF>::native(a0.x), Hasher<HF>::native(a0.y), Hasher<HF>::native(a0.z),
@@ -944,6 +968,11 @@ extern "C" int ss_p_merkle(ss_ctx *ctx, uint32_t hash, size_t n_leaves, uint32_t
         return ss_internal_set_err(SS_ERR_ARG, "ss_p_merkle: bad argument");
     size_t off = 0;
     for (size_t n = n_leaves; n > 1; n >>= 1) {
+        if (n <= 512) {  // the rest of the tree in one launch
+            if (hash) hipLaunchKernelGGL(p_merkle_tail_kernel<1>, dim3(1), dim3(256), 0, (hipStream_t)stream, (uint32_t)n, levels + off * 8);
+            else hipLaunchKernelGGL(p_merkle_tail_kernel<0>, dim3(1), dim3(256), 0, (hipStream_t)stream, (uint32_t)n, levels + off * 8);
+            break;
+        }
         const size_t parents = n >> 1;
         uint32_t *children = levels + off * 8, *out = levels + (off + n) * 8;
         if (hash)
