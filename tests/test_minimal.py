@@ -468,5 +468,29 @@ def test_minimal_walk_against_an_independent_python_restatement(i):
             if top != bytes(root):
                 seen.add("root")
                 assert st != 0
+        # FriLayerVerifier::extract_evaluation (crates/prover/src/core/fri.rs), the order only: the layer's queries grouped
+        # by fold pair, pairs ascending, and inside a pair a member that is not queried itself takes the NEXT of the proof's
+        # evals -- so query q's partner at layer l is eval number k of fri_witness[l] exactly where R(M) holds that eval
+        # (partners that another query produces are computed values: field arithmetic, not restated here)
+        fo = head + Q * qstride
+        for l in range(K + 1):
+            stride = 4 + 8 * (L - 1 - l)
+            if int(back[tbase + (2 + l) * Q]) == 0:  # (this layer's lists do not have the queries' lengths)
+                fo += Q * stride
+                continue
+            members = sorted({x >> l for x in qs})
+            present, k, taken = set(members), 0, {}
+            for pair in sorted({x >> 1 for x in members}):
+                for mem in (2 * pair, 2 * pair + 1):
+                    if mem not in present:
+                        taken[mem ^ 1] = k  # the queried member mem ^ 1 gets eval k as its partner
+                        k += 1
+            assert k == len(mp.fri_witness[l])
+            for q in range(Q):
+                x = qs[q] >> l
+                if x in taken:
+                    assert np.array_equal(back[fo + q * stride:fo + q * stride + 4], mp.fri_witness[l][taken[x]]), (l, q)
+                    seen.add("eval")
+            fo += Q * stride
     # (with one query a list one hash longer is more than the config allows: malformed before any walk)
-    assert ({"ok", "short", "long"} if Q > 1 else {"ok", "short"}) <= seen
+    assert ({"ok", "short", "long", "eval"} if Q > 1 else {"ok", "short", "eval"}) <= seen
