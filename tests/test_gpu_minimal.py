@@ -364,3 +364,18 @@ def test_minimal_texts_through_the_gpu_reader_give_the_records_verdicts(ver, tmp
     assert got4.tolist() == want[-12:] + [2]
     auto, _ = ver.verify_stwo_texts(cfg, texts[:2])  # (read as a per-query proof.json: its lists are too short for that form)
     assert (auto != 0).all()
+
+
+def test_committed_minimal_texts_are_accepted_on_the_gpu(ver):
+    """tests/golden/formats/*.minimal.json (the reference's two proofs in the minimal form, as this repository's writers
+    print it; tests/test_minimal.py holds writers and readers to those bytes): read by the GPU reader, accepted."""
+    import json
+    from stark_symphony_amd import binding as B
+    golden = os.path.join(ROOT, "tests", "golden")
+    for name in ("stwo_proof", "stwo_proof_test"):
+        text = open(os.path.join(golden, "formats", name + ".minimal.json"), "rb").read()
+        cfg = ss.stwo_from_json(json.load(open(os.path.join(golden, name + ".json")))).cfg
+        st, stats = ver.verify_stwo_texts(cfg, [text, text], fmt=B.TEXT_JSON_MINIMAL)
+        assert st.tolist() == [0, 0] and stats["host_parsed"] == 0
+        assert ver.verify_stwo_texts(cfg, [text], mode=verifier.MODE_LITERAL, fmt=B.TEXT_JSON_MINIMAL)[0].tolist() == \
+            [O.stwo_verify_minimal(cfg, verifier.parse_stwo_minimal_text(cfg, text)[1], verifier.MODE_LITERAL)]

@@ -494,3 +494,25 @@ def test_minimal_walk_against_an_independent_python_restatement(i):
             fo += Q * stride
     # (with one query a list one hash longer is more than the config allows: malformed before any walk)
     assert ({"ok", "short", "long", "eval"} if Q > 1 else {"ok", "short", "eval"}) <= seen
+
+
+@pytest.mark.parametrize("name", ["stwo_proof", "stwo_proof_test"])
+def test_committed_minimal_texts(name):
+    """tests/golden/formats/*.minimal.json (made by tests/golden/make_minimal_golden.py from the reference's two proofs):
+    the Python writer and the native writer still print those bytes, both host readers and the scalar rule of the GPU
+    reader read them to the record the per-query proof minimises to, and the checker accepts that record."""
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    text = open(os.path.join(golden, "formats", name + ".minimal.json"), "rb").read()
+    with open(os.path.join(golden, name + ".json")) as f:
+        p = ss.stwo_from_json(json.load(f))
+    cfg = p.cfg
+    m = formats.stwo_minimise(p)
+    rec = verifier.stwo_minimal_record(m)
+    assert json.dumps(formats.stwo_minimal_to_json(m), separators=(",", ":")).encode() == text
+    assert verifier.write_stwo_minimal_text(cfg, rec, python_separators=False) == text
+    for reader in (verifier.READER_STREAM, verifier.READER_GENERAL):
+        rc, got = verifier.parse_stwo_minimal_text(cfg, text, reader=reader)
+        assert rc == 0 and np.array_equal(got, rec)
+    taken, got = verifier.stwo_minimal_text_is_canonical(cfg, text)
+    assert taken and np.array_equal(got, rec)
+    assert O.stwo_verify_minimal(cfg, rec, 1) == 0
