@@ -222,7 +222,12 @@ int ss_stwo_minimise_record(const ss_stwo_cfg *cfg, const uint32_t *record, cons
  * (ss_*_verify_batch_dev / _phase_dev, ss_stwo_pack_dev) take caller-owned buffers and a caller-owned
  * stream and run concurrently from any number of threads (the timing list has its own lock); what they
  * require is the usual HIP rule that the buffers of two in-flight calls are distinct.  Functions
- * without a context (sizes, packers, parsers, writers) are pure.                          */
+ * without a context (sizes, packers, parsers, writers) are pure.
+ * Process environment.  When the library is LOADED it puts GPU_MAX_HW_QUEUES=24 into the process environment unless the
+ * variable is already set or SS_KEEP_ENV is (csrc/ss_env.cpp): the HIP runtime reads it when it initialises -- at the
+ * process's first HIP call -- and its default of 4 hardware queues serialises streams that share one, which is what the
+ * pipelined entry points and every caller that keeps several passes in flight on streams of its own must avoid
+ * (stark101 x 4 096, 16 passes in flight: 40.9 M proofs/s at the default, 63.7 M with 24).                            */
 typedef struct ss_ctx ss_ctx;
 int ss_ctx_create(int device, ss_ctx **out);
 void ss_ctx_destroy(ss_ctx *ctx);

@@ -12,6 +12,13 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libss_verify.so")
 
+# The process default the library itself sets when it is loaded (csrc/ss_env.cpp: streams that share one of the runtime's 4
+# default hardware queues serialise, which is what the pipelines here exist to avoid) -- set at import already, because this
+# module loads the library lazily and the HIP runtime reads the variable when it initialises (torch's first CUDA call).
+# A value the caller has set wins; SS_KEEP_ENV=1 leaves the environment alone.
+if "SS_KEEP_ENV" not in os.environ:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+
 SS_OK, SS_ERR_ARG, SS_ERR_HIP, SS_ERR_NO_DEVICE, SS_ERR_WORKSPACE, SS_ERR_NOMEM = 0, -1, -2, -3, -4, -5
 MODE_LITERAL, MODE_FIXTURE = 0, 1
 

@@ -531,3 +531,27 @@ def test_bench_uses_counter_profiles_only_for_the_sources_they_were_taken_on(tmp
     monkeypatch.undo()
     t, i, src = bench.pmc_profile("stwo_2p20", 65536)
     assert (t and i and "the ones in this tree" in src) or (t is None and i is None and "other kernel sources" in src), src
+
+
+def test_the_library_sets_its_process_default_when_it_is_loaded():
+    """csrc/ss_env.cpp: loading libss_verify.so puts GPU_MAX_HW_QUEUES=24 into the process environment (the HIP runtime
+    reads it when it initialises, at the first HIP call: tools/probes/hw_queues_probe.hip measures that a program linking
+    the library gets the 16-stream rate without knowing the variable); a value the caller has set wins; SS_KEEP_ENV=1
+    switches it off.  The Python binding does the same when it is imported (it loads the library lazily)."""
+    import subprocess
+    import sys
+    from stark_symphony_amd import binding as B
+    child = ("import ctypes, os, sys\n"
+             "ctypes.CDLL(%r)\n"
+             "libc = ctypes.CDLL(None)\n"
+             "libc.getenv.restype = ctypes.c_char_p\n"
+             "print(libc.getenv(b'GPU_MAX_HW_QUEUES'))\n" % B.LIB_PATH)
+    base = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "SS_KEEP_ENV")}
+
+    def run(extra, code=child):
+        return subprocess.run([sys.executable, "-c", code], env={**base, **extra}, capture_output=True, text=True).stdout.strip()
+    assert run({}) == "b'24'"
+    assert run({"GPU_MAX_HW_QUEUES": "8"}) == "b'8'"
+    assert run({"SS_KEEP_ENV": "1"}) == "None"
+    pkg = "import sys, os\nsys.path.insert(0, %r)\nfrom stark_symphony_amd import verifier\nprint(os.environ.get('GPU_MAX_HW_QUEUES'))\n" % ROOT
+    assert run({}, pkg) == "24" and run({"SS_KEEP_ENV": "1"}, pkg) == "None" and run({"GPU_MAX_HW_QUEUES": "6"}, pkg) == "6"
