@@ -796,8 +796,10 @@ int stwo_read_texts_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char 
     args.mhints = min_fmt ? (MinHint *)hint.p : nullptr;
     args.shared_records = (uint32_t *)shrec.p;
     const size_t wcap = ((size_t)n_windows + 4) & ~(size_t)3;
+    // (the fill on the stream the reader runs on: hipMemset on the null stream is asynchronous to the host and tp.cx does not
+    // wait for the null stream -- with more hardware queues than streams the fill overtook the reader's stores)
     if (hipMemcpy(text.p, host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(rec.p, c ? 0xee : 0, n * W * 4) != hipSuccess)  // (stark101 records have zero padding the reader leaves alone)
+        hipMemsetAsync(rec.p, c ? 0xee : 0, n * W * 4, tp.cx) != hipSuccess)  // (stark101 records have zero padding the reader leaves alone)
         return done(set_err(SS_ERR_HIP, "upload failed"));
     const uint8_t *dev = (const uint8_t *)text.p;
     args.texts = dev;
