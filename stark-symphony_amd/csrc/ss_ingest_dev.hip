@@ -131,6 +131,7 @@ int template_of(ss_ctx *ctx, const ss_stwo_cfg &cfg, int fmt, hipStream_t s, Tex
             HIP_TRY(hipMemcpy(d.trailer, h.trailer.data(), h.trailer.size() * 4, hipMemcpyHostToDevice));
         if (!h.fixed.empty())
             HIP_TRY(hipMemcpy((uint32_t *)d.trailer + h.trailer.size(), h.fixed.data(), h.fixed.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipDeviceSynchronize());  // (once per template: its readers run on streams that do not wait for the null stream)
         d.view = h.view();
         d.view.skel = (const uint8_t *)d.skel;
         d.view.slots = (const TextSlot *)d.slots;
