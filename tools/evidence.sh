@@ -4,10 +4,10 @@
 #
 #   gpurun --timeout 1200 -- 'bash tools/evidence.sh r04 [section ...]'      then here:  python tools/profiles.py r04
 #
-# sections (default: all): bench configs stats pmc e2e host sha prover fuzz
+# sections (default: all): bench configs stats pmc e2e host sha prover fuzz queues
 # Output: gpurun_out/<tag>/ (scratch); tools/profiles.py turns it into the committed profiles/<tag>_* files.
 TAG=${1:?usage: evidence.sh <tag> [sections]}; shift
-SECTIONS=${*:-bench configs stats pmc e2e host sha prover fuzz}
+SECTIONS=${*:-bench configs stats pmc e2e host sha prover fuzz queues}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
 want() { [[ " $SECTIONS " == *" $1 "* ]]; }
@@ -44,6 +44,17 @@ if want host; then
     python tools/host_path_bench.py $n >> $O/host_path.txt 2>&1
     python tools/host_path_bench.py $n distinct >> $O/host_path.txt 2>&1
   done
+fi
+if want queues; then  # the library's load-time default of GPU_MAX_HW_QUEUES, from a C++ program that links it (csrc/ss_env.cpp)
+  mkdir -p build
+  /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 -Iinclude tools/probes/hw_queues_probe.hip -o build/hw_queues_probe -Lstark-symphony_amd -lss_verify -Wl,-rpath,$R/stark-symphony_amd 2>/dev/null
+  P="build/hw_queues_probe tests/golden/stark101_proof.json"
+  ( unset GPU_MAX_HW_QUEUES
+    for i in 1 2; do
+      echo -n "default (library sets it):        "; $P 2>&1 | grep -v amdgpu.ids
+      echo -n "SS_KEEP_ENV=1 (runtime default):  "; SS_KEEP_ENV=1 $P 2>&1 | grep -v amdgpu.ids
+      echo -n "caller sets GPU_MAX_HW_QUEUES=24: "; GPU_MAX_HW_QUEUES=24 $P 2>&1 | grep -v amdgpu.ids
+    done ) > $O/hw_queues.txt 2>&1; ok queues
 fi
 if want e2e; then
   python tools/e2e_bench.py --n 4096 --reps 4 --fmt all --files > $O/e2e_4096.json 2> $O/e2e.err; ok e2e
