@@ -195,9 +195,9 @@ long read_into(const char *path, uint8_t *dst, size_t cap)
 // What differs between the proof families behind the one pipeline.
 struct Family {
     size_t W = 0;                 // words of a record on the device
-    TextTemplate tmpl[4];         // device views: proof.json, proof.wit, shared-path proof.json (stwo only), minimal proof.json
-    SharedTextInfo sinfo{};       // of tmpl[2]
-    MinTextInfo minfo{};          // of tmpl[3]
+    TextTemplate tmpl[4];         // device views by kTextJson / kTextWit / kTextShared / kTextMinimal (the last two: stwo only)
+    SharedTextInfo sinfo{};       // of tmpl[kTextShared]
+    MinTextInfo minfo{};          // of tmpl[kTextMinimal]
     bool minimal = false;         // every text is a minimal proof.json (format 3): records are capacity-form minimal records
     const ss_stwo_cfg *shared_cfg = nullptr;  // not null: shared-path texts are read and expanded on the GPU
     const char *wit_key = "";     // the member name a .wit starts with (format sniffing for the GPU reader's first guess)
@@ -239,16 +239,16 @@ static int ingest_pipeline(ss_ctx *ctx, const Family &F, size_t n, const char *c
     int rc;
     const size_t W = F.W;
     TextParseArgs args{};
-    args.tmpl[0] = F.tmpl[0];
-    args.tmpl[1] = F.tmpl[1];
-    args.tmpl[2] = F.tmpl[2];
-    args.tmpl[3] = F.tmpl[3];
+    args.tmpl[kTextJson] = F.tmpl[kTextJson];
+    args.tmpl[kTextWit] = F.tmpl[kTextWit];
+    args.tmpl[kTextShared] = F.tmpl[kTextShared];
+    args.tmpl[kTextMinimal] = F.tmpl[kTextMinimal];
     args.sinfo = F.sinfo;
     args.minfo = F.minfo;
-    const bool min_ok = F.minimal && F.tmpl[3].skel;
+    const bool min_ok = F.minimal && F.tmpl[kTextMinimal].skel;
     args.record_words = (uint32_t)W;
-    const bool shared_ok = F.shared_cfg && F.tmpl[2].skel;
-    const size_t SW = shared_ok ? F.tmpl[2].record_words : 0;  // words of a capacity-form shared record
+    const bool shared_ok = F.shared_cfg && F.tmpl[kTextShared].skel;
+    const size_t SW = shared_ok ? F.tmpl[kTextShared].record_words : 0;  // words of a capacity-form shared record
     const unsigned threads = effective_cpus();
     // staging is a copy: a few threads saturate it, and the thread that drives the GPU needs a core too
     unsigned stage_threads = std::max(1u, std::min(threads > 1 ? threads - 1 : 1u, 8u));
@@ -367,21 +367,22 @@ static int ingest_pipeline(ss_ctx *ctx, const Family &F, size_t n, const char *c
             lens32[i] = len;
             // which template to try: a .wit is a JSON object whose first member is COMMITMENTS / P_MT_ROOT.  A wrong
             // guess only costs the fast path -- the host reader sniffs for itself.
-            uint8_t f = fmt == SS_TEXT_WIT;
+            uint32_t f = fmt == SS_TEXT_WIT ? kTextWit : kTextJson;
             if (fmt == SS_TEXT_AUTO) {
                 const size_t look = len < 64 ? len : 64;
                 const size_t kl = strlen(F.wit_key);
-                for (size_t p = 0; p + kl <= look && !f; p++) f = memcmp(dst + p, F.wit_key, kl) == 0;
+                for (size_t p = 0; p + kl <= look && f == kTextJson; p++)
+                    if (memcmp(dst + p, F.wit_key, kl) == 0) f = kTextWit;
             }
             // ... and a shared-path proof.json ends with its "queries" member (at most 64 short numbers: the last KiB)
-            if (shared_ok && !f && fmt != SS_TEXT_WIT) {
-                if (fmt == SS_TEXT_JSON_SHARED) f = 2;
+            if (shared_ok && f == kTextJson && fmt != SS_TEXT_WIT) {
+                if (fmt == SS_TEXT_JSON_SHARED) f = kTextShared;
                 else {
                     const size_t look = len < 1024 ? len : 1024;
-                    if (look >= 9 && memmem(dst + (len - look), look, "\"queries\"", 9)) f = 2;
+                    if (look >= 9 && memmem(dst + (len - look), look, "\"queries\"", 9)) f = kTextShared;
                 }
             }
-            fmts[i] = F.minimal ? 3 : f;
+            fmts[i] = (uint8_t)(F.minimal ? kTextMinimal : f);
         }, stage_threads);
         uint32_t n_windows = 0;  // (after the reads: a file may have shrunk since its stat)
         for (size_t i = 0; i < ch.cnt; i++) {
@@ -570,9 +571,9 @@ int stwo_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char *con
     if ((rc = ensure_streams(ctx->tp))) return rc;
     Family F;
     F.W = ss_stwo_record_words(c);
-    if ((rc = template_of(ctx, *c, SS_TEXT_JSON, ctx->tp.cx, F.tmpl[0]))) return rc;
-    if ((rc = template_of(ctx, *c, SS_TEXT_WIT, ctx->tp.cx, F.tmpl[1]))) return rc;
-    if ((rc = template_of(ctx, *c, SS_TEXT_JSON_SHARED, ctx->tp.cx, F.tmpl[2], &F.sinfo))) return rc;
+    if ((rc = template_of(ctx, *c, SS_TEXT_JSON, ctx->tp.cx, F.tmpl[kTextJson]))) return rc;
+    if ((rc = template_of(ctx, *c, SS_TEXT_WIT, ctx->tp.cx, F.tmpl[kTextWit]))) return rc;
+    if ((rc = template_of(ctx, *c, SS_TEXT_JSON_SHARED, ctx->tp.cx, F.tmpl[kTextShared], &F.sinfo))) return rc;
     F.wit_key = "\"COMMITMENTS\"";
     const ss_stwo_cfg cv = *c;
     F.shared_cfg = &cv;
@@ -623,7 +624,7 @@ int stwo_minimal_ingest_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const c
     F.W = ss_stwo_minimal_max_words(c);
     {
         SharedTextInfo unused;
-        if ((rc = template_of(ctx, *c, SS_TEXT_JSON_MINIMAL, ctx->tp.cx, F.tmpl[3], &unused, &F.minfo))) return rc;
+        if ((rc = template_of(ctx, *c, SS_TEXT_JSON_MINIMAL, ctx->tp.cx, F.tmpl[kTextMinimal], &unused, &F.minfo))) return rc;
     }
     const ss_stwo_cfg cv = *c;
     const size_t W = F.W;
@@ -673,8 +674,8 @@ int s101_ingest_dev(ss_ctx *ctx, size_t n, const char *const *texts, const size_
     Family F;
     const ss_s101_shape sh = {kS101Layers, kS101Path};
     F.W = ss_s101_record_words(&sh);
-    if ((rc = template_of(ctx, key, SS_TEXT_JSON, ctx->tp.cx, F.tmpl[0]))) return rc;
-    if ((rc = template_of(ctx, key, SS_TEXT_WIT, ctx->tp.cx, F.tmpl[1]))) return rc;
+    if ((rc = template_of(ctx, key, SS_TEXT_JSON, ctx->tp.cx, F.tmpl[kTextJson]))) return rc;
+    if ((rc = template_of(ctx, key, SS_TEXT_WIT, ctx->tp.cx, F.tmpl[kTextWit]))) return rc;
     F.wit_key = "\"P_MT_ROOT\"";
     F.zero_records = true;
     std::vector<S101Parsed *> deferred(n, nullptr);
@@ -751,14 +752,14 @@ int stwo_read_texts_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char 
     const ss_s101_shape sh = {kS101Layers, kS101Path};
     const size_t W = min_fmt ? ss_stwo_minimal_max_words(c) : c ? ss_stwo_record_words(c) : ss_s101_record_words(&sh);
     TextParseArgs args{};
-    if ((rc = template_of(ctx, c ? *c : key, SS_TEXT_JSON, tp.cx, args.tmpl[0]))) return rc;
-    if ((rc = template_of(ctx, c ? *c : key, SS_TEXT_WIT, tp.cx, args.tmpl[1]))) return rc;
-    if (sh_fmt && (rc = template_of(ctx, *c, SS_TEXT_JSON_SHARED, tp.cx, args.tmpl[2], &args.sinfo))) return rc;
-    if (sh_fmt && !args.tmpl[2].skel) return set_err(SS_ERR_ARG, "no shared-path text exists for this config");
+    if ((rc = template_of(ctx, c ? *c : key, SS_TEXT_JSON, tp.cx, args.tmpl[kTextJson]))) return rc;
+    if ((rc = template_of(ctx, c ? *c : key, SS_TEXT_WIT, tp.cx, args.tmpl[kTextWit]))) return rc;
+    if (sh_fmt && (rc = template_of(ctx, *c, SS_TEXT_JSON_SHARED, tp.cx, args.tmpl[kTextShared], &args.sinfo))) return rc;
+    if (sh_fmt && !args.tmpl[kTextShared].skel) return set_err(SS_ERR_ARG, "no shared-path text exists for this config");
     if (min_fmt) {
         SharedTextInfo unused;
-        if ((rc = template_of(ctx, *c, SS_TEXT_JSON_MINIMAL, tp.cx, args.tmpl[3], &unused, &args.minfo))) return rc;
-        if (!args.tmpl[3].skel) return set_err(SS_ERR_ARG, "no minimal proof.json exists for this config");
+        if ((rc = template_of(ctx, *c, SS_TEXT_JSON_MINIMAL, tp.cx, args.tmpl[kTextMinimal], &unused, &args.minfo))) return rc;
+        if (!args.tmpl[kTextMinimal].skel) return set_err(SS_ERR_ARG, "no minimal proof.json exists for this config");
     }
     args.record_words = (uint32_t)W;
     auto aligned = [](size_t v) { return (v + 15) & ~(size_t)15; };
@@ -782,7 +783,7 @@ int stwo_read_texts_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char 
         l32[i] = (uint32_t)lens[i];
         wb[i] = n_windows;
         n_windows += (uint32_t)((lens[i] + 1023) >> 10);
-        f8[i] = min_fmt ? 3 : sh_fmt ? 2 : fmt == SS_TEXT_WIT;
+        f8[i] = (uint8_t)(min_fmt ? kTextMinimal : sh_fmt ? kTextShared : fmt == SS_TEXT_WIT ? kTextWit : kTextJson);
     }
     wb[n] = n_windows;
     GrowBuf text, rec, out, win, shrec, hint;
@@ -790,7 +791,7 @@ int stwo_read_texts_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char 
     if ((rc = grow(text, bytes, false)) || (rc = grow(rec, n * W * 4, false)) || (rc = grow(out, n * 4, false)) ||
         (rc = grow(win, (size_t)(n_windows + 4) * (4 + sizeof(WinSum) + sizeof(WinIn)), false)))
         return done(rc);
-    if (sh_fmt && ((rc = grow(shrec, n * (size_t)args.tmpl[2].record_words * 4, false)) || (rc = grow(hint, n * sizeof(TextHint), false))))
+    if (sh_fmt && ((rc = grow(shrec, n * (size_t)args.tmpl[kTextShared].record_words * 4, false)) || (rc = grow(hint, n * sizeof(TextHint), false))))
         return done(rc);
     if (min_fmt && (rc = grow(hint, n * sizeof(MinHint), false))) return done(rc);
     args.hints = sh_fmt ? (TextHint *)hint.p : nullptr;
@@ -816,7 +817,7 @@ int stwo_read_texts_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_t n, const char 
     args.n = (uint32_t)n;
     args.n_windows = n_windows;
     launch_text_parse(args, tp.cx);
-    if (sh_fmt && (rc = shared_expand_launch(ctx, c, n, args.shared_records, nullptr, args.tmpl[2].record_words, args.records,
+    if (sh_fmt && (rc = shared_expand_launch(ctx, c, n, args.shared_records, nullptr, args.tmpl[kTextShared].record_words, args.records,
                                              args.outcome, tp.cx, args.fmt, args.hints->pos, (uint32_t)(sizeof(TextHint) / 4))))
         return done(rc);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(tp.cx) != hipSuccess ||

@@ -29,6 +29,9 @@ struct MinHint {
     uint32_t lm[3][kMaxLandmarks];     // numbers in front of each landmark, in any order
 };
 
+// which template a text is read against (TextParseArgs::fmt / ::tmpl)
+enum : uint32_t { kTextJson = 0, kTextWit = 1, kTextShared = 2, kTextMinimal = 3 };
+
 struct TextParseArgs {
     const uint8_t *texts;      // the chunk's texts, each starting at a 16-byte aligned offset; >= kTextSlack readable bytes behind the last
     const uint64_t *offs;      // [n] byte offset of text i in `texts`

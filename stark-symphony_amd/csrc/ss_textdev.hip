@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(64) text_index_kernel(TextParseArgs a)
     const uint32_t t = blockIdx.x;
     if (t >= a.n) return;
     for (uint32_t w = a.win_base[t] + threadIdx.x; w < a.win_base[t + 1]; w += 64) a.win_text[w] = t;
-    if (a.mhints && a.fmt[t] == 3 && threadIdx.x < 3) a.mhints[t].n_lm[threadIdx.x] = 0;
+    if (a.mhints && a.fmt[t] == kTextMinimal && threadIdx.x < 3) a.mhints[t].n_lm[threadIdx.x] = 0;
 }
 
 // Format 2 only: the positions a shared-path text names (read backwards from its last KiB by one lane: <= 64 short
@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(64) text_hint_kernel(TextParseArgs a)
     __shared__ uint4 s_tail4[68];
     __shared__ uint32_t s_pos[64], s_cnt[kMaxTrees], s_ok;
     const uint32_t t = blockIdx.x, lane = threadIdx.x;
-    if (t >= a.n || a.fmt[t] != 2) return;
+    if (t >= a.n || a.fmt[t] != kTextShared) return;
     const SharedTextInfo &I = a.sinfo;
     const uint32_t len = a.lens[t];
     const uint32_t base = len > 1024 ? (len - 1024) & ~15u : 0;
@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(64) text_hint_kernel(TextParseArgs a)
     __syncthreads();
     if (lane == 0) {
         const uint32_t tail = len < 1024 ? len : 1024;
-        bool ok = a.tmpl[2].skel != nullptr && shared_text_hint(reinterpret_cast<const uint8_t *>(s_tail4) + (len - base - tail), tail, I.Q, s_pos);
+        bool ok = a.tmpl[kTextShared].skel != nullptr && shared_text_hint(reinterpret_cast<const uint8_t *>(s_tail4) + (len - base - tail), tail, I.Q, s_pos);
         for (uint32_t q = 0; q < I.Q && ok; q++) ok = (s_pos[q] >> I.L) == 0;
         s_ok = ok;
     }
@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(64) text_hint_kernel(TextParseArgs a)
         if (lane == 0) s_cnt[k] = c;
     }
     __syncthreads();
-    if (lane == 0) shared_text_gaps(I, s_cnt, a.tmpl[2].skel_len, a.tmpl[2].n_slots, h->g);
+    if (lane == 0) shared_text_gaps(I, s_cnt, a.tmpl[kTextShared].skel_len, a.tmpl[kTextShared].n_slots, h->g);
     if (q < I.Q) h->pos[q] = pos;
 }
 
@@ -247,13 +247,13 @@ __global__ void __launch_bounds__(64) text_scan_kernel(TextParseArgs a)
     if (t >= a.n) return;
     const uint32_t w0 = a.win_base[t], nwin = a.win_base[t + 1] - w0;
     const uint32_t f = a.fmt[t];
-    const bool wit = f == 1;
+    const bool wit = f == kTextWit;
     const uint8_t *skel = a.tmpl[f].skel;
     // (a shared-path text has the totals its own positions imply: text_hint_kernel)
-    const uint32_t skel_len = f == 2 ? a.hints[t].g.skel_len : a.tmpl[f].skel_len;
-    const uint32_t n_slots = f == 2 ? a.hints[t].g.n_slots : a.tmpl[f].n_slots;
+    const uint32_t skel_len = f == kTextShared ? a.hints[t].g.skel_len : a.tmpl[f].skel_len;
+    const uint32_t n_slots = f == kTextShared ? a.hints[t].g.n_slots : a.tmpl[f].n_slots;
     uint32_t carry_run = kRunNone, carry_str = 0, skel_pos = 0, tok_pos = 0;
-    bool bad = skel == nullptr || nwin == 0 || skel_len == 0xffffffffu || (f == 3 && !a.mhints);
+    bool bad = skel == nullptr || nwin == 0 || skel_len == 0xffffffffu || (f == kTextMinimal && !a.mhints);
     const uint64_t below = (1ull << lane) - 1;
     for (uint32_t g = 0; g < nwin && !bad; g += 64) {
         const uint32_t w = g + lane;
@@ -290,10 +290,10 @@ __global__ void __launch_bounds__(64) text_scan_kernel(TextParseArgs a)
     }
     // (a minimal proof.json has the totals its list lengths imply, and those are found next: text_minhint_kernel compares;
     // here the full-length template's totals are upper bounds)
-    const bool good = !bad && (f == 3 || (skel_pos == skel_len && tok_pos == n_slots)) && carry_str == 0;
-    if (f == 3 && lane == 0 && a.mhints) { a.mhints[t].seen_skel = skel_pos; a.mhints[t].seen_tok = tok_pos; }
-    if (good && f < 2) {  // the path-length trailer of a canonical text is the config's (format 2: written by the expansion)
-        const TextTemplate &T = wit ? a.tmpl[1] : a.tmpl[0];
+    const bool good = !bad && (f == kTextMinimal || (skel_pos == skel_len && tok_pos == n_slots)) && carry_str == 0;
+    if (f == kTextMinimal && lane == 0 && a.mhints) { a.mhints[t].seen_skel = skel_pos; a.mhints[t].seen_tok = tok_pos; }
+    if (good && f < kTextShared) {  // the path-length trailer of a canonical text is the config's (format 2: written by the expansion)
+        const TextTemplate &T = wit ? a.tmpl[kTextWit] : a.tmpl[kTextJson];
         uint32_t *rec = a.records + (size_t)t * a.record_words;
         for (uint32_t i = lane; i < T.n_trailer; i += 64) rec[T.tbase + i] = T.trailer[i];
         for (uint32_t i = lane; i < T.n_fixed; i += 64) rec[T.fixed[2 * i]] = T.fixed[2 * i + 1];
@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(64) text_landmark_kernel(TextParseArgs a)
     const uint32_t gw = blockIdx.x, lane = threadIdx.x;
     if (gw >= a.n_windows) return;
     const uint32_t t = a.win_text[gw];
-    if (a.fmt[t] != 3 || a.outcome[t] != 0) return;
+    if (a.fmt[t] != kTextMinimal || a.outcome[t] != 0) return;
     const uint32_t w = gw - a.win_base[t], nwin = a.win_base[t + 1] - a.win_base[t], len = a.lens[t];
     const uint4 *text4 = reinterpret_cast<const uint4 *>(a.texts + a.offs[t]);
     const WinIn in = a.win_in[gw];
@@ -361,7 +361,7 @@ __global__ void __launch_bounds__(64) text_minhint_kernel(TextParseArgs a)
 {
     __shared__ uint32_t s_lm[3][kMaxLandmarks], s_sorted[3][kMaxLandmarks], s_counts[kMaxTextLists], s_ok;
     const uint32_t t = blockIdx.x, lane = threadIdx.x;
-    if (t >= a.n || a.fmt[t] != 3 || a.outcome[t] != 0) return;
+    if (t >= a.n || a.fmt[t] != kTextMinimal || a.outcome[t] != 0) return;
     MinHint *h = a.mhints + t;
     const MinTextInfo &I = a.minfo;
     const uint32_t n_lm[3] = {h->n_lm[0], h->n_lm[1], h->n_lm[2]};
@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(64) text_minhint_kernel(TextParseArgs a)
             bool good = min_text_counts(I, s_sorted[kLmHash], n_lm[kLmHash], s_sorted[kLmColumn], n_lm[kLmColumn], s_sorted[kLmPow],
                                         n_lm[kLmPow], s_counts);
             if (good) {
-                min_text_gaps(I, s_counts, a.tmpl[3].skel_len, a.tmpl[3].n_slots, h->g);
+                min_text_gaps(I, s_counts, a.tmpl[kTextMinimal].skel_len, a.tmpl[kTextMinimal].n_slots, h->g);
                 good = h->g.skel_len == h->seen_skel && h->g.n_slots == h->seen_tok;
             }
             s_ok = good;
@@ -411,17 +411,17 @@ __global__ void __launch_bounds__(64) text_place_kernel(TextParseArgs a)
     if (a.outcome[t] != 0) return;  // the scan (or another window) has already sent this text to the host reader
     const uint32_t w = gw - a.win_base[t], nwin = a.win_base[t + 1] - a.win_base[t], len = a.lens[t];
     const uint32_t f = a.fmt[t];
-    const bool shared = f >= 2;  // a text whose lists are shorter than the template's: shared-path (2) or minimal (3) proof.json
+    const bool shared = f >= kTextShared;  // a text whose lists are shorter than the template's: shared-path (2) or minimal (3) proof.json
     const uint8_t *skel = a.tmpl[f].skel;
     const TextSlot *slots = a.tmpl[f].slots;
-    const uint32_t n_slots = f == 2 ? a.hints[t].g.n_slots : f == 3 ? a.mhints[t].g.n_slots : a.tmpl[f].n_slots;
-    uint32_t *rec = f == 2 ? a.shared_records + (size_t)t * a.tmpl[2].record_words : a.records + (size_t)t * a.record_words;
+    const uint32_t n_slots = f == kTextShared ? a.hints[t].g.n_slots : f == kTextMinimal ? a.mhints[t].g.n_slots : a.tmpl[f].n_slots;
+    uint32_t *rec = f == kTextShared ? a.shared_records + (size_t)t * a.tmpl[kTextShared].record_words : a.records + (size_t)t * a.record_words;
     // formats 2 and 3: positions in this text -> positions in the full-length template (ss_text.h, TextGaps / MinTextGaps)
     __shared__ uint32_t s_G[kMaxTextLists], s_D[kMaxTextLists], s_Gk[kMaxTextLists], s_Dk[kMaxTextLists];
-    const uint32_t n_trees = f == 3 ? a.minfo.n_lists : a.sinfo.n_trees;  // (gaps)
+    const uint32_t n_trees = f == kTextMinimal ? a.minfo.n_lists : a.sinfo.n_trees;  // (gaps)
     if (shared) {
-        const uint32_t *gG = f == 2 ? a.hints[t].g.G : a.mhints[t].g.G, *gD = f == 2 ? a.hints[t].g.D : a.mhints[t].g.D;
-        const uint32_t *gGk = f == 2 ? a.hints[t].g.Gk : a.mhints[t].g.Gk, *gDk = f == 2 ? a.hints[t].g.Dk : a.mhints[t].g.Dk;
+        const uint32_t *gG = f == kTextShared ? a.hints[t].g.G : a.mhints[t].g.G, *gD = f == kTextShared ? a.hints[t].g.D : a.mhints[t].g.D;
+        const uint32_t *gGk = f == kTextShared ? a.hints[t].g.Gk : a.mhints[t].g.Gk, *gDk = f == kTextShared ? a.hints[t].g.Dk : a.mhints[t].g.Dk;
         for (uint32_t i = lane; i < n_trees; i += 64) { s_G[i] = gG[i]; s_D[i] = gD[i]; s_Gk[i] = gGk[i]; s_Dk[i] = gDk[i]; }
         __syncthreads();
     }
