@@ -686,6 +686,7 @@ def main() -> None:
     timed_pipe = verifier.Pipeline(slots, tail_streams=args.tail_streams) if args.tail_streams > 1 else pipe
     accs = [torch.zeros(1, dtype=torch.int32, device=ver.device) for _ in range(nslot)]
     acc = accs[0]
+    torch.cuda.synchronize()  # the fills ran on the current stream; the reduces write `accs` on the pipelines' head streams
 
     def reduce_accepts(k: int) -> None:
         if grouped:  # the path's only exchange: accept-count reduce over xGMI

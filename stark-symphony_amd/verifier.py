@@ -21,6 +21,22 @@ MODE_LITERAL, MODE_FIXTURE = B.MODE_LITERAL, B.MODE_FIXTURE
 PHASE_HEAD, PHASE_TAIL, PHASE_ALL = 1, 2, 3
 
 
+def _after_current(streams, dev) -> None:
+    """Order `streams` after everything already enqueued on the caller's current stream of `dev`.
+
+    torch's side streams are non-blocking: they are NOT ordered after the legacy null stream, so a `fill_` / `zeros` /
+    `copy_` a caller issued on its current stream can still be pending when a pass on a side stream starts -- or land
+    after that pass has finished, in which case the caller's write replaces the verifier's status words (round 5's red
+    test: profiles/r06_null_stream_order.txt).  The status word is the verifier's and only the verifier's
+    (stark101/src/verifier.simf:24-42, simfony-cli/src/main.rs:254-257), so every helper below joins the current
+    stream when it is made, and again on request (`wait_current`)."""
+    torch = _torch()
+    cur = torch.cuda.current_stream(dev)
+    for s in streams:
+        if s != cur:
+            s.wait_stream(cur)
+
+
 class Pipeline:
     """Keeps `depth` passes over resident batches in flight on two HIP streams: the HEAD half
     (transcript + query kernels, latency bound) of pass i+1 runs on the head stream while the
@@ -48,6 +64,12 @@ class Pipeline:
         self.head_done = [torch.cuda.Event() for _ in self.slots]
         self.tail_done = [None for _ in self.slots]
         self.i = 0
+        self.wait_current()
+
+    def wait_current(self) -> None:
+        """Order every later pass after what the caller has enqueued on its current stream so far (done once by the
+        constructor; call it again after writing to a slot's buffers from the current stream)."""
+        _after_current(set(self.head_streams + self.tail_streams + [self.comm_stream]), self.slots[0].ver.device)
 
     def submit(self, after_tail=None, on_reuse=None) -> int:
         """Enqueue one pass; returns the slot it used.
@@ -119,6 +141,11 @@ class IndependentStreams:
         dev = self.slots[0].ver.device
         self.streams = [torch.cuda.Stream(device=dev) for _ in self.slots]
         self.i = 0
+        self.wait_current()
+
+    def wait_current(self) -> None:
+        """Order every later pass after what the caller has enqueued on its current stream so far (see Pipeline)."""
+        _after_current(self.streams, self.slots[0].ver.device)
 
     def submit(self) -> int:
         k = self.i % len(self.slots)
@@ -182,7 +209,10 @@ class GraphedPipeline:
         self._pipe, self._branches = pipe, branches  # keeps the captured streams and events alive
 
     def replay(self) -> int:
-        """Enqueue one pass over every slot; returns the number of passes."""
+        """Enqueue one pass over every slot, ordered after what the caller's current stream holds so far (torch's own
+        CUDAGraph.replay runs ON the current stream; this one runs on the capture stream, so it joins it instead);
+        returns the number of passes."""
+        _after_current([self.stream], self.slots[0].ver.device)
         with _torch().cuda.stream(self.stream):
             self.graph.replay()
         return self.steps_per_replay
@@ -590,6 +620,9 @@ class _DeviceBatch:
         self.status_dev = torch.empty(n, dtype=torch.int32, device=ver.device)
         self.accept_dev = torch.zeros(1, dtype=torch.int32, device=ver.device)
         self.batch_bytes = self.batch.numel() * 4
+        # nothing of the construction (the fill above, a subclass's device gather) may still be pending on the caller's
+        # current stream when a pass starts on another stream: passes run on non-blocking side streams (_after_current)
+        torch.cuda.current_stream(ver.device).synchronize()
 
     def _stream(self, stream) -> int:
         torch = _torch()
@@ -606,13 +639,18 @@ class _DeviceBatch:
         other.ws = torch.empty_like(self.ws)
         other.status_dev = torch.empty_like(self.status_dev)
         other.accept_dev = torch.zeros_like(self.accept_dev)
+        torch.cuda.current_stream(self.ver.device).synchronize()  # as in __init__: no fill left pending
         return other
 
     def status(self) -> np.ndarray:
-        """Synchronises, returns the per-proof status words (0 = ACCEPT)."""
+        """Waits for every stream of the device (the passes may have run on any of them), returns the per-proof
+        status words (0 = ACCEPT)."""
+        _torch().cuda.synchronize(self.ver.device)
         return self.status_dev.cpu().numpy().view(np.uint32).copy()
 
     def accepted(self) -> int:
+        """Waits like status(); the number of accepted proofs of the last pass."""
+        _torch().cuda.synchronize(self.ver.device)
         return int(self.accept_dev.item())
 
 

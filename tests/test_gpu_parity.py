@@ -254,6 +254,7 @@ def test_stwo_baseline_configs(ver, name):
     assert lit.tolist() == O.stwo_verify_batch(batch, O.MODE_LITERAL).tolist()
 
 
+@pytest.mark.streams
 def test_pipeline_matches_single_stream(ver, stwo_prod):
     """HEAD/TAIL halves on two streams with two slots give the same verdicts."""
     rng = np.random.default_rng(SEED + 12)
@@ -270,6 +271,7 @@ def test_pipeline_matches_single_stream(ver, stwo_prod):
         assert slot.accepted() == int((ref == 0).sum())
 
 
+@pytest.mark.streams
 def test_pipeline_callbacks_see_every_pass_once(ver, stwo_prod):
     """Pipeline.submit(after_tail=...) / (on_reuse=...) + flush: the hook a caller hangs its accept reduce on runs exactly
     once per pass, ordered after that pass and before the slot's next one (bench.py's use: all_reduce of the count); with
@@ -287,6 +289,7 @@ def test_pipeline_callbacks_see_every_pass_once(ver, stwo_prod):
             pipe = verifier.Pipeline(slots, **kw)
             # one accumulator per slot: on_reuse hooks of different slots run on different head streams, at the same time
             totals = torch.zeros(len(slots), dtype=torch.int64, device=ver.device)
+            pipe.wait_current()  # the fill ran on the current stream; the hooks write `totals` on the pipeline's streams
             calls = []
 
             def hook(k):
@@ -316,6 +319,7 @@ def test_device_pack_equals_host_pack(ver, stwo_small, stwo_prod, which, n):
     assert np.array_equal(dev.cpu().numpy().view(np.uint32), host)
 
 
+@pytest.mark.streams
 def test_host_buffer_entry_point(ver, stwo_prod):
     """ss_stwo_verify_records: pinned chunked upload + GPU packing + verify, several chunks
     (1300 proofs of 54 KB > one 64 MiB staging buffer), called twice to reuse its scratch."""
@@ -395,6 +399,7 @@ def test_stwo_full_size_batch_65536(ver):
         torch.cuda.empty_cache()
 
 
+@pytest.mark.streams
 @pytest.mark.parametrize("concurrent", [False, True])
 def test_graphed_pipeline_matches_eager(ver, s101_proof, stwo_prod, concurrent):
     """hipGraph replay of the pipelined passes (fork / join of the head and tail streams captured
@@ -417,7 +422,7 @@ def test_graphed_pipeline_matches_eager(ver, s101_proof, stwo_prod, concurrent):
         assert gp.steps_per_replay == 3
         for _ in range(3):
             for s in slots:
-                s.status_dev.fill_(0x55)
+                s.status_dev.fill_(0x55)  # on the current stream; replay() orders the graph after it
             gp.replay()
             gp.synchronize()
             for s in slots:
@@ -840,6 +845,7 @@ def test_simfony_run_shim_in_c(tmp_path):
     assert run(str(pstwo), "--witness", str(tmp_path / "absent.wit")).returncode == 1
 
 
+@pytest.mark.streams
 def test_independent_streams_match_single_stream(ver, s101_proof, stwo_prod):
     """verifier.IndependentStreams (whole passes on their own streams, what bench.py uses for small
     batches): every slot ends with the oracle's status words and accept count, also when a slot is
@@ -854,6 +860,9 @@ def test_independent_streams_match_single_stream(ver, s101_proof, stwo_prod):
         ind = verifier.IndependentStreams(slots)
         for s in slots:
             s.status_dev.fill_(0x55)
+        # the fills ran on the current stream and the passes run on non-blocking side streams: without this join a fill
+        # may land after its slot's last pass and replace the verifier's status words (GPUTEST_r05, profiles/r06_null_stream_order.txt)
+        ind.wait_current()
         used = [ind.submit() for _ in range(23)]
         ind.synchronize()
         assert used == [i % 5 for i in range(23)]
@@ -873,6 +882,7 @@ def test_empty_batches_have_empty_answers(ver, stwo_prod):
     assert st.shape == (0,)
 
 
+@pytest.mark.streams
 def test_two_contexts_in_one_process(ver, stwo_prod):
     """the device entry points bind the context's device themselves (csrc/ss_ctx.h DeviceGuard), so a
     process may hold several contexts -- the C / Rust caller of INTEGRATION.md holds one per GPU.  On a one-GPU box:
