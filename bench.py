@@ -251,7 +251,10 @@ def end_to_end(ver, proofs, n: int, rank: int = 0, world: int = 1, dist=None):
              "json_shared": [json.dumps(ss.stwo_to_json(p, shared=True), separators=(",", ":")).encode() for p in distinct]}
     out = {"proofs": n, "note": "proof text -> verdict through ss_stwo_verify_texts: raw bytes staged into pinned memory, "
                                 "uploaded, turned into records by the GPU reader (csrc/ss_textdev.hip), re-tiled, verified; "
-                                "bound by the host link, not what `value` measures"}
+                                "bound by the host link, not what `value` measures",
+           "parity": "json / wit / records are the forms the reference's adapters emit (generate_wit.py:106-245): pinned as the "
+                     "bench line says; json_shared, shared_records, minimal_records, json_minimal have no bytes in the reference: "
+                     "unpinned, held to the per-query record they expand to"}
     if world > 1:
         out["ranks"] = world
         out["host_threads_per_rank"] = int(os.environ.get("SS_HOST_THREADS", "0")) or None
@@ -857,7 +860,12 @@ def main() -> None:
                        "hash_compressions_per_proof": compr_per_proof,
                        "hash_compressions_executed_per_proof": executed,
                        "pair_memoisation": family == "stwo" and not args.no_dedup, "hash": hash_name,
-                       "parity": "unpinned (Blake2s is not in the reference)" if hash_name == "blake2s" else "pinned (reference KATs + proofs)",
+                       # what "pinned" covers: leaf functions by the reference's 86 fn test_* KATs (oracle and
+                       # device); end to end stark101 by the reference prover's proof, stwo by the reference's two shipped
+                       # proofs -- which only FIXTURE mode accepts (the .simf text rejects its own proofs)
+                       "parity": "unpinned (Blake2s is not in the reference: RFC 7693 vectors + prover / oracle / GPU agreement)" if hash_name == "blake2s" else
+                                 "pinned: SHA-256, stark101 verify_proof (86 reference KATs + the reference prover's proof)" if family != "stwo" else
+                                 "pinned: SHA-256, FIXTURE mode (86 reference KATs + 3 reference proofs); LITERAL mode by the .simf text only",
                        "mode": "fixture_correct", "inflight_streams": nslot,
                        "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
                        "GPU_MAX_HW_QUEUES_matters_for": "value, ms_per_step and kernels_ms_per_step of every pipelined / multi-stream "

@@ -30,13 +30,55 @@ def _world(group=None) -> Tuple[int, int]:
     return 0, 1
 
 
+# Host threads the staged host paths (ss_stwo_verify_files / _texts / _records: stager threads copy the caller's bytes into
+# the library's pinned chunks) need to keep a 55 GB/s host link busy; measured 2 threads: 37-47 GB/s, 1 thread: 30-34 GB/s,
+# 8: 52-54 GB/s (profiles/r05_host_path_threads.txt).  Below that the caller-pinned entry points are faster: the DMA engine
+# reads the caller's page-locked buffer and no host thread touches a byte.
+STAGED_PATH_THREADS = 8
+
+
+def host_threads_per_rank(world: int) -> int:
+    """Cores one rank of `world` may use on this host: scheduler affinity capped by the cgroup quota, shared evenly (what
+    bench.py exports as SS_HOST_THREADS)."""
+    import os
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n // max(1, world))
+
+
+def use_pinned_inputs(world: Optional[int] = None) -> bool:
+    """True where a rank should hand the library caller-pinned inputs (`ss_stwo_verify_*_pinned`) instead of the staged
+    ones: whenever its share of the host's cores cannot feed the staging copy -- every rank of an 8-GPU node on a 16-core
+    grant (2 threads each), not a single process that owns the host."""
+    if world is None:
+        world = _world()[1]
+    return host_threads_per_rank(world) < STAGED_PATH_THREADS
+
+
+def files_verifier(ver, cfg, mode: Optional[int] = None, world: Optional[int] = None) -> Callable[[Sequence[str]], np.ndarray]:
+    """The `verify_files_local` to hand to verify_files_sharded on a GPU box: paths -> status words through THIS rank's
+    Verifier, reading the files into one page-locked buffer (Verifier.verify_stwo_files_pinned) when the rank's host-thread
+    budget is below what the staged reader needs, else through ss_stwo_verify_files."""
+    from . import verifier as V
+    m = V.MODE_FIXTURE if mode is None else mode
+    if use_pinned_inputs(world):
+        return lambda ps: ver.verify_stwo_files_pinned(cfg, ps, m)[0]
+    return lambda ps: ver.verify_stwo_files(cfg, ps, m)[0]
+
+
 def verify_files_sharded(paths: Sequence[str], verify_files_local: Callable[[Sequence[str]], np.ndarray],
                          group=None, gather_status: bool = False, device=None):
     """Rank-local ingest ("each rank reads only its slice"): every rank is handed the same list of file
     NAMES and opens only the files of its own contiguous slice -- the reference's caller hands one file per process
     (stwo-verifier/Makefile:17-18: `simfony run main.simf --witness proof.wit`).  verify_files_local(paths_slice) ->
-    uint32 status per file; on the GPU box `lambda ps: Verifier(local_rank).verify_stwo_files(cfg, ps)[0]`
-    (ss_stwo_verify_files: the library reads, uploads and parses the text itself).  The only exchange is the final
+    uint32 status per file; on the GPU box `files_verifier(Verifier(local_rank), cfg)`: the caller-pinned entry point when
+    the rank shares the host's cores with seven others, ss_stwo_verify_files (the library reads, stages and uploads the text
+    itself) when it owns them.  The only exchange is the final
     accept-reduce, as in verify_sharded.  Returns (local_status, accepted_total, n_total[, all_status])."""
     rank, world = _world(group)
     lo, hi = shard_range(len(paths), rank, world)

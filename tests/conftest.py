@@ -37,6 +37,8 @@ _GPU_ORDER = ["test_gpu_kats.py", "test_gpu_parity.py", "test_blake2s.py", "test
 
 
 def pytest_collection_modifyitems(config, items):
+    if os.environ.get("SS_TEST_ORDER") == "collection":  # (tools/probes/null_order_insuite.py: round 5's order, to replay its failure)
+        return
     def key(item):
         name = os.path.basename(str(item.fspath))
         if item.get_closest_marker("gpu") is None:

@@ -58,6 +58,45 @@ def test_sharded_verify_gloo(tmp_path, world, n):
     assert [(s == 0) for s in allst] == [bool(i % 3) for i in range(n)]
 
 
+def _index_worker(rank: int, world: int, port: int, n: int, out_dir: str) -> None:
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from stark_symphony_amd import distributed
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seen = []
+
+    def verdicts(sl):  # a verdict that names its proof: status = index + 1 for every seventh, else ACCEPT
+        seen.append((sl[0], sl[-1], len(sl)))
+        idx = np.asarray(sl, dtype=np.int64)
+        return np.where(idx % 7 == 0, idx + 1, 0).astype(np.uint32)
+    local, accepted, total, allst = distributed.verify_sharded(range(n), verdicts, gather_status=True)
+    np.savez(os.path.join(out_dir, "i%d.npz" % rank), local=local, accepted=accepted, total=total, allst=allst,
+             seen=np.array(seen, dtype=np.int64))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [65536, 65539, 5])
+def test_sharded_verify_at_the_real_world_size(tmp_path, n):
+    """BASELINE configs[3] as it is sharded on an 8-GPU node: world size 8, 65 536 proof indices (8 192 per rank), plus a
+    batch that does not divide (ranks differ by one proof: the gather pads) and one with fewer proofs than ranks (three
+    ranks own nothing and still take part in both collectives)."""
+    from stark_symphony_amd.distributed import shard_range
+    world, port = 8, _free_port()
+    mp.spawn(_index_worker, args=(world, port, n, str(tmp_path)), nprocs=world, join=True)
+    res = [np.load(os.path.join(tmp_path, "i%d.npz" % r)) for r in range(world)]
+    want = np.where(np.arange(n) % 7 == 0, np.arange(n) + 1, 0).astype(np.uint32)
+    for r, d in enumerate(res):
+        lo, hi = shard_range(n, r, world)
+        assert np.array_equal(d["local"], want[lo:hi])
+        assert d["seen"].tolist() == ([[lo, hi - 1, hi - lo]] if hi > lo else [])  # its slice, once, nothing else
+        assert int(d["total"]) == n and int(d["accepted"]) == int((want == 0).sum())
+        assert np.array_equal(d["allst"], want)
+    if n == 65536:
+        assert all(len(d["local"]) == 8192 for d in res)
+
+
 def _files_worker(rank: int, world: int, port: int, paths, out_dir: str) -> None:
     sys.path.insert(0, ROOT)
     import builtins
@@ -129,3 +168,24 @@ def test_shard_range_is_a_partition():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_ranks_that_share_a_host_are_told_to_use_pinned_inputs(monkeypatch):
+    """distributed.use_pinned_inputs / files_verifier: a rank whose share of the host's cores is below what the staged host
+    paths need (8 threads for a 55 GB/s link, profiles/r05_host_path_threads.txt) gets the caller-pinned entry points --
+    every rank of an 8-GPU node on a 16-core grant; a process that owns 16 cores keeps the staged ones."""
+    from stark_symphony_amd import distributed
+
+    class Ver:
+        def verify_stwo_files(self, cfg, ps, mode):
+            return ("staged", list(ps)), {}
+
+        def verify_stwo_files_pinned(self, cfg, ps, mode):
+            return ("pinned", list(ps)), {}
+    monkeypatch.setattr(os, "sched_getaffinity", lambda _: set(range(16)))  # (the cgroup quota may still cap it below)
+    assert distributed.host_threads_per_rank(1) <= 16 and distributed.host_threads_per_rank(8) <= 2
+    assert distributed.use_pinned_inputs(8) and distributed.use_pinned_inputs(4)
+    if distributed.host_threads_per_rank(1) >= distributed.STAGED_PATH_THREADS:
+        assert not distributed.use_pinned_inputs(1)
+        assert distributed.files_verifier(Ver(), None, world=1)(["a"])[0] == "staged"
+    assert distributed.files_verifier(Ver(), None, world=8)(["a", "b"]) == ("pinned", ["a", "b"])

@@ -141,6 +141,14 @@ def test_verify_texts_mixed_batch_and_chunking(ver, tmp_path):
     paths.append(str(tmp_path / "absent.json"))
     status, stats = ver.verify_stwo_files(cfg, paths)
     assert status.tolist() == want[:12] + [2]
+    # the same files read into ONE page-locked buffer (what a rank of an 8-GPU host uses: distributed.files_verifier)
+    empty = tmp_path / "empty.json"
+    empty.write_bytes(b"")
+    pstatus, pstats = ver.verify_stwo_files_pinned(cfg, paths + [str(empty)])
+    assert pstatus.tolist() == want[:12] + [2, 2] and pstats["host_parsed"] == stats["host_parsed"] + 1
+    from stark_symphony_amd import distributed
+    for world in (1, 8):
+        assert distributed.files_verifier(ver, cfg, world=world)(paths).tolist() == want[:12] + [2]
     status, _ = ver.verify_stwo_texts(cfg, [variants[0], variants[2]], fmt=JSON)
     assert status.tolist() == [want[0], 2]  # a .wit read as proof.json is no proof.json
 

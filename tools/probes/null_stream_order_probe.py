@@ -23,48 +23,57 @@ import torch  # noqa: E402
 import stark_symphony_amd as ss  # noqa: E402
 from stark_symphony_amd import verifier  # noqa: E402
 
-reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
-join = len(sys.argv) > 2 and sys.argv[2] == "join"
-busy = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # extra streams kept alive and busy (a process with many queues in use)
-ver = verifier.Verifier(0)
-s101 = ss.stark101_from_json(json.load(open(os.path.join(ROOT, "tests", "golden", "stark101_proof.json"))))
-batch = ver.stark101_batch([s101], replicate=300)
-slots = [batch.sibling() for _ in range(5)]
-streams = [torch.cuda.Stream() for _ in slots]
-extra = [torch.cuda.Stream() for _ in range(busy)]
-junk = torch.zeros(1 << 22, device="cuda")
-torch.cuda.synchronize()
-where = {"before_first": 0, "between": 0, "after_last": 0}
-stale = 0
-for r in range(reps):
-    for e in extra:
-        with torch.cuda.stream(e):
-            junk.add_(1.0)
-    for s in slots:
-        s.status_dev.fill_(0x55)
-    filled = torch.cuda.Event(enable_timing=True)
-    filled.record()  # null stream, behind the fills
-    if join:
-        for st in streams:
-            st.wait_stream(torch.cuda.current_stream())
-    first = [None] * 5
-    last = [None] * 5
-    for i in range(23):
-        k = i % 5
-        slots[k].run(streams[k])
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record(streams[k])
-        if first[k] is None:
-            first[k] = ev
-        last[k] = ev
+
+def measure(ver, reps: int, join: bool, busy: int = 0, n_slots: int = 5, passes: int = 23):
+    """-> (where the fill event fell per slot, slots whose status ended 0x55)"""
+    s101 = ss.stark101_from_json(json.load(open(os.path.join(ROOT, "tests", "golden", "stark101_proof.json"))))
+    batch = ver.stark101_batch([s101], replicate=300)
+    slots = [batch.sibling() for _ in range(n_slots)]
+    streams = [torch.cuda.Stream() for _ in slots]
+    extra = [torch.cuda.Stream() for _ in range(busy)]  # extra streams kept alive and busy (a process with many queues in use)
+    junk = torch.zeros(1 << 22, device="cuda")
     torch.cuda.synchronize()
-    for k in range(5):
-        if first[k].elapsed_time(filled) <= 0:      # filled is not later than first
-            where["before_first"] += 1
-        elif last[k].elapsed_time(filled) <= 0:
-            where["between"] += 1
-        else:
-            where["after_last"] += 1
-        stale += int((slots[k].status_dev == 0x55).any().item())
-print("GPU_MAX_HW_QUEUES=%s join=%s busy_streams=%d reps=%d slots=5: fill event %s; slots whose status words ended 0x55: %d of %d" % (
-    os.environ.get("GPU_MAX_HW_QUEUES", "unset"), join, busy, reps, where, stale, 5 * reps), flush=True)
+    where = {"before_first": 0, "between": 0, "after_last": 0}
+    stale = 0
+    late_ms = []
+    for r in range(reps):
+        for e in extra:
+            with torch.cuda.stream(e):
+                junk.add_(1.0)
+        for s in slots:
+            s.status_dev.fill_(0x55)
+        filled = torch.cuda.Event(enable_timing=True)
+        filled.record()  # null stream, behind the fills
+        if join:
+            for st in streams:
+                st.wait_stream(torch.cuda.current_stream())
+        first = [None] * n_slots
+        last = [None] * n_slots
+        for i in range(passes):
+            k = i % n_slots
+            slots[k].run(streams[k])
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(streams[k])
+            if first[k] is None:
+                first[k] = ev
+            last[k] = ev
+        torch.cuda.synchronize()
+        for k in range(n_slots):
+            if first[k].elapsed_time(filled) <= 0:      # filled is not later than first
+                where["before_first"] += 1
+            elif last[k].elapsed_time(filled) <= 0:
+                where["between"] += 1
+            else:
+                where["after_last"] += 1
+                late_ms.append(last[k].elapsed_time(filled))
+            stale += int((slots[k].status_dev == 0x55).any().item())
+    return where, stale, late_ms
+
+
+if __name__ == "__main__":
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+    join = len(sys.argv) > 2 and sys.argv[2] == "join"
+    busy = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    where, stale, late = measure(verifier.Verifier(0), reps, join, busy)
+    print("GPU_MAX_HW_QUEUES=%s join=%s busy_streams=%d reps=%d slots=5: fill event %s; slots whose status words ended 0x55: %d of %d" % (
+        os.environ.get("GPU_MAX_HW_QUEUES", "unset"), join, busy, reps, where, stale, 5 * reps), flush=True)
