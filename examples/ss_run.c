@@ -6,7 +6,7 @@
  * and its callers read the exit status: 0 = the program ran (ACCEPT), 1 = `Error: Failed to run program
  * ...` (a failed assert) or a witness that does not type-check (simfony-cli/src/main.rs:77-81,187-190,
  * 205-206,254-257).  This program takes the same arguments, hands the .wit file to the library's native
- * reader (ss_*_verify_files) and returns the same exit status -- a one-line change in a Makefile.  The
+ * reader (ss_verify_inputs: SS_FORM_TEXT from SS_SRC_FILES) and returns the same exit status -- a one-line change in a Makefile.  The
  * program file is not executed (the verifier it contains is the library's kernels); it only selects
  * the witness family when --family is not given: from its path ("stark101" / "stwo"), else from its
  * text (`witness::P_MT_ROOT` is read by stark101/src/main.simf:13, `witness::COMMITMENTS` by
@@ -120,10 +120,21 @@ int main(int argc, char **argv)
     ss_ctx *ctx = NULL;
     uint32_t *status = (uint32_t *)malloc(n * sizeof *status);
     if (!status) { fprintf(stderr, "Error: out of memory\n"); free(wits); return 2; }
+    ss_process_defaults();  /* before the first HIP call (ss_ctx_create below); one witness needs no extra queues, a batch caller does */
     int rc = ss_ctx_create(device, &ctx);
-    if (rc == SS_OK)
-        rc = s101 ? ss_s101_verify_files(ctx, n, wits, SS_TEXT_WIT, status, NULL)
-                  : ss_stwo_verify_files(ctx, &cfg, n, wits, SS_TEXT_WIT, status, NULL);
+    if (rc == SS_OK) {
+        /* the library's ONE host entry point: n witness FILES of text, read, uploaded and parsed by the library itself */
+        ss_input_desc in;
+        memset(&in, 0, sizeof in);
+        in.family = s101 ? SS_FAMILY_STARK101 : SS_FAMILY_STWO;
+        in.form = SS_FORM_TEXT;
+        in.source = SS_SRC_FILES;
+        in.text_fmt = SS_TEXT_WIT;
+        in.cfg = s101 ? NULL : &cfg;
+        in.n = n;
+        in.items = (const void *const *)wits;
+        rc = ss_verify_inputs(ctx, &in, status, NULL);
+    }
     if (rc != SS_OK) {  /* no GPU, unsupported config: an error, never a verdict */
         fprintf(stderr, "Error: libss_verify: %s (code %d)\n", ss_last_error(), rc);
         ss_ctx_destroy(ctx);

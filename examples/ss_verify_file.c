@@ -26,6 +26,7 @@
 #include <string.h>
 
 #include "ss_verify.h"
+#include "ss_verify_forms.h" /* the layouts of shared / minimal records */
 
 static uint32_t *read_words(const char *path, size_t *n_words)
 {
@@ -83,7 +84,13 @@ int main(int argc, char **argv)
         ss_ingest_stats stats;
         ss_ctx *tctx = NULL;
         int trc = ss_ctx_create(0, &tctx);
-        if (trc == SS_OK) trc = ss_stwo_verify_files(tctx, &cfg, nf, (const char *const *)(argv + 11), atoi(argv[10]), st, &stats);
+        if (trc == SS_OK) {
+            ss_input_desc in;
+            memset(&in, 0, sizeof in);
+            in.family = SS_FAMILY_STWO; in.form = SS_FORM_TEXT; in.source = SS_SRC_FILES; in.text_fmt = (uint32_t)atoi(argv[10]);
+            in.cfg = &cfg; in.n = nf; in.items = (const void *const *)(argv + 11);
+            trc = ss_verify_inputs(tctx, &in, st, &stats);
+        }
         if (trc != SS_OK) { fprintf(stderr, "libss_verify: %s (code %d)\n", ss_last_error(), trc); return 2; }
         size_t bad = 0;
         for (size_t i = 0; i < nf; i++) {
@@ -152,11 +159,20 @@ int main(int argc, char **argv)
 
     ss_ctx *ctx = NULL;
     int rc = ss_ctx_create(0, &ctx);
-    if (rc == SS_OK)
-        rc = shared ? ss_stwo_verify_shared_records(ctx, &cfg, n, recs, lens, status)
-             : minimal ? ss_stwo_verify_minimal_records(ctx, &cfg, n, recs, lens, status)
-             : stwo ? ss_stwo_verify_records(ctx, &cfg, n, recs, status)
-                    : ss_s101_verify_records(ctx, &shape, n, recs, status);
+    if (rc == SS_OK) {
+        /* one descriptor for all four: the form of one input, where the n inputs lie (include/ss_verify.h section 4) */
+        ss_input_desc in;
+        memset(&in, 0, sizeof in);
+        in.family = stwo ? SS_FAMILY_STWO : SS_FAMILY_STARK101;
+        in.form = shared ? SS_FORM_SHARED_RECORDS : minimal ? SS_FORM_MINIMAL_RECORDS : SS_FORM_RECORDS;
+        in.source = SS_SRC_HOST;
+        in.cfg = stwo ? &cfg : NULL;
+        in.shape = stwo ? NULL : &shape;
+        in.n = n;
+        in.items = (const void *const *)recs;
+        in.lens = lens;  /* words of every shared / minimal record; per-query records have their config's size */
+        rc = ss_verify_inputs(ctx, &in, status, NULL);
+    }
     if (rc != SS_OK) {  /* no CPU fallback: a missing GPU is an error, never a verdict */
         fprintf(stderr, "libss_verify: %s (code %d)\n", ss_last_error(), rc);
         return 2;

@@ -12,12 +12,25 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libss_verify.so")
 
-# The process default the library itself sets when it is loaded (csrc/ss_env.cpp: streams that share one of the runtime's 4
-# default hardware queues serialise, which is what the pipelines here exist to avoid) -- set at import already, because this
-# module loads the library lazily and the HIP runtime reads the variable when it initialises (torch's first CUDA call).
-# A value the caller has set wins; SS_KEEP_ENV=1 leaves the environment alone.
-if "SS_KEEP_ENV" not in os.environ:
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+def process_defaults() -> int:
+    """ss_process_defaults() (include/ss_verify.h): ask the HIP runtime for 24 hardware queues unless the caller's
+    environment already says otherwise (or SS_KEEP_ENV is set) -- streams that share one of the runtime's 4 default queues
+    serialise, which is what the pipelines here exist to avoid.  An explicit call since ABI 2.4 (the library no longer
+    touches the environment when it is loaded); this module makes it when it is IMPORTED, because the runtime reads the
+    variable once, at the process's first HIP call (torch's first CUDA call), and the library itself is loaded lazily.
+    Returns the queue count now in the environment (0 = unset).  Verdicts never depend on it."""
+    if os.path.exists(LIB_PATH):
+        n = int(C.CDLL(LIB_PATH).ss_process_defaults())
+    else:  # not built yet: lib() raises later; same rule meanwhile
+        if "SS_KEEP_ENV" not in os.environ:
+            os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+        return int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0)
+    if n and "GPU_MAX_HW_QUEUES" not in os.environ:  # C setenv does not show in os.environ: mirror it for child processes and reports
+        os.environ["GPU_MAX_HW_QUEUES"] = str(n)
+    return n
+
+
+process_defaults()
 
 SS_OK, SS_ERR_ARG, SS_ERR_HIP, SS_ERR_NO_DEVICE, SS_ERR_WORKSPACE, SS_ERR_NOMEM = 0, -1, -2, -3, -4, -5
 MODE_LITERAL, MODE_FIXTURE = 0, 1
@@ -49,6 +62,18 @@ class StwoWsLayout(C.Structure):
                 ("n_pow", C.c_uint32), ("top_levels", C.c_uint32), ("has_plan", C.c_uint32), ("plan", C.c_uint64)]
 
 
+class InputDesc(C.Structure):
+    """ss_input_desc: what ss_verify_inputs takes (family, form of one input, where the n inputs lie)"""
+    _fields_ = [("family", C.c_uint32), ("form", C.c_uint32), ("source", C.c_uint32), ("text_fmt", C.c_uint32),
+                ("cfg", C.c_void_p), ("shape", C.c_void_p), ("n", C.c_size_t), ("items", C.c_void_p),
+                ("lens", C.c_void_p), ("blob", C.c_void_p), ("offs", C.c_void_p)]
+
+
+FAMILY_STARK101, FAMILY_STWO = 1, 2
+FORM_RECORDS, FORM_SHARED_RECORDS, FORM_MINIMAL_RECORDS, FORM_TEXT = 0, 1, 2, 3
+SRC_HOST, SRC_PINNED, SRC_FILES = 0, 1, 2
+
+
 class IngestStats(C.Structure):
     """ss_ingest_stats"""
     _fields_ = [("read_s", C.c_double), ("parse_s", C.c_double), ("total_s", C.c_double),
@@ -60,8 +85,8 @@ TEXT_AUTO, TEXT_JSON, TEXT_WIT, TEXT_JSON_SHARED, TEXT_JSON_MINIMAL = 0, 1, 2, 3
 STATUS_CONFIG_MISMATCH, STATUS_MALFORMED = 1, 2
 
 EXPORTS = [
-    "ss_version", "ss_last_error", "ss_device_count", "ss_abi_sizeof_cfg", "ss_abi_sizeof_shape",
-    "ss_stwo_ws_layout_of", "ss_stwo_read_intermediates", "ss_stwo_parse", "ss_s101_parse",
+    "ss_version", "ss_last_error", "ss_device_count", "ss_abi_sizeof_cfg", "ss_abi_sizeof_shape", "ss_process_defaults",
+    "ss_verify_inputs", "ss_stwo_ws_layout_of", "ss_stwo_read_intermediates", "ss_stwo_parse", "ss_s101_parse",
     "ss_stwo_verify_texts", "ss_stwo_verify_files", "ss_s101_verify_texts", "ss_s101_verify_files",
     "ss_s101_record_words", "ss_s101_batch_words", "ss_s101_workspace_bytes", "ss_s101_pack",
     "ss_stwo_record_words", "ss_stwo_batch_words", "ss_stwo_workspace_bytes", "ss_stwo_pack",
@@ -126,6 +151,8 @@ def lib() -> C.CDLL:
     sig("ss_stwo_verify_phase_dev", C.c_int, vp, cp, sz, vp, vp, sz, vp, vp, C.c_int, vp)
     sig("ss_stwo_pack_dev", C.c_int, vp, cp, sz, vp, vp, vp)
     sig("ss_s101_pack_dev", C.c_int, vp, sp, sz, vp, vp, vp)
+    sig("ss_process_defaults", C.c_int)
+    sig("ss_verify_inputs", C.c_int, vp, C.POINTER(InputDesc), vp, vp)
     sig("ss_s101_verify_records", C.c_int, vp, sp, sz, pp, vp)
     sig("ss_stwo_verify_records", C.c_int, vp, cp, sz, pp, vp)
     sig("ss_ctx_set_timing", C.c_int, vp, C.c_int)

@@ -11,7 +11,7 @@
 #include <chrono>
 #include <string>
 
-#include "../../include/ss_verify.h"
+#include "ss_abi.h"
 #include "ss_copy.h"
 #include "ss_ctx.h"
 #include "ss_fields.h"

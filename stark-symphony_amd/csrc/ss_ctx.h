@@ -8,7 +8,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/ss_verify.h"
+#include "ss_abi.h"
 #include "ss_pack.h"
 #include "ss_pool.h"
 #include "ss_text.h"

@@ -13,7 +13,7 @@
 
 #include <vector>
 
-#include "../../include/ss_verify.h"
+#include "ss_abi.h"
 
 namespace ss {
 

@@ -12,7 +12,7 @@
 #include <mutex>
 #include <vector>
 
-#include "../../include/ss_verify.h"
+#include "ss_abi.h"
 #include "ss_channel.h"
 #include "ss_ctx.h"
 #include "ss_fields.h"

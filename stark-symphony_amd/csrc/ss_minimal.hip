@@ -22,7 +22,7 @@
 #include <algorithm>
 #include <vector>
 
-#include "../../include/ss_verify.h"
+#include "ss_abi.h"
 #include "ss_copy.h"
 #include "ss_ctx.h"
 #include "ss_kernels.h"

@@ -3,7 +3,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
-#include "../../include/ss_verify.h"
+#include "ss_abi.h"
 #include "ss_layout.h"
 
 namespace ss {

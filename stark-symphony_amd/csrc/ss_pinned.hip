@@ -13,7 +13,7 @@
 #include <algorithm>
 #include <vector>
 
-#include "../../include/ss_verify.h"
+#include "ss_abi.h"
 #include "ss_ctx.h"
 #include "ss_layout.h"
 #include "ss_minimal.h"

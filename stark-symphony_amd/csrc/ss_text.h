@@ -23,7 +23,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
-#include "../../include/ss_verify.h"
+#include "ss_abi.h"
 
 #ifndef SS_HD
 #ifdef __HIPCC__

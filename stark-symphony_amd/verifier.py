@@ -1087,6 +1087,68 @@ class Verifier:
                 out_dev.cpu().numpy().view(np.uint32).copy())
 
     # -- text in, verdicts out (native readers, csrc/ss_ingest.cpp) --------------------------
+    def verify_inputs(self, form: str, source: str, inputs=None, *, cfg: Optional[StwoConfig] = None, mode: int = MODE_FIXTURE,
+                      shape=None, blob=None, offsets=None, lengths=None, fmt: int = B.TEXT_AUTO):
+        """ss_verify_inputs, the library's ONE host entry point (include/ss_verify.h section 4): `form` in {"records",
+        "shared_records", "minimal_records", "text"} says what one input is, `source` in {"host", "pinned", "files"} where the
+        inputs lie; cfg given = stwo (the config the caller expects), else stark101 (`shape` = (max_layers, max_path) for its
+        records).  host: `inputs` = uint32 arrays (records) or bytes (texts); files: paths; pinned: `blob` (page-locked array:
+        pinned_buffer / pinned_text_blob / register_host) with `offsets` (n + 1; none for per-query records) and, for texts,
+        `lengths`.  The named methods (verify_stwo_records, verify_stwo_texts_pinned, ...) are this call with the descriptor
+        their name says.  -> (status, stats)"""
+        d = B.InputDesc()
+        d.family = B.FAMILY_STWO if cfg is not None else B.FAMILY_STARK101
+        d.form = {"records": B.FORM_RECORDS, "shared_records": B.FORM_SHARED_RECORDS, "minimal_records": B.FORM_MINIMAL_RECORDS,
+                  "text": B.FORM_TEXT}[form]
+        d.source = {"host": B.SRC_HOST, "pinned": B.SRC_PINNED, "files": B.SRC_FILES}[source]
+        d.text_fmt = fmt
+        keep = []  # ctypes objects the descriptor points to
+        if cfg is not None:
+            cs = stwo_cfg_struct(cfg, mode, self.stwo_flags)
+            keep.append(cs)
+            d.cfg = C.addressof(cs)
+        if shape is not None:
+            sh = B.S101Shape(*shape)
+            keep.append(sh)
+            d.shape = C.addressof(sh)
+        if source == "pinned":
+            d.blob = blob.ctypes.data
+            if offsets is not None:
+                offs = np.ascontiguousarray(offsets, dtype=np.uint64)
+                keep.append(offs)
+                d.offs = offs.ctypes.data
+                n = offs.size - 1
+            else:
+                n = blob.view(np.uint32).size // B.lib().ss_stwo_record_words(C.byref(cs))
+            if lengths is not None:
+                lens = (C.c_size_t * n)(*[int(x) for x in lengths])
+                keep.append(lens)
+                d.lens = C.addressof(lens)
+        else:
+            n = len(inputs)
+            if source == "files":
+                arr = (C.c_char_p * n)(*[os.fsencode(p) for p in inputs])
+            elif form == "text":
+                bufs = [bytes(t) for t in inputs]
+                arr = (C.c_char_p * n)(*bufs)
+                lens = (C.c_size_t * n)(*[len(b) for b in bufs])
+                keep += [bufs, lens]
+                d.lens = C.addressof(lens)
+            else:
+                recs = [np.ascontiguousarray(r, dtype=np.uint32) for r in inputs]
+                arr = (C.c_void_p * n)(*[r.ctypes.data for r in recs])
+                lens = (C.c_size_t * n)(*[r.size for r in recs])
+                keep += [recs, lens]
+                d.lens = C.addressof(lens)
+            keep.append(arr)
+            d.items = C.addressof(arr)
+        d.n = n
+        status = np.full(n, 0xFFFFFFFF, dtype=np.uint32)
+        stats = B.IngestStats()
+        if n:
+            B.check(B.lib().ss_verify_inputs(self.ctx, C.byref(d), status.ctypes.data, C.byref(stats)))
+        return status, {k: getattr(stats, k) for k, _ in B.IngestStats._fields_}
+
     def _ingest(self, fn, head_args, items, fmt):
         n = len(items)
         status = np.full(n, 0xFFFFFFFF, dtype=np.uint32)

@@ -4,12 +4,19 @@ Every status word must equal the oracle's -- not only accept/reject but the code
 failing assert.  Run on the GPU box with `pytest -m gpu`.
 """
 import ctypes as C
+import json
+import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
 
-from stark_symphony_amd import formats, verifier
+import stark_symphony_amd as ss
+from stark_symphony_amd import binding, formats, verifier
 from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 SEED = 0x5EED2025
@@ -930,3 +937,76 @@ def test_context_on_a_device_that_is_not_current(stwo_prod):
     got = v1.verify_stwo_records(stwo_prod.cfg, [verifier.stwo_record(p) for p in proofs])
     assert np.array_equal(got, want) and torch.cuda.current_device() == 0
     v1.close()
+
+
+def test_one_descriptor_entry_point_equals_the_named_ones(ver, tmp_path, s101_proof, stwo_prod):
+    """ss_verify_inputs (ABI 2.4, include/ss_verify.h section 4): every (form, source) pair through the ONE descriptor call
+    gives the status words of the oracle -- the same the named entry point of that pair gives (ss_verify_forms.h) --, and
+    combinations that do not exist are SS_ERR_ARG, not a verdict."""
+    cfg = stwo_prod.cfg
+    rng = np.random.default_rng(SEED + 400)
+    proofs = [stwo_prod] + [formats.stwo_corrupt(stwo_prod, rng)[0] for _ in range(6)]
+    want = O.stwo_verify_batch(proofs, O.MODE_FIXTURE).tolist()
+    recs = [verifier.stwo_record(p) for p in proofs]
+    # per-query records: host pointers, one pinned buffer
+    assert ver.verify_inputs("records", "host", recs, cfg=cfg)[0].tolist() == want == ver.verify_stwo_records(cfg, recs).tolist()
+    pin = ver.pinned_buffer(sum(r.size for r in recs))
+    pin[:] = np.concatenate(recs)
+    assert ver.verify_inputs("records", "pinned", cfg=cfg, blob=pin)[0].tolist() == want
+    # shared and minimal records of the proofs that have such a form
+    qs = formats.stwo_queries(stwo_prod)
+    for form, make in (("shared_records", lambda p: verifier.stwo_shared_record(p, qs)),
+                       ("minimal_records", lambda p: verifier.stwo_minimise_record(cfg, verifier.stwo_record(p), qs))):
+        have = []
+        for i, p in enumerate(proofs):
+            try:
+                have.append((i, make(p)))
+            except ValueError:
+                pass
+        assert have and have[0][0] == 0
+        got, _ = ver.verify_inputs(form, "host", [r for _, r in have], cfg=cfg)
+        assert got.tolist() == [want[i] for i, _ in have]
+        offs = np.zeros(len(have) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([r.size for _, r in have])
+        pin = ver.pinned_buffer(int(offs[-1]))
+        pin[:] = np.concatenate([r for _, r in have])
+        assert ver.verify_inputs(form, "pinned", cfg=cfg, blob=pin, offsets=offs)[0].tolist() == got.tolist()
+    # texts: host, pinned, files; a text that is no witness gets the stage-0 verdict on every route
+    texts = [ss.stwo_to_wit(p).encode() if i % 2 else json.dumps(ss.stwo_to_json(p), separators=(",", ":")).encode()
+             for i, p in enumerate(proofs)] + [b"not a witness"]
+    got, stats = ver.verify_inputs("text", "host", texts, cfg=cfg)
+    assert got.tolist() == want + [2] and stats["host_parsed"] == 1 and stats["text_bytes"] == sum(len(t) for t in texts)
+    blob, boffs, blens = ver.pinned_text_blob(texts)
+    assert ver.verify_inputs("text", "pinned", cfg=cfg, blob=blob, offsets=boffs, lengths=blens)[0].tolist() == want + [2]
+    paths = []
+    for i, t in enumerate(texts):
+        f = tmp_path / ("w%d.txt" % i)
+        f.write_bytes(t)
+        paths.append(str(f))
+    assert ver.verify_inputs("text", "files", paths + [str(tmp_path / "absent")], cfg=cfg)[0].tolist() == want + [2, 2]
+    # stark101: records of their shape, texts
+    d101 = [s101_proof] + [formats.stark101_corrupt(s101_proof, rng)[0] for _ in range(4)]
+    want101 = O.s101_verify_batch(d101).tolist()
+    ml, pm = verifier.s101_shape_of(d101)
+    got, _ = ver.verify_inputs("records", "host", [verifier.s101_record(p, ml, pm) for p in d101], shape=(ml, pm))
+    assert got.tolist() == want101 == ver.verify_stark101(d101).tolist()
+    t101 = [json.dumps(ss.stark101_to_json(p)).encode() for p in d101]
+    assert ver.verify_inputs("text", "host", t101)[0].tolist() == want101
+    # what does not exist is an argument error
+    for bad in (lambda: ver.verify_inputs("shared_records", "host", recs),                    # stark101 has no shared form
+                lambda: ver.verify_inputs("records", "files", paths, cfg=cfg)):               # files hold text
+        with pytest.raises(binding.SsError) as e:
+            bad()
+        assert e.value.code == binding.SS_ERR_ARG
+
+
+def test_verdicts_do_not_depend_on_the_hardware_queue_count():
+    """GPU_MAX_HW_QUEUES decides which streams share a hardware queue, i.e. what overlaps -- never a status word: the
+    multi-stream tests of this file (pipeline, independent streams, graph replay, two contexts / two threads) in a child
+    process that runs with the runtime's own default of 4 queues (the binding asks for 24: binding.process_defaults,
+    profiles/r06_hw_queues_sweep.txt), each three times."""
+    env = {k: v for k, v in os.environ.items() if k != "SS_KEEP_ENV"}
+    env["GPU_MAX_HW_QUEUES"] = "4"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu and streams", "--repeat-streams", "3",
+                        "-x", "-q", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0 and " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

@@ -45,13 +45,14 @@ if want host; then
     python tools/host_path_bench.py $n distinct >> $O/host_path.txt 2>&1
   done
 fi
-if want queues; then  # the library's load-time default of GPU_MAX_HW_QUEUES, from a C++ program that links it (csrc/ss_env.cpp)
+if want queues; then  # ss_process_defaults() from a C++ program that links the library (csrc/ss_env.cpp)
   mkdir -p build
   /opt/rocm/bin/hipcc -O2 --offload-arch=gfx950 -Iinclude tools/probes/hw_queues_probe.hip -o build/hw_queues_probe -Lstark-symphony_amd -lss_verify -Wl,-rpath,$R/stark-symphony_amd 2>/dev/null
   P="build/hw_queues_probe tests/golden/stark101_proof.json"
   ( unset GPU_MAX_HW_QUEUES
     for i in 1 2; do
-      echo -n "default (library sets it):        "; $P 2>&1 | grep -v amdgpu.ids
+      echo -n "ss_process_defaults() called:     "; $P 2>&1 | grep -v amdgpu.ids
+      echo -n "not called (runtime default):     "; $P nodefaults 2>&1 | grep -v amdgpu.ids
       echo -n "SS_KEEP_ENV=1 (runtime default):  "; SS_KEEP_ENV=1 $P 2>&1 | grep -v amdgpu.ids
       echo -n "caller sets GPU_MAX_HW_QUEUES=24: "; GPU_MAX_HW_QUEUES=24 $P 2>&1 | grep -v amdgpu.ids
     done ) > $O/hw_queues.txt 2>&1; ok queues

@@ -9,13 +9,12 @@ k=d['kernels_ms_per_step']
 print('%-44s %10.0f proofs/s  %8.3f ms/step  alu %.3f  merkle %.3f top %.3f' % (sys.argv[2], d['value'], d['ms_per_step'], d['alu_roofline']['frac'], k.get('stwo_merkle',0), k.get('stwo_top',0)))" "$@"; }
 T=$(mktemp -d)
 B="python bench.py --no-cpu-baseline --e2e 0 --distinct 16"
-for rep in 1 2; do
+for rep in 1; do
 for n in 65536 8192; do
   S=$([ $n = 65536 ] && echo 40 || echo 240)
   $B --proofs-per-gpu $n --steps $S --warmup 4 --tail-streams 1 > $T/o.json 2> $T/err && line $T/o.json "$n pipeline, 1 tail stream" || tail -3 $T/err
   $B --proofs-per-gpu $n --steps $S --warmup 4 --tail-streams 2 > $T/o.json 2> $T/err && line $T/o.json "$n pipeline, 2 tail streams" || tail -3 $T/err
-  $B --proofs-per-gpu $n --steps $S --warmup 4 --tail-streams 3 > $T/o.json 2> $T/err && line $T/o.json "$n pipeline, 3 tail streams" || tail -3 $T/err
-  for s in 2 3 4 6; do
+  for s in 2 3 4; do
     $B --proofs-per-gpu $n --steps $S --warmup 4 --graph streams --streams $s > $T/o.json 2> $T/err && line $T/o.json "$n whole passes on $s streams" || tail -3 $T/err
   done
 done

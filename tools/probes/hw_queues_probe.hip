@@ -1,7 +1,7 @@
-// Does the library's load-time default of GPU_MAX_HW_QUEUES (csrc/ss_env.cpp) reach the HIP runtime of a program that LINKS
-// the library (the C / Rust caller of INTEGRATION.md 3)?  16 stark101 passes of 4 096 proofs in flight, each on its own
-// stream, through the C ABI; run three times by tools/probes/hw_queues_probe.sh: nothing in the environment (the library's
-// constructor sets 24), SS_KEEP_ENV=1 (the runtime's default, 4), GPU_MAX_HW_QUEUES=24 set by the caller.
+// Does ss_process_defaults() (csrc/ss_env.cpp; an explicit call since ABI 2.4, a constructor before) reach the HIP runtime of a
+// program that LINKS the library (the C / Rust caller of INTEGRATION.md 3)?  16 stark101 passes of 4 096 proofs in flight, each
+// on its own stream, through the C ABI; run by tools/evidence.sh: the program calls ss_process_defaults() first (24), the same
+// with SS_KEEP_ENV=1 or with `nodefaults` as second argument (the runtime's default, 4), GPU_MAX_HW_QUEUES set by the caller.
 //   hipcc -O2 -Iinclude tools/probes/hw_queues_probe.hip -o build/hw_queues_probe -Lstark-symphony_amd -lss_verify -Wl,-rpath,$PWD/stark-symphony_amd
 #include <hip/hip_runtime.h>
 
@@ -20,7 +20,8 @@
 
 int main(int argc, char **argv)
 {
-    if (argc != 2) { fprintf(stderr, "usage: hw_queues_probe tests/golden/stark101_proof.json\n"); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: hw_queues_probe tests/golden/stark101_proof.json [nodefaults]\n"); return 2; }
+    if (argc < 3) ss_process_defaults();  // before the process's first HIP call
     std::ifstream f(argv[1]);
     std::stringstream ss;
     ss << f.rdbuf();
