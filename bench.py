@@ -548,10 +548,11 @@ def main() -> None:
     ap.add_argument("--e2e", type=int, default=4096,
                     help="proof.json / proof.wit texts for the end-to-end (text -> verdict) figures; 0 = skip")
     ap.add_argument("--tail-streams", type=int, default=0,
-                    help="streams the Merkle halves alternate over; 2: consecutive Merkle launches overlap at their edges "
-                         "(+6.6 %% at 8 192 proofs per GPU, +0.9 %% at 65 536: profiles/r03_tail_streams.txt) and the kernel "
-                         "durations for the roofline come from a separate non-overlapping pass.  0 = auto: 2 when a "
-                         "rank's share is below 32 768 proofs, else 1 (durations measured in the timed region itself)")
+                    help="streams the Merkle halves alternate over; 2: the Merkle stage of consecutive passes overlaps "
+                         "(+7 %% at 8 192 proofs per GPU, +1.6 %% at 65 536: profiles/r06_overlap_ab.txt) and the kernel "
+                         "durations for the roofline come from a separate non-overlapping pass.  0 = auto: 2 for stwo, "
+                         "1 for stark101 (whose small batches run on independent streams anyway); 1 = durations measured in "
+                         "the timed region itself")
     ap.add_argument("--graph", choices=["auto", "on", "off", "streams"], default="auto",
                     help="small batches (auto: stark101): 'streams' = whole passes on 16 independent streams, "
                          "'on' = hipGraph replay of independent slots; kernel durations for the roofline then "
@@ -685,7 +686,12 @@ def main() -> None:
     slots = [batch] + [batch.sibling() for _ in range(nslot - 1)]
     pipe = verifier.Pipeline(slots)
     if args.tail_streams == 0:
-        args.tail_streams = 2 if (family == "stwo" and n_local < 65536) else 1
+        # two tail streams: the Merkle stage of pass i + 1 fills the issue slots the top kernel of pass i leaves empty (its
+        # half-empty last turns and block barriers: 0.87 of the SHA roof alone) and the drain of every launch.  Measured on the
+        # metric batch 3.58 -> 3.64 M proofs/s, at 8 192 proofs per pass 3.24 -> 3.47 M; whole passes on 2-4 independent streams
+        # 3.59-3.61 M (profiles/r06_overlap_ab.txt).  Kernel durations measured under that overlap are not the kernels' own, so
+        # the roofline's come from a separate pass with one tail stream (same batch, same kernels, HIP events).
+        args.tail_streams = 2 if family == "stwo" else 1
     timed_pipe = verifier.Pipeline(slots, tail_streams=args.tail_streams) if args.tail_streams > 1 else pipe
     accs = [torch.zeros(1, dtype=torch.int32, device=ver.device) for _ in range(nslot)]
     acc = accs[0]
@@ -887,6 +893,14 @@ def main() -> None:
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_avg_ms": k_avg_s * 1e3, "kernel_launches": k_n,
+                         # the rate the timed region itself sustains: one launch of the stage completes every ms_per_step
+                         # (below the sum of the two kernels' own durations when consecutive launches overlap)
+                         "launch_period_ms": elapsed / args.steps * 1e3,
+                         "achieved_per_launch_period": launch_bytes / (elapsed / args.steps) / 1e9,
+                         "durations_from": ("a separate pass with one tail stream after the timed region (HIP events on the launch "
+                                            "stream): launches of the timed region overlap, a kernel's duration there is not its own")
+                         if (family == "stwo" and args.tail_streams > 1 and not streams and not graphed) else
+                         "HIP events on the launch stream",
                          "algorithmic_bytes_per_launch": launch_bytes,
                          "note": "integer-ALU bound by construction (2 SHA-256 / 1 Blake2s compression "
                                  "per 32-byte sibling); see alu_roofline"},
@@ -895,6 +909,9 @@ def main() -> None:
                                  compr_per_proof * n_local / k_avg_s if k_avg_s else 0.0,
                              "calibrated_peak_compressions_per_s": alu_peak,
                              "frac": compr_s / alu_peak,
+                             # the same over the WHOLE step (HEAD kernels, launch edges and all): compressions a pass executes
+                             # / ms_per_step -- what the timed region itself sustains against the calibrated roof
+                             "frac_of_step": executed * n_local / (elapsed / args.steps) / alu_peak,
                              # the absolute figure beside the calibrated one: VALU wave-instructions the Merkle stage issues
                              # (SQ_INSTS_VALU of the committed counter passes) x 2 cycles -- what a wave64 VALU operation
                              # occupies a SIMD for (MI355X_MICROARCH.md) -- over SIMD-cycles at the nominal clock

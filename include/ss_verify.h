@@ -72,7 +72,8 @@ size_t ss_abi_sizeof_shape(void);
  * share one, which is what callers keeping several passes in flight (section 3) must avoid; 24 is the smallest count
  * that holds every measured rate (profiles/r06_hw_queues_sweep.txt: stark101 x 4 096 on 16 streams 44.7 M proofs/s at
  * 4, 51 M at 16, 61 M at 24 and 32; one batch of 65 536 stwo proofs per pass does not depend on it).  Verdicts never
- * depend on it.  Returns the queue count now in the environment (0 = unset).  The Python binding calls it on import.  */
+ * depend on it.  Returns the queue count now in the environment (0 = unset).  The Python binding applies the same rule on
+ * import (in Python: loading this library before torch would bind the system's HIP runtime ahead of torch's).         */
 int ss_process_defaults(void);
 
 /* ============================================================================================= 2. proofs

@@ -13,21 +13,20 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libss_verify.so")
 
 def process_defaults() -> int:
-    """ss_process_defaults() (include/ss_verify.h): ask the HIP runtime for 24 hardware queues unless the caller's
-    environment already says otherwise (or SS_KEEP_ENV is set) -- streams that share one of the runtime's 4 default queues
-    serialise, which is what the pipelines here exist to avoid.  An explicit call since ABI 2.4 (the library no longer
-    touches the environment when it is loaded); this module makes it when it is IMPORTED, because the runtime reads the
-    variable once, at the process's first HIP call (torch's first CUDA call), and the library itself is loaded lazily.
-    Returns the queue count now in the environment (0 = unset).  Verdicts never depend on it."""
-    if os.path.exists(LIB_PATH):
-        n = int(C.CDLL(LIB_PATH).ss_process_defaults())
-    else:  # not built yet: lib() raises later; same rule meanwhile
-        if "SS_KEEP_ENV" not in os.environ:
-            os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
-        return int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0)
-    if n and "GPU_MAX_HW_QUEUES" not in os.environ:  # C setenv does not show in os.environ: mirror it for child processes and reports
-        os.environ["GPU_MAX_HW_QUEUES"] = str(n)
-    return n
+    """The rule of ss_process_defaults() (include/ss_verify.h, csrc/ss_env.cpp), stated in Python: ask the HIP runtime for
+    24 hardware queues unless the caller's environment already says otherwise (or SS_KEEP_ENV is set) -- streams that share
+    one of the runtime's 4 default queues serialise, which is what the pipelines here exist to avoid.  An explicit call
+    since ABI 2.4 (the library no longer touches the environment when it is loaded); this module makes it when it is
+    IMPORTED, because the runtime reads the variable once, at the process's first HIP call (torch's first CUDA call).
+    In Python and not through the library: loading libss_verify.so here, before torch is imported, would bind the
+    system's libamdhip64 ahead of the one torch ships, and torch then finds no GPU.  Returns the queue count now in the
+    environment (0 = unset).  Verdicts never depend on it."""
+    if "SS_KEEP_ENV" not in os.environ:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+    try:
+        return int(os.environ.get("GPU_MAX_HW_QUEUES", "0"))
+    except ValueError:
+        return 0
 
 
 process_defaults()
