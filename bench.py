@@ -46,7 +46,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E spec peak
 # The roof that actually binds: SHA-256 compressions/s of a register-only pair-hash chain on
 # the whole chip (tools/sha_bench.hip, measured on MI355X: 34.7 G/s; rotates are half-rate
-# v_alignbit_b32, see tools/valu_bench.hip and DESIGN.md section 5).
+# v_alignbit_b32, see tools/valu_bench.hip and DESIGN.md section 4).
 SHA_CALIBRATED_PEAK = 34.7e9
 B2S_CALIBRATED_PEAK = 38.9e9  # Blake2s-256 compressions/s, same tool (one compression per node)
 
@@ -54,7 +54,7 @@ B2S_CALIBRATED_PEAK = 38.9e9  # Blake2s-256 compressions/s, same tool (one compr
 # Workloads without a committed fixture (none at present): every proof of the batch is then made by the
 # GPU prover at start-up.  BASELINE.json configs[2] / configs[4] with the hash they name (Blake2s) have
 # fixtures since round 3 (tests/golden/stwo_trace16_blake2s.npz, stwo_wide256_blake2s.npz; parity unpinned,
-# DESIGN.md section 2) and `-m gpu` parity tests behind them.
+# DESIGN.md section 1) and `-m gpu` parity tests behind them.
 GEN_ONLY: dict = {}
 
 
@@ -543,8 +543,9 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--distinct", type=int, default=64,
                     help="distinct valid proofs in the batch (made by the GPU prover; 0 = fixtures only)")
-    ap.add_argument("--inflight", type=int, default=3,
-                    help="batch passes in flight (one HIP stream each)")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="batch passes in flight (one HIP stream each); 0 = auto: 3, or 6 when a rank's share is below 32 768 "
+                         "stwo proofs (with three tail streams: 3.47 -> 3.52 M proofs/s at 8 192, profiles/r06_overlap_ab.txt)")
     ap.add_argument("--e2e", type=int, default=4096,
                     help="proof.json / proof.wit texts for the end-to-end (text -> verdict) figures; 0 = skip")
     ap.add_argument("--tail-streams", type=int, default=0,
@@ -560,7 +561,7 @@ def main() -> None:
     ap.add_argument("--streams", type=int, default=16, help="independent streams of --graph streams")
     ap.add_argument("--top-checks", action="store_true",
                     help="SS_FLAG_TOP_CHECKS: the pair memoisation's byte compares run in the top kernel (the round-3 split); "
-                         "less HBM traffic, 2.5 %% more time (DESIGN.md 5)")
+                         "less HBM traffic, 2.5 %% more time (DESIGN.md 4)")
     ap.add_argument("--no-dedup", action="store_true",
                     help="SS_FLAG_NO_DEDUP: hash every query's Merkle path in full (A/B of the pair memoisation)")
     args = ap.parse_args()
@@ -682,6 +683,9 @@ def main() -> None:
     # `--inflight` run slots over the same resident batch, pipelined on a head and a tail stream:
     # the latency-bound transcript kernel of step i+1 overlaps the ALU-bound Merkle kernel of
     # step i; Merkle kernels themselves stay serialized on the tail stream.
+    small_share = family == "stwo" and n_local < 32768  # one GPU's share of the batch under strong scaling
+    if args.inflight == 0:
+        args.inflight = 6 if small_share else 3
     nslot = max(1, args.inflight)
     slots = [batch] + [batch.sibling() for _ in range(nslot - 1)]
     pipe = verifier.Pipeline(slots)
@@ -691,7 +695,8 @@ def main() -> None:
         # metric batch 3.58 -> 3.64 M proofs/s, at 8 192 proofs per pass 3.24 -> 3.47 M; whole passes on 2-4 independent streams
         # 3.59-3.61 M (profiles/r06_overlap_ab.txt).  Kernel durations measured under that overlap are not the kernels' own, so
         # the roofline's come from a separate pass with one tail stream (same batch, same kernels, HIP events).
-        args.tail_streams = 2 if family == "stwo" else 1
+        # (a small share -- a few milliseconds per pass -- gains from a third tail stream and six passes in flight; 65 536 does not)
+        args.tail_streams = (3 if small_share else 2) if family == "stwo" else 1
     timed_pipe = verifier.Pipeline(slots, tail_streams=args.tail_streams) if args.tail_streams > 1 else pipe
     accs = [torch.zeros(1, dtype=torch.int32, device=ver.device) for _ in range(nslot)]
     acc = accs[0]
@@ -868,7 +873,7 @@ def main() -> None:
                        "pair_memoisation": family == "stwo" and not args.no_dedup, "hash": hash_name,
                        # what "pinned" covers: leaf functions by the reference's 86 fn test_* KATs (oracle and
                        # device); end to end stark101 by the reference prover's proof, stwo by the reference's two shipped
-                       # proofs -- which only FIXTURE mode accepts (DESIGN.md 2: the .simf text rejects its own proofs)
+                       # proofs -- which only FIXTURE mode accepts (DESIGN.md 1: the .simf text rejects its own proofs)
                        "parity": "unpinned (Blake2s is not in the reference: RFC 7693 vectors + prover / oracle / GPU agreement)" if hash_name == "blake2s" else
                                  "pinned: SHA-256, stark101 verify_proof (86 reference KATs + the reference prover's proof)" if family != "stwo" else
                                  "pinned: SHA-256, FIXTURE mode (86 reference KATs + 3 reference proofs); LITERAL mode by the .simf text only",

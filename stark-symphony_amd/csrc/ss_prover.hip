@@ -557,7 +557,7 @@ __global__ void p_merkle_level_kernel(size_t n_parents, const uint32_t *__restri
 
 // The last levels of a tree (n <= 512 nodes -> the root) by ONE block: a level with at most 256 parents is one wavefront per
 // SIMD of a CU, i.e. one pair hash of latency, which is what a launch of its own takes too -- minus the launch.  Levels above
-// stay launches: a single CU hashes them slower than the chip does (DESIGN.md 8).  levels: the n nodes, then their parents...
+// stay launches: a single CU hashes them slower than the chip does (DESIGN.md 7).  levels: the n nodes, then their parents...
 template <int HF>
 __global__ void __launch_bounds__(256) p_merkle_tail_kernel(uint32_t n, uint32_t *levels)
 {

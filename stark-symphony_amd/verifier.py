@@ -1213,7 +1213,7 @@ class Verifier:
         """Files -> verdicts with no staging threads: every file is read (`readinto`) straight into ONE page-locked buffer,
         each at a multiple of 16, and ss_stwo_verify_texts_pinned lets the DMA engine fetch the texts from there.  What a rank
         of an 8-GPU host should call (distributed.files_verifier): the staged ss_stwo_verify_files needs about eight host
-        threads to feed the link and a rank of eight has two (DESIGN.md 7).  A file that cannot be read gets
+        threads to feed the link and a rank of eight has two (DESIGN.md 6).  A file that cannot be read gets
         SS_STATUS_MALFORMED like in ss_stwo_verify_files (simfony-cli/src/main.rs:187-190: a witness that cannot be loaded is
         exit 1, not a crash).  -> (status, stats)."""
         paths = [str(p) for p in paths]

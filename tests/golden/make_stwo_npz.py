@@ -5,7 +5,7 @@
 
 Proofs come from tools/stwo_prover.py, the numpy restatement of the external stwo prover that
 reproduces the reference's own two proofs byte for byte (tests/test_prover.py).  The reference has
-no Blake2s, so the *_blake2s fixtures are parity-unpinned by construction (DESIGN.md section 2)."""
+no Blake2s, so the *_blake2s fixtures are parity-unpinned by construction (DESIGN.md section 1)."""
 import os
 import sys
 

@@ -228,7 +228,7 @@ def _check_multi_rank_line(d: dict, n: int, backend: str) -> None:
 def test_two_ranks_on_one_gpu_over_nccl_or_the_documented_refusal():
     """`bench.py --gpus 2 --scaling strong` with BOTH ranks on the one GPU of the test box over the nccl backend.  RCCL
     either accepts two communicator ranks on one device -- then the line is checked like the first real multi-GPU run
-    will be -- or refuses them ("Duplicate GPU detected", ncclInvalidUsage: what DESIGN.md section 7 documents), in which
+    will be -- or refuses them ("Duplicate GPU detected", ncclInvalidUsage: what DESIGN.md section 6 documents), in which
     case the launcher must report that rank's own words and the same command over gloo must work."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(SS_BENCH_SHARE_GPU="1", SS_BENCH_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")

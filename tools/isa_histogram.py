@@ -5,7 +5,7 @@
 
 Compiles stark-symphony_amd/csrc/ss_stwo.hip with `--cuda-device-only -S` (no GPU needed) and counts
 mnemonics.  The "loop" of the Merkle kernels is one sibling level of 64 chains: the basic blocks
-between the backward branch's target label and the branch.  DESIGN.md section 5 quotes these counts."""
+between the backward branch's target label and the branch.  DESIGN.md section 4 quotes these counts."""
 import collections
 import os
 import re

@@ -65,6 +65,7 @@ if want("bench") and os.path.exists(os.path.join(G, "bench_default.json")):
     json.dump(last_json(os.path.join(G, "bench_default.json")), open(os.path.join(P, TAG + "_default_bench.json"), "w"))
 if want("stats"):
     copy(one("stats/*/*_kernel_stats.csv"), "default_kernel_stats.csv")
+    copy(one("stats_ts1/*/*_kernel_stats.csv"), "ts1_kernel_stats.csv")  # one tail stream: the kernels' own durations (the roofline's)
     copy(one("stats_e2e/*/*_kernel_stats.csv"), "e2e_kernel_stats.csv")
     copy(one("stats_prover/*/*_kernel_stats.csv"), "prover_kernel_stats.csv")
 have_pmc = want("pmc") and all(one(d + "/*/*_counter_collection.csv") for d in ("pmc_valu", "pmc_wait", "pmc_fetch", "pmc_write"))
@@ -136,7 +137,7 @@ for f in sorted(glob.glob(os.path.join(G, "bench_*.json"))) if want("bench") els
 if lines:
     json.dump({"note": "one bench.py JSON line per configuration (tools/evidence.sh, sections bench + configs), each stamped with the commit it was "
                        "measured at; *_nodedup = SS_FLAG_NO_DEDUP (every path hashed in full); *_8192 = one GPU's share of the 65 536-proof batch "
-                       "split over 8 (--proofs-per-gpu 8192; _ts1 = one Merkle stream, default = two)",
+                       "split over 8 (--proofs-per-gpu 8192); _ts1 = one tail stream (round 5's submission), default = two (three below 32 768 proofs per rank)",
                "lines": lines}, open(os.path.join(P, TAG + "_bench_configs.json"), "w"), indent=1)
 e2e = {}
 for f in sorted(glob.glob(os.path.join(G, "e2e_*.json"))) if want("e2e") else []:
