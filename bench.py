@@ -255,6 +255,11 @@ def end_to_end(ver, proofs, n: int, rank: int = 0, world: int = 1, dist=None):
            "parity": "json / wit / records are the forms the reference's adapters emit (generate_wit.py:106-245): pinned as the "
                      "bench line says; json_shared, shared_records, minimal_records, json_minimal have no bytes in the reference: "
                      "unpinned, held to the per-query record they expand to"}
+    # which rows a caller on this host should read: with fewer than 8 host threads per rank (every rank of an 8-GPU node on a
+    # 16-core grant) the staged entry points cannot feed the link and distributed.files_verifier / use_pinned_inputs pick the
+    # caller-pinned ones (the *_pinned rows); a process that owns the host may use either
+    out["rows_for_this_host"] = {"ranks": world, "host_threads_per_rank": distributed.host_threads_per_rank(world),
+                                 "use": "*_pinned" if distributed.use_pinned_inputs(world) else "staged or *_pinned"}
     if world > 1:
         out["ranks"] = world
         out["host_threads_per_rank"] = int(os.environ.get("SS_HOST_THREADS", "0")) or None

@@ -51,6 +51,11 @@ def test_integration_md_python_calls(tmp_path):
     blob, boffs, blens = ver.pinned_text_blob([a.read_bytes(), b.read_bytes()])
     status, stats = ver.verify_stwo_texts_pinned(p.cfg, blob, boffs, blens)
     assert status.tolist() == [0, 0]
+    # section 4: rank-local file ingest through the entry point the rank's host-thread budget calls for (one rank here)
+    from stark_symphony_amd import distributed
+    local, accepted, total = distributed.verify_files_sharded([str(a), str(b)], distributed.files_verifier(ver, ss.PRODUCTION_CONFIG))
+    assert local.tolist() == [0, 0] and (accepted, total) == (2, 2)
+    assert distributed.files_verifier(ver, ss.PRODUCTION_CONFIG, world=8)([str(a), str(b)]).tolist() == [0, 0]   # the pinned route
     # resident batches, pipelined; the accept reduce hook; a hipGraph replay
     batch = ver.stwo_batch([p, bad])
     pipe = verifier.Pipeline([batch, batch.sibling(), batch.sibling()])
