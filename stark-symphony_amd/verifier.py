@@ -1118,6 +1118,8 @@ class Verifier:
                 keep.append(offs)
                 d.offs = offs.ctypes.data
                 n = offs.size - 1
+            elif cfg is None or form != "records":
+                raise ValueError("a pinned buffer needs n + 1 offsets (only stwo per-query records have a fixed stride)")
             else:
                 n = blob.view(np.uint32).size // B.lib().ss_stwo_record_words(C.byref(cs))
             if lengths is not None:
