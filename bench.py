@@ -549,8 +549,9 @@ def main() -> None:
     ap.add_argument("--distinct", type=int, default=64,
                     help="distinct valid proofs in the batch (made by the GPU prover; 0 = fixtures only)")
     ap.add_argument("--inflight", type=int, default=0,
-                    help="batch passes in flight (one HIP stream each); 0 = auto: 3, or 6 when a rank's share is below 32 768 "
-                         "stwo proofs (with three tail streams: 3.47 -> 3.52 M proofs/s at 8 192, profiles/r06_overlap_ab.txt)")
+                    help="batch passes in flight (one HIP stream each); 0 = auto: 3, or 6 when a single process verifies fewer than "
+                         "32 768 stwo proofs per pass (with three tail streams: 3.47 -> 3.52 M proofs/s at 8 192; not with a per-step "
+                         "collective: profiles/r06_overlap_ab.txt)")
     ap.add_argument("--e2e", type=int, default=4096,
                     help="proof.json / proof.wit texts for the end-to-end (text -> verdict) figures; 0 = skip")
     ap.add_argument("--tail-streams", type=int, default=0,
@@ -688,7 +689,11 @@ def main() -> None:
     # `--inflight` run slots over the same resident batch, pipelined on a head and a tail stream:
     # the latency-bound transcript kernel of step i+1 overlaps the ALU-bound Merkle kernel of
     # step i; Merkle kernels themselves stay serialized on the tail stream.
-    small_share = family == "stwo" and n_local < 32768  # one GPU's share of the batch under strong scaling
+    # one GPU's share of the batch under strong scaling, verified WITHOUT a per-step collective: six passes in flight on three tail
+    # streams fill the chip best (3.47 -> 3.52-3.55 M proofs/s at 8 192).  With the accept reduce on the slots' head streams the
+    # same setting loses (2.98 M against 3.43 M with three passes / two tail streams, one-rank RCCL group: collectives of one
+    # communicator complete in issue order, which chains six head streams to each other) -- so ranks of a group keep 3 / 2.
+    small_share = family == "stwo" and n_local < 32768 and not grouped
     if args.inflight == 0:
         args.inflight = 6 if small_share else 3
     nslot = max(1, args.inflight)
