@@ -549,9 +549,8 @@ def main() -> None:
     ap.add_argument("--distinct", type=int, default=64,
                     help="distinct valid proofs in the batch (made by the GPU prover; 0 = fixtures only)")
     ap.add_argument("--inflight", type=int, default=0,
-                    help="batch passes in flight (one HIP stream each); 0 = auto: 3, or 6 when a single process verifies fewer than "
-                         "32 768 stwo proofs per pass (with three tail streams: 3.47 -> 3.52 M proofs/s at 8 192; not with a per-step "
-                         "collective: profiles/r06_overlap_ab.txt)")
+                    help="batch passes in flight (one HIP stream each); 0 = auto: 3, or 4 (with three tail streams) when a rank's "
+                         "share is below 32 768 stwo proofs per pass: profiles/r06_overlap_ab.txt")
     ap.add_argument("--e2e", type=int, default=4096,
                     help="proof.json / proof.wit texts for the end-to-end (text -> verdict) figures; 0 = skip")
     ap.add_argument("--tail-streams", type=int, default=0,
@@ -689,13 +688,13 @@ def main() -> None:
     # `--inflight` run slots over the same resident batch, pipelined on a head and a tail stream:
     # the latency-bound transcript kernel of step i+1 overlaps the ALU-bound Merkle kernel of
     # step i; Merkle kernels themselves stay serialized on the tail stream.
-    # one GPU's share of the batch under strong scaling, verified WITHOUT a per-step collective: six passes in flight on three tail
-    # streams fill the chip best (3.47 -> 3.52-3.55 M proofs/s at 8 192).  With the accept reduce on the slots' head streams the
-    # same setting loses (2.98 M against 3.43 M with three passes / two tail streams, one-rank RCCL group: collectives of one
-    # communicator complete in issue order, which chains six head streams to each other) -- so ranks of a group keep 3 / 2.
-    small_share = family == "stwo" and n_local < 32768 and not grouped
+    # one GPU's share of the batch under strong scaling: a few milliseconds per pass.  Three tail streams and FOUR passes in
+    # flight hold both ways it runs (profiles/r06_overlap_ab.txt): alone 3.50 M proofs/s (2 / 3: 3.47; 3 / 6: 3.52), with the
+    # per-step accept reduce through RCCL on the slots' head streams 3.48 M (2 / 3: 3.43) -- where SIX passes lose (2.98 M):
+    # collectives of one communicator complete in issue order, which chains the head streams to each other.
+    small_share = family == "stwo" and n_local < 32768
     if args.inflight == 0:
-        args.inflight = 6 if small_share else 3
+        args.inflight = 4 if small_share else 3
     nslot = max(1, args.inflight)
     slots = [batch] + [batch.sibling() for _ in range(nslot - 1)]
     pipe = verifier.Pipeline(slots)
@@ -705,7 +704,7 @@ def main() -> None:
         # metric batch 3.58 -> 3.64 M proofs/s, at 8 192 proofs per pass 3.24 -> 3.47 M; whole passes on 2-4 independent streams
         # 3.59-3.61 M (profiles/r06_overlap_ab.txt).  Kernel durations measured under that overlap are not the kernels' own, so
         # the roofline's come from a separate pass with one tail stream (same batch, same kernels, HIP events).
-        # (a small share -- a few milliseconds per pass -- gains from a third tail stream and six passes in flight; 65 536 does not)
+        # (a small share -- a few milliseconds per pass -- gains from a third tail stream and a fourth pass in flight; 65 536 does not)
         args.tail_streams = (3 if small_share else 2) if family == "stwo" else 1
     timed_pipe = verifier.Pipeline(slots, tail_streams=args.tail_streams) if args.tail_streams > 1 else pipe
     accs = [torch.zeros(1, dtype=torch.int32, device=ver.device) for _ in range(nslot)]
