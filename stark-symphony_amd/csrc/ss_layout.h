@@ -86,7 +86,11 @@ struct StwoLayout {
 
 constexpr uint32_t kTopChains = 256;     // chains a top-kernel block plans at once (= its threads)
 constexpr uint32_t kTopMaxT = 8;         // ceil_log2(kMaxQueries) + 2 >= T
-constexpr uint32_t kTopMinGroups = 1024;  // a smaller batch is cut into smaller groups until it gives this many
+#ifndef SS_TOP_MIN_GROUPS
+#define SS_TOP_MIN_GROUPS 512  // A/B at 512 / 1 024 / 2 048 (profiles/r06_top_min_groups_ab.txt): 8 192 proofs verify 1 % faster in 512 groups of
+                               // 16 proofs on 512 blocks (fuller plans; the free block slots go to the next pass's merkle kernel) than in 1 024 of 8
+#endif
+constexpr uint32_t kTopMinGroups = SS_TOP_MIN_GROUPS;  // a smaller batch is cut into smaller groups until it gives this many
 // workspace slices of the persistent top kernel.  The launch uses min(groups, blocks resident at once), and at
 // 256 threads and >= 123 VGPRs per lane at most 4 blocks fit a CU (3 for SHA-256): 1024 on the 256 CUs of an MI355X.
 constexpr uint32_t kTopMaxBlocks = 1024;
@@ -186,8 +190,8 @@ SS_HD inline StwoLayout stwo_layout(uint32_t N, uint32_t TL, uint32_t L, uint32_
     y.ws_alpha = w; w += (uint64_t)y.n_pow * 4 * y.np;
     y.ws_leaf = w;  w += (uint64_t)(K + 1) * 8 * y.nip;
     y.top_G = kTopChains / Q;  // Q <= kMaxQueries = 64
-    // a batch that gives fewer groups than the ~1024 blocks the chip holds at once (4 per CU) is cut
-    // into smaller groups: half-empty plans cost less than half-empty CUs
+    // a batch that gives fewer groups than kTopMinGroups (two per CU) is cut into smaller groups: half-empty plans cost less
+    // than idle CUs -- but not less than blocks the overlapping next pass could have used, hence 512 and not the 768-1 024 resident slots
     while (y.top_G > 1 && (n + y.top_G - 1) / y.top_G < min_groups) y.top_G = (y.top_G + 1) / 2;
     const uint64_t groups = (n + y.top_G - 1) / y.top_G;
     y.top_blocks = y.T ? (uint32_t)(groups < kTopMaxBlocks ? groups : kTopMaxBlocks) : 0;
