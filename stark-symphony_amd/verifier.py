@@ -1211,9 +1211,10 @@ class Verifier:
         return self._ingest(B.lib().ss_stwo_verify_files, (C.byref(cs),), [str(p) for p in paths], fmt)
 
     def verify_stwo_files_pinned(self, cfg: StwoConfig, paths: Sequence[str], mode: int = MODE_FIXTURE,
-                                 fmt: int = B.TEXT_AUTO):
-        """Files -> verdicts with no staging threads: every file is read (`readinto`) straight into ONE page-locked buffer,
-        each at a multiple of 16, and ss_stwo_verify_texts_pinned lets the DMA engine fetch the texts from there.  What a rank
+                                 fmt: int = B.TEXT_AUTO, chunk_bytes: int = 1 << 30):
+        """Files -> verdicts with no staging threads: the files are read (`readinto`) straight into ONE page-locked buffer,
+        each at a multiple of 16, and ss_stwo_verify_texts_pinned lets the DMA engine fetch the texts from there -- `chunk_bytes`
+        of files at a time (1 GiB: the buffer is allocated once and reused, so a rank never pins more than that).  What a rank
         of an 8-GPU host should call (distributed.files_verifier): the staged ss_stwo_verify_files needs about eight host
         threads to feed the link and a rank of eight has two.  A file that cannot be read gets
         SS_STATUS_MALFORMED like in ss_stwo_verify_files (simfony-cli/src/main.rs:187-190: a witness that cannot be loaded is
@@ -1225,25 +1226,42 @@ class Verifier:
                 sizes.append(os.path.getsize(p))
             except OSError:
                 sizes.append(0)
-        lens = np.array(sizes, dtype=np.uint64)
-        offs = np.zeros(len(paths) + 1, dtype=np.uint64)
-        offs[1:] = np.cumsum((lens + np.uint64(15)) & ~np.uint64(15))
-        blob = self.pinned_buffer((int(offs[-1]) + 3) // 4 + 4).view(np.uint8)
-        for i, p in enumerate(paths):
-            got = 0
-            if sizes[i]:
-                try:
-                    with open(p, "rb", buffering=0) as f:
-                        view = memoryview(blob)[int(offs[i]):int(offs[i]) + sizes[i]]
-                        while got < sizes[i]:
-                            k = f.readinto(view[got:])
-                            if not k:
-                                break
-                            got += k
-                except OSError:
-                    got = 0
-            lens[i] = got if got == sizes[i] else 0  # an empty text is no witness: SS_STATUS_MALFORMED
-        return self.verify_stwo_texts_pinned(cfg, blob, offs, lens, mode, fmt)
+        status = np.full(len(paths), 0xFFFFFFFF, dtype=np.uint32)
+        total = {k: 0 for k, _ in B.IngestStats._fields_}
+        padded = [(n + 15) & ~15 for n in sizes]
+        cap = max([chunk_bytes] + padded)  # (a single file larger than the chunk still goes through, alone)
+        blob, lo = None, 0
+        while lo < len(paths):
+            hi, used = lo, 0
+            while hi < len(paths) and (hi == lo or used + padded[hi] <= cap):
+                used += padded[hi]
+                hi += 1
+            if blob is None:  # sized for the largest chunk there will be: this one unless a later single file is larger
+                blob = self.pinned_buffer(min(cap, max(sum(padded), 16)) // 4 + 4).view(np.uint8)
+            lens = np.zeros(hi - lo, dtype=np.uint64)
+            offs = np.zeros(hi - lo + 1, dtype=np.uint64)
+            offs[1:] = np.cumsum(padded[lo:hi])
+            for i in range(lo, hi):
+                got = 0
+                if sizes[i]:
+                    try:
+                        with open(paths[i], "rb", buffering=0) as f:
+                            o = int(offs[i - lo])
+                            view = memoryview(blob)[o:o + sizes[i]]
+                            while got < sizes[i]:
+                                k = f.readinto(view[got:])
+                                if not k:
+                                    break
+                                got += k
+                    except OSError:
+                        got = 0
+                lens[i - lo] = got if got == sizes[i] else 0  # an empty text is no witness: SS_STATUS_MALFORMED
+            st, stats = self.verify_stwo_texts_pinned(cfg, blob, offs, lens, mode, fmt)
+            status[lo:hi] = st
+            for k, v in stats.items():
+                total[k] = max(total[k], v) if k == "threads" else total[k] + v
+            lo = hi
+        return status, total
 
     def verify_stark101_texts(self, texts: Sequence[bytes], fmt: int = B.TEXT_AUTO):
         return self._ingest(B.lib().ss_s101_verify_texts, (), list(texts), fmt)

@@ -146,6 +146,8 @@ def test_verify_texts_mixed_batch_and_chunking(ver, tmp_path):
     empty.write_bytes(b"")
     pstatus, pstats = ver.verify_stwo_files_pinned(cfg, paths + [str(empty)])
     assert pstatus.tolist() == want[:12] + [2, 2] and pstats["host_parsed"] == stats["host_parsed"] + 1
+    cstatus, cstats = ver.verify_stwo_files_pinned(cfg, paths + [str(empty)], chunk_bytes=200_000)   # several chunks, one buffer
+    assert cstatus.tolist() == pstatus.tolist() and cstats["text_bytes"] == pstats["text_bytes"]
     from stark_symphony_amd import distributed
     for world in (1, 8):
         assert distributed.files_verifier(ver, cfg, world=world)(paths).tolist() == want[:12] + [2]
