@@ -14,6 +14,13 @@ config, BASELINE.json configs[3]: "batch of 65536 proofs sharded across 8 x MI35
 on the one GPU at N = 1.  `--scaling weak`: every rank owns its own `--proofs-per-gpu` batch
 (65 536 by default), total work grows with N.  The JSON line says which.
 
+Submission (round 6): K steps are K passes of the HEAD / TAIL pipeline (verifier.Pipeline) with the TAIL halves
+alternating over two streams -- three, with four passes in flight, when a rank's share is below 32 768 proofs -- so that
+the Merkle stage of consecutive passes overlaps.  `value` and `ms_per_step` come from that timed region; a kernel's
+duration is not its own under overlap, so the durations behind `roofline` / `alu_roofline.frac` are measured by HIP events
+in a pass with ONE tail stream right after it (`roofline.durations_from`), and `roofline.launch_period_ms` /
+`alu_roofline.frac_of_step` give the timed region's own figures beside them.  `--tail-streams 1` is round 5's submission.
+
 Workloads (`--workload`):
   stwo_2p20      2^20-row wide-Fibonacci trace, blowup 2^4 (LDE 2^24), 16 queries, 19 inner FRI
                  layers, SHA-256 -- BASELINE.json configs[3], the configuration the metric is
