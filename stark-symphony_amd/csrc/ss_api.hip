@@ -290,11 +290,10 @@ extern "C" int ss_stwo_verify_phase_dev(ss_ctx *ctx, const ss_stwo_cfg *c, size_
     uint32_t *ws = (uint32_t *)workspace;
     Timer t(ctx, s);
     if (phases & SS_PHASE_HEAD) {
-        HIP_TRY(hipMemsetAsync(status, 0xff, n * 4, s));
-        if (accept_count) HIP_TRY(hipMemsetAsync(accept_count, 0, 4, s));
+        // (the transcript kernel resets the pass's status words and accept count itself: no memset dispatches)
         t.begin();
         hipLaunchKernelGGL(c->hash == SS_HASH_BLAKE2S ? stwo_transcript_kernel_b2s : stwo_transcript_kernel_sha,
-                           dim3((y.n + 63) / 64), dim3(64), 0, s, y, batch, ws, status);
+                           dim3((y.n + 63) / 64), dim3(64), 0, s, y, batch, ws, status, accept_count, 1u);
         t.end("stwo_transcript");
         t.begin();
         hipLaunchKernelGGL(stwo_query_kernel, dim3((y.ni + 63) / 64), dim3(64), 2 * (y.K + 3) * 64 * 4, s, y, batch,
@@ -375,10 +374,9 @@ extern "C" int ss_s101_verify_phase_dev(ss_ctx *ctx, const ss_s101_shape *sh, si
     uint32_t *ws = (uint32_t *)workspace;
     Timer t(ctx, s);
     if (phases & SS_PHASE_HEAD) {
-        HIP_TRY(hipMemsetAsync(status, 0xff, n * 4, s));
-        if (accept_count) HIP_TRY(hipMemsetAsync(accept_count, 0, 4, s));
+        // (the transcript kernel resets the pass's status words and accept count itself: no memset dispatches)
         t.begin();
-        hipLaunchKernelGGL(s101_transcript_kernel, dim3((y.n + 63) / 64), dim3(64), 0, s, y, batch, ws, status);
+        hipLaunchKernelGGL(s101_transcript_kernel, dim3((y.n + 63) / 64), dim3(64), 0, s, y, batch, ws, status, accept_count);
         t.end("s101_transcript");
     }
     if (phases & SS_PHASE_TAIL) {

@@ -213,7 +213,7 @@ int stwo_minimal_head(ss_ctx *ctx, const ss_stwo_cfg *c, const StwoLayout &y, co
     t.end("stwo_min_head");
     t.begin();
     hipLaunchKernelGGL(c->hash == SS_HASH_BLAKE2S ? stwo_transcript_kernel_b2s : stwo_transcript_kernel_sha,
-                       dim3((y.n + 63) / 64), dim3(64), 0, s, y, (const uint32_t *)batch, ws, status);
+                       dim3((y.n + 63) / 64), dim3(64), 0, s, y, (const uint32_t *)batch, ws, status, (uint32_t *)nullptr, 0u);  // (reset by the caller: stwo_min_head may have written verdicts)
     t.end("stwo_transcript");
     t.begin();
     hipLaunchKernelGGL(stwo_min_expand_kernel, dim3(y.n), dim3(256), 0, s, y, a, batch, ws, status);

@@ -23,7 +23,7 @@ namespace ss {
 
 __global__ void __launch_bounds__(64)
 s101_transcript_kernel(S101Layout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,
-                       uint32_t *__restrict__ status)
+                       uint32_t *__restrict__ status, uint32_t *__restrict__ accept_count)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= lay.n) return;
@@ -115,7 +115,10 @@ s101_transcript_kernel(S101Layout lay, const uint32_t *__restrict__ batch, uint3
     }
     INT(5 + nl, cur);
     if (cur != last) FAIL(s101_code(5, 0));
-    if (fail != 0xffffffffu) atomicMin(&status[p], fail);
+    // the first kernel of a pass: it also RESETS the pass's status words and accept count (no memset dispatches: a stark101 x
+    // 4 096 pass is 60 us, each memset in front of it cost 6 %, profiles/r06_reset_in_kernel_ab.txt)
+    status[p] = fail;
+    if (p == 0 && accept_count) *accept_count = 0;
 }
 
 __device__ __forceinline__ uint32_t jet_div(uint32_t a, uint32_t b) { return b ? a / b : 0; }

@@ -34,7 +34,8 @@ namespace ss {
 // ========================================================================== transcript
 template <int HF>
 __device__ __forceinline__ void stwo_transcript_body(const StwoLayout &lay, const uint32_t *__restrict__ batch,
-                                                     uint32_t *__restrict__ ws, uint32_t *__restrict__ status)
+                                                     uint32_t *__restrict__ ws, uint32_t *__restrict__ status,
+                                                     uint32_t *__restrict__ accept_count, uint32_t reset)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= lay.n) return;
@@ -266,20 +267,29 @@ __device__ __forceinline__ void stwo_transcript_body(const StwoLayout &lay, cons
             CQ(lay.c_m1, alpha_i);  // alpha^(N+17), fri/answers.simf:126
         }
     }
-    if (fail != 0xffffffffu) atomicMin(&status[p], fail);
+    // `reset`: this kernel is the first of the pass that touches the status words, so it also RESETS them -- status[p] =
+    // "no assert failed yet" or this lane's code, the accept count = 0 -- which saves the pass two memset dispatches (worth
+    // 6 % each where a pass is 60 us: stark101 x 4 096 on 16 streams, profiles/r06_reset_in_kernel_ab.txt).  Behind minimal
+    // records an earlier kernel has already written verdicts (reset = 0: the caller has reset, codes go through atomicMin).
+    if (reset) {
+        status[p] = fail;
+        if (p == 0 && accept_count) *accept_count = 0;
+    } else if (fail != 0xffffffffu) {
+        atomicMin(&status[p], fail);
+    }
 }
 
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 stwo_transcript_kernel_sha(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,
-                           uint32_t *__restrict__ status)
+                           uint32_t *__restrict__ status, uint32_t *__restrict__ accept_count, uint32_t reset)
 {
-    stwo_transcript_body<0>(lay, batch, ws, status);
+    stwo_transcript_body<0>(lay, batch, ws, status, accept_count, reset);
 }
 __global__ void __launch_bounds__(64)
 stwo_transcript_kernel_b2s(StwoLayout lay, const uint32_t *__restrict__ batch, uint32_t *__restrict__ ws,
-                           uint32_t *__restrict__ status)
+                           uint32_t *__restrict__ status, uint32_t *__restrict__ accept_count, uint32_t reset)
 {
-    stwo_transcript_body<1>(lay, batch, ws, status);
+    stwo_transcript_body<1>(lay, batch, ws, status, accept_count, reset);
 }
 
 // =============================================================================== query
