@@ -61,7 +61,7 @@ def test_bench_two_ranks_share_one_gpu():
     assert e["shared_records"]["bytes_per_proof"] < e["records"]["bytes_per_proof"]
 
 
-@pytest.mark.parametrize("n", [2, 4])  # the pytest process + 4 ranks: the GPU box allows 6 processes on its card
+@pytest.mark.parametrize("n", [2, pytest.param(4, marks=pytest.mark.launcher_extra)])  # the pytest process + 4 ranks: the GPU box allows 6 processes on its card
 def test_bench_spawns_its_own_ranks(n):
     """`python bench.py --gpus N` exactly as the scaling driver may type it (no torchrun, no WORLD_SIZE):
     the process turns into a launcher before touching torch / HIP, starts N ranks, relays rank 0's
@@ -77,7 +77,7 @@ def test_bench_spawns_its_own_ranks(n):
     assert abs(d["value"] - n * 256 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
 
 
-@pytest.mark.parametrize("n,batch", [(2, 1024), (3, 1000)])
+@pytest.mark.parametrize("n,batch", [(2, 1024), pytest.param(3, 1000, marks=pytest.mark.launcher_extra)])
 def test_bench_strong_scaling_splits_one_batch(n, batch):
     """--scaling strong (the default): ONE batch of --batch proofs split shard_range-wise over the ranks
     (BASELINE.json configs[3]: 65 536 proofs over 8 GPUs); value counts the batch once per step.  An
@@ -225,6 +225,7 @@ def _check_multi_rank_line(d: dict, n: int, backend: str) -> None:
     assert e["minimal_records"]["bytes_per_proof"] < e["shared_records"]["bytes_per_proof"] < e["records"]["bytes_per_proof"]
 
 
+@pytest.mark.launcher_extra
 def test_two_ranks_on_one_gpu_over_nccl_or_the_documented_refusal():
     """`bench.py --gpus 2 --scaling strong` with BOTH ranks on the one GPU of the test box over the nccl backend.  RCCL
     either accepts two communicator ranks on one device -- then the line is checked like the first real multi-GPU run
@@ -255,7 +256,7 @@ def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
     assert r.returncode != 0 and "disagrees" in r.stderr
 
 
-@pytest.mark.parametrize("how,label", [("auto", "independent streams"), ("on", "hipGraph")])
+@pytest.mark.parametrize("how,label", [("auto", "independent streams"), pytest.param("on", "hipGraph", marks=pytest.mark.launcher_extra)])
 def test_bench_stark101_small_batch_submission(how, label):
     """BASELINE.json configs[1] (stark101 x 4096) cannot fill the chip with one pass: bench.py overlaps
     whole passes (16 independent streams by default, hipGraph replay with --graph on) for the timed
