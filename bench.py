@@ -18,7 +18,7 @@ Submission (round 6): K steps are K passes of the HEAD / TAIL pipeline (verifier
 alternating over two streams -- three, with four passes in flight, when a rank's share is below 32 768 proofs -- so that
 the Merkle stage of consecutive passes overlaps.  `value` and `ms_per_step` come from that timed region; a kernel's
 duration is not its own under overlap, so the durations behind `roofline` / `alu_roofline.frac` are measured by HIP events
-in a pass with ONE tail stream right after it (`roofline.durations_from`), and `roofline.launch_period_ms` /
+in a pass through a ONE-slot pipeline right after it, where nothing overlaps (`roofline.durations_from`), and `roofline.launch_period_ms` /
 `alu_roofline.frac_of_step` give the timed region's own figures beside them.  `--tail-streams 1` is round 5's submission.
 
 Workloads (`--workload`):
@@ -710,7 +710,7 @@ def main() -> None:
         # half-empty last turns and block barriers: 0.87 of the SHA roof alone) and the drain of every launch.  Measured on the
         # metric batch 3.58 -> 3.64 M proofs/s, at 8 192 proofs per pass 3.24 -> 3.47 M; whole passes on 2-4 independent streams
         # 3.59-3.61 M (profiles/r06_overlap_ab.txt).  Kernel durations measured under that overlap are not the kernels' own, so
-        # the roofline's come from a separate pass with one tail stream (same batch, same kernels, HIP events).
+        # the roofline's come from a separate pass through a one-slot pipeline (same batch, same kernels, HIP events).
         # (a small share -- a few milliseconds per pass -- gains from a third tail stream and a fourth pass in flight; 65 536 does not)
         args.tail_streams = (3 if small_share else 2) if family == "stwo" else 1
     timed_pipe = verifier.Pipeline(slots, tail_streams=args.tail_streams) if args.tail_streams > 1 else pipe
@@ -740,6 +740,18 @@ def main() -> None:
         if grouped and lazy:
             (p or pipe).flush(reduce_accepts)
 
+    def own_durations():
+        """The kernels' OWN durations for the roofline, where the timed region overlaps launches (two or more tail streams,
+        independent streams, graph replays): up to 20 passes through a ONE-slot pipeline -- HEAD, then TAIL, then the next
+        pass -- so that nothing shares the chip with a kernel while HIP events on its stream time it."""
+        iso = verifier.Pipeline(slots[:1])
+        ver.set_timing(True)
+        ver.collect_timing()
+        for i in range(min(args.steps, 20)):
+            step(i, iso)
+        flush(iso)
+        torch.cuda.synchronize()
+
     for i in range(args.warmup):
         step(i)
     flush()
@@ -767,12 +779,7 @@ def main() -> None:
         elapsed = time.perf_counter() - t0
         assert all(s.accepted() == n_local for s in islots), "independent streams: not every proof accepted"
         graphed = True  # (for the reporting below: per-kernel durations come from the eager pass)
-        ver.set_timing(True)
-        ver.collect_timing()
-        for i in range(min(args.steps, 20)):
-            step(i)
-        flush()
-        torch.cuda.synchronize()
+        own_durations()
         timing = ver.collect_timing()
         ver.set_timing(False)
     elif graphed:
@@ -793,12 +800,7 @@ def main() -> None:
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         assert all(s.accepted() == n_local for s in gslots[:S]), "graphed pass: not every proof accepted"
-        ver.set_timing(True)
-        ver.collect_timing()
-        for i in range(min(args.steps, 20)):
-            step(i)
-        flush()
-        torch.cuda.synchronize()
+        own_durations()
         timing = ver.collect_timing()
         ver.set_timing(False)
     else:
@@ -821,13 +823,8 @@ def main() -> None:
         if grouped:
             dist.barrier()
         elapsed = time.perf_counter() - t0
-        if overlapped:  # Merkle launches overlapped at their edges: their durations come from a pass where they do not
-            ver.set_timing(True)
-            ver.collect_timing()
-            for i in range(min(args.steps, 20)):
-                step(i)
-            flush()
-            torch.cuda.synchronize()
+        if overlapped:  # the Merkle stages of consecutive passes overlap: their durations come from a pass where nothing does
+            own_durations()
         timing = ver.collect_timing()
         ver.set_timing(False)
     if grouped:
@@ -918,10 +915,11 @@ def main() -> None:
                          # (below the sum of the two kernels' own durations when consecutive launches overlap)
                          "launch_period_ms": elapsed / args.steps * 1e3,
                          "achieved_per_launch_period": launch_bytes / (elapsed / args.steps) / 1e9,
-                         "durations_from": ("a separate pass with one tail stream after the timed region (HIP events on the launch "
-                                            "stream): launches of the timed region overlap, a kernel's duration there is not its own")
-                         if (family == "stwo" and args.tail_streams > 1 and not streams and not graphed) else
-                         "HIP events on the launch stream",
+                         "durations_from": ("up to 20 passes through a one-slot pipeline after the timed region (HIP events on the launch "
+                                            "stream; nothing else on the chip): launches of the timed region overlap, a kernel's duration "
+                                            "there is not its own")
+                         if (streams or graphed or (family == "stwo" and args.tail_streams > 1)) else
+                         "HIP events on the launch stream, in the timed region",
                          "algorithmic_bytes_per_launch": launch_bytes,
                          "note": "integer-ALU bound by construction (2 SHA-256 / 1 Blake2s compression "
                                  "per 32-byte sibling); see alu_roofline"},

@@ -79,8 +79,8 @@ cd /tmp; export TMPDIR=/tmp
 if want stats; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline --e2e 0 > $O/stats.log 2>&1; ok stats
   # the default submission overlaps consecutive launches of the Merkle stage (two tail streams): a kernel's duration in that trace is
-  # not its own.  The roofline's durations come from a pass with ONE tail stream -- this is the rocprof twin of that pass.
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_ts1 -- python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline --e2e 0 --tail-streams 1 > $O/stats_ts1.log 2>&1; ok stats_ts1
+  # not its own.  The roofline's durations come from a pass through a ONE-slot pipeline (nothing overlaps) -- this is its rocprof twin.
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_ts1 -- python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline --e2e 0 --tail-streams 1 --inflight 1 > $O/stats_ts1.log 2>&1; ok stats_ts1
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_e2e -- python3 $R/tools/e2e_bench.py --n 4096 --reps 2 --fmt all > $O/stats_e2e.log 2>&1
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_prover -- python3 $R/tools/prover_bench.py 20 3 sha256 > $O/stats_prover.log 2>&1
 fi
