@@ -21,7 +21,7 @@ def pytest_configure(config):
 # collected LAST start about forty of them.  Tests marked `launcher_extra` repeat a launch shape another test already covers
 # (4 ranks beside 2, 3 beside 2, hipGraph beside independent streams, two nccl ranks on one card): once the session has run
 # longer than this they are skipped with the reason spelled out, so a slow box ends green and inside the limit instead of being killed.
-SLOW_SESSION_S = float(os.environ.get("SS_TEST_SLOW_SESSION_S", "480"))
+SLOW_SESSION_S = float(os.environ.get("SS_TEST_SLOW_SESSION_S", "420"))
 _session_t0 = None
 
 
