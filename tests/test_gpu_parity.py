@@ -550,6 +550,23 @@ def test_replicated_batch_built_on_the_device_equals_the_host_pack(ver, stwo_pro
 
 
 # ---------------------------------------------------------- `simfony run` shim
+def _cli_here(*args):
+    """The same command through cli.main() in THIS process (stdout / stderr captured): the exit status is main()'s return
+    value.  A new python process per case costs seconds (twenty each on a slow box); the process-level contract itself is
+    checked by the cases that go through _cli."""
+    import contextlib
+    import io
+    import types
+    from stark_symphony_amd import cli
+    out, err = io.StringIO(), io.StringIO()
+    with contextlib.redirect_stdout(out), contextlib.redirect_stderr(err):
+        try:
+            rc = cli.main(["verify", *args])
+        except SystemExit as e:  # argparse
+            rc = e.code
+    return types.SimpleNamespace(returncode=rc, stdout=out.getvalue(), stderr=err.getvalue())
+
+
 def _cli(*args):
     import os
     import subprocess
@@ -574,13 +591,13 @@ def test_cli_verify_exit_status_contract(tmp_path):
     assert r.returncode == 0 and "ACCEPT" in r.stdout and r.stderr == "", r.stderr
     r = _cli("--family", "stwo", "--witness", os.path.join(F, "stwo_proof.wit"))  # production = default
     assert r.returncode == 0 and "ACCEPT" in r.stdout, r.stderr
-    r = _cli("--family", "stwo", "--config", "testing", "--witness", os.path.join(F, "stwo_proof_test.wit"))
+    r = _cli_here("--family", "stwo", "--config", "testing", "--witness", os.path.join(F, "stwo_proof_test.wit"))
     assert r.returncode == 0, r.stderr
-    r = _cli("--family", "stwo", "--proof", os.path.join(GOLDEN, "stwo_proof.json"),
+    r = _cli_here("--family", "stwo", "--proof", os.path.join(GOLDEN, "stwo_proof.json"),
              os.path.join(GOLDEN, "stwo_proof.json"))
     assert r.returncode == 0 and r.stdout.count("ACCEPT") == 2
     # the test-config proof where production is enforced: shape mismatch = typing failure = exit 1
-    r = _cli("--family", "stwo", "--witness", os.path.join(F, "stwo_proof_test.wit"))
+    r = _cli_here("--family", "stwo", "--witness", os.path.join(F, "stwo_proof_test.wit"))
     assert r.returncode == 1 and r.stderr.startswith("Error: Failed to run program") and "ACCEPT" not in r.stdout
     # one flipped bit in a committed root of the stark101 witness
     wit = json.load(open(os.path.join(F, "stark101_proof.wit")))
@@ -591,15 +608,15 @@ def test_cli_verify_exit_status_contract(tmp_path):
     r = _cli("--family", "stark101", "--witness", str(bad))
     assert r.returncode == 1 and r.stderr.startswith("Error: Failed to run program"), (r.stdout, r.stderr)
     # accepted and rejected inputs together: every verdict is printed, exit 1
-    r = _cli("--family", "stark101", "--witness", os.path.join(F, "stark101_proof.wit"), str(bad))
+    r = _cli_here("--family", "stark101", "--witness", os.path.join(F, "stark101_proof.wit"), str(bad))
     assert r.returncode == 1 and r.stdout.count("ACCEPT") == 1 and "REJECT" in r.stderr
     # literal mode = the .simf text, which rejects the repo's own proof at the first FRI decommitment
-    r = _cli("--family", "stwo", "--mode", "literal", "--witness", os.path.join(F, "stwo_proof.wit"))
+    r = _cli_here("--family", "stwo", "--mode", "literal", "--witness", os.path.join(F, "stwo_proof.wit"))
     assert r.returncode == 1 and "0x07000001" in r.stderr
     # malformed witness / missing file: exit 1, nothing verified
     junk = tmp_path / "junk.wit"
     junk.write_text("{\"P_MT_ROOT\": {\"value\": \"(1, 2\", \"type\": \"u256\"}}")
-    assert _cli("--family", "stark101", "--witness", str(junk)).returncode == 1
+    assert _cli_here("--family", "stark101", "--witness", str(junk)).returncode == 1
     assert _cli("--family", "stwo", "--witness", str(tmp_path / "absent.wit")).returncode == 1
 
 

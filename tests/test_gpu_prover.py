@@ -141,17 +141,32 @@ def test_cli_prove_writes_what_the_reference_flow_writes(tmp_path):
     import subprocess
     F = os.path.join(GOLDEN, "formats")
 
-    def cli(*args):
+    def cli_process(*args):
         return subprocess.run([sys.executable, "-m", "stark_symphony_amd.cli", *args], cwd=ROOT, capture_output=True,
                               text=True, timeout=600)
-    r = cli("prove", "--family", "stark101")
+
+    def cli(*args):
+        """the same command through cli.main() in this process: a new python process per case costs seconds (twenty each on
+        a slow box); the first prove and the first verify below go through real processes"""
+        import contextlib
+        import io
+        import types
+        from stark_symphony_amd import cli as C_
+        out, err = io.StringIO(), io.StringIO()
+        with contextlib.redirect_stdout(out), contextlib.redirect_stderr(err):
+            try:
+                rc = C_.main(list(args))
+            except SystemExit as e:
+                rc = e.code
+        return types.SimpleNamespace(returncode=rc, stdout=out.getvalue(), stderr=err.getvalue())
+    r = cli_process("prove", "--family", "stark101")
     assert r.returncode == 0, r.stderr
     assert json.loads(r.stdout) == json.load(open(os.path.join(GOLDEN, "stark101_proof.json")))
     wit = tmp_path / "proof.wit"
     r = cli("prove", "--family", "stark101", "--to", "wit", "--out", str(wit))
     assert r.returncode == 0 and r.stdout == "", r.stderr
     assert wit.read_text() == open(os.path.join(F, "stark101_proof.wit")).read()
-    assert cli("verify", "--family", "stark101", "--witness", str(wit)).returncode == 0
+    assert cli_process("verify", "--family", "stark101", "--witness", str(wit)).returncode == 0
     r = cli("prove", "--family", "stwo")  # defaults = the sizes of tests/data/proof.json
     assert r.returncode == 0 and json.loads(r.stdout) == json.load(open(os.path.join(GOLDEN, "stwo_proof.json"))), r.stderr
     r = cli("prove", "--family", "stwo", "--trace-log", "3", "--log-blowup", "1", "--n-queries", "1", "--to", "wit")
