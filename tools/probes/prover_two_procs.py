@@ -24,8 +24,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     print("%f %f %d" % (t0, time.time(), n), flush=True)
     sys.exit(0)
 
-for procs, workers in ((1, 4), (1, 6), (2, 2), (2, 3), (2, 4), (3, 2), (1, 4)):
-    n = 96 // procs
+COMBOS = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]] or [(1, 4), (1, 6), (2, 2), (2, 3), (2, 4), (3, 2), (1, 4)]
+for procs, workers in COMBOS:
+    n = 96 // procs if procs != 5 else 20
     start_at = time.time() + 25.0
     ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "child", str(workers), str(n), str(start_at)],
                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(procs)]
